@@ -1,0 +1,152 @@
+/*
+ * nmfx.h -- C ABI of the MI355X-native NMF solver engine (libnmfx.so).
+ *
+ * The reference (raleng/nmf) is pure Python and has no FFI of its own; its
+ * boundary is the Python call surface NMF(data, k).factorize(method=...) and the
+ * four solver functions it forwards to.  This header is the native boundary a
+ * maintainer would bind (ctypes stub in INTEGRATION.md) to replace the bodies of
+ * those solver loops.  Each entry point names the reference lines it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain C, opaque handle, plain pointers and sizes; no torch / numpy types.
+ *  - host matrices are C-contiguous row-major like the reference's ndarrays.
+ *    Factors cross the boundary as float64 (the reference's dtype for W/H,
+ *    nmf/utils.py:51-52); the engine computes in float32 on MFMA and keeps
+ *    objective sums in float64.
+ *  - every function returns 0 or a negative NMFX_E_* code; nmfx_last_error()
+ *    gives the message.  One handle = one device + one stream; a handle is not
+ *    thread-safe, independent handles are.
+ *  - the caller owns all host buffers, the library owns all device buffers
+ *    (except exchange buffers handed in with nmfx_set_exchange_buffers).
+ *  - device-side control flow: a stop flag in device memory is set by the
+ *    engine when the reference's convergence_check (nmf/utils.py:4-15) fires;
+ *    all later launches become no-ops, so iterations can be queued in batches
+ *    without a host round trip per iteration.
+ */
+#ifndef NMFX_H
+#define NMFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmfx_engine* nmfx_handle_t;
+
+enum {
+    NMFX_OK = 0,
+    NMFX_E_ARG = -1,     /* bad argument / unsupported shape (k > 128)            */
+    NMFX_E_HIP = -2,     /* HIP runtime error, no device                          */
+    NMFX_E_NOTPD = -3,   /* Gram + rho I not positive definite (scipy LinAlgError, nmf/ao_admm.py:55) */
+    NMFX_E_STATE = -4,   /* call sequence error (no V uploaded, no factors set)   */
+    NMFX_E_NOMEM = -5
+};
+
+enum { NMFX_F32 = 0, NMFX_F64 = 1 };                 /* host dtype of V          */
+enum { NMFX_EU = 0, NMFX_KL = 1 };                   /* distance_type            */
+enum { NMFX_PROX_NN = 0, NMFX_PROX_L1N = 1, NMFX_PROX_L2N = 2 };  /* reg type   */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* m, n: rows/cols of the LOCAL block of V held by this handle (all of V on one
+ * GPU; a row shard when the caller shards rows over ranks).  k <= 128.        */
+int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k);
+int nmfx_destroy(nmfx_handle_t h);
+const char* nmfx_last_error(nmfx_handle_t h);        /* h may be NULL            */
+int nmfx_version(void);
+int nmfx_device_count(void);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of
+ * the handle's own stream; NULL restores the internal one.                    */
+int nmfx_set_stream(nmfx_handle_t h, void* hip_stream);
+int nmfx_synchronize(nmfx_handle_t h);
+
+/* ---- data --------------------------------------------------------------- */
+/* Copy rows [row0, row0+rows) of the local V from host memory (row stride `ld`
+ * elements, dtype NMFX_F32/F64).  V is borrowed, never modified (the MUR shift
+ * of negative data, nmf/mur.py:99-101, is done by the caller on its array).   */
+int nmfx_upload_v(nmfx_handle_t h, const void* host, int dtype, int64_t ld,
+                  int64_t row0, int64_t rows);
+/* W (m x k) and H (k x n), float64 row-major; either may be NULL to skip.
+ * set_factors also zeroes all dual/auxiliary state and the iteration state.   */
+int nmfx_set_factors(nmfx_handle_t h, const double* w, const double* hmat);
+int nmfx_get_factors(nmfx_handle_t h, double* w, double* hmat);
+/* Other state matrices by name: "dual_w" "dual_h" (AO-ADMM / ADMM),
+ * "w_aux" "h_aux" (ADMM).  Shapes as W / H.                                   */
+int nmfx_get_matrix(nmfx_handle_t h, const char* name, double* out);
+
+/* ---- iteration state ---------------------------------------------------- */
+/* stop_rule: 0 running, 1 / 2 = which branch of convergence_check fired
+ * (nmf/utils.py:8-11); stop_i: the reference's loop index `i` at which it
+ * fired; n_obj: number of objective values recorded so far (obj[0] is the
+ * objective of the initial factors, nmf/mur.py:115).                           */
+int nmfx_get_state(nmfx_handle_t h, int* stop_rule, int64_t* stop_i, int64_t* n_obj);
+int nmfx_get_objectives(nmfx_handle_t h, int64_t first, int64_t count, double* out);
+
+/* ---- MUR (replaces the loop body nmf/mur.py:119-131) -------------------- */
+/* Queue `count` outer iterations starting at iteration `first` (= number of
+ * iterations already run on this handle).  Iteration j computes, like
+ * mur.py:122-127: W <- w_update (mur.py:20-33), H <- h_update with the new W
+ * (mur.py:36-49), objective of the result (utils.py:18-33), and the
+ * convergence check for `i = j` when j > min_iter (mur.py:131).  Asynchronous;
+ * read results with nmfx_get_state / nmfx_get_objectives (they synchronise).  */
+int nmfx_mur_run(nmfx_handle_t h, int distance, double lambda_w, double lambda_h,
+                 int64_t min_iter, double tol1, double tol2,
+                 int64_t first, int64_t count);
+/* Complete the objective/convergence bookkeeping of the last queued iteration
+ * (the engine evaluates the objective of iteration j inside the first kernel
+ * of iteration j+1; this runs that evaluation alone).                         */
+int nmfx_mur_finish(nmfx_handle_t h, int distance, int64_t min_iter, double tol1,
+                    double tol2, int64_t iters_done);
+
+/* Row-sharded form: phase A = everything up to the rank-local partial sums
+ * [W^T V | W^T W | objective], phase B = H update from the (all-reduced) sums.
+ * Between the two the caller sum-all-reduces the exchange buffers over ranks
+ * (RCCL via torch.distributed, see nmf_amd/dist.py).                          */
+int nmfx_mur_phase_a(nmfx_handle_t h, int distance, double lambda_w, int64_t j);
+int nmfx_mur_phase_b(nmfx_handle_t h, int distance, double lambda_h,
+                     int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_mur_finish_a(nmfx_handle_t h, int distance, int64_t j);
+int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
+
+/* Exchange buffers: f32 part = [W^T V (kp x n_pad) | W^T W (kp x kp)] (+ KL:
+ * column sums of W), f64 part = [objective partial, 3 spare].  Sizes in
+ * elements.  The caller may supply its own device allocations (e.g. torch
+ * tensors, so that torch.distributed can all-reduce them in place).           */
+int nmfx_exchange_sizes(nmfx_handle_t h, int64_t* n_f32, int64_t* n_f64);
+int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, void* dev_f64);
+int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
+
+/* ---- AO-ADMM (replaces nmf/ao_admm.py:259-301) -------------------------- */
+/* One call queues `count` outer iterations: H sub-problem then W sub-problem
+ * (admm_ls_update, ao_admm.py:46-68: Gram, rho = trace/k, Cholesky, up to
+ * admm_iter rounds of solve / prox / dual update with the `terminate` test of
+ * ao_admm.py:33-43 evaluated on the device), objective, convergence check.
+ * inner counts per outer iteration are readable with nmfx_get_inner_counts.   */
+int nmfx_aoadmm_run(nmfx_handle_t h, int distance, int prox_w, double lambda_w,
+                    int prox_h, double lambda_h, int admm_iter,
+                    int64_t min_iter, double tol1, double tol2,
+                    int64_t first, int64_t count);
+int nmfx_get_inner_counts(nmfx_handle_t h, int64_t first, int64_t count, int32_t* out_pairs);
+
+/* ---- ADMM (replaces nmf/admm.py:292-334) -------------------------------- */
+int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double lambda_w,
+                  int prox_h, double lambda_h, int64_t min_iter, double tol1,
+                  double tol2, int64_t first, int64_t count);
+
+/* ---- ANLS (replaces nmf/anls.py:111-122) -------------------------------- */
+int nmfx_anls_run(nmfx_handle_t h, double lambda_w, double lambda_h,
+                  int64_t min_iter, double tol1, double tol2,
+                  int64_t first, int64_t count);
+
+/* ---- measurement -------------------------------------------------------- */
+/* Accumulated device time (HIP events on the handle's stream) and launch count
+ * of a named kernel since the last reset; names: "wphase" "hphase" ...        */
+int nmfx_profile_enable(nmfx_handle_t h, int on);
+int nmfx_profile_get(nmfx_handle_t h, const char* name, double* total_ms, int64_t* launches);
+int nmfx_profile_reset(nmfx_handle_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMFX_H */

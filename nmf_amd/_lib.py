@@ -1,0 +1,98 @@
+"""ctypes binding of libnmfx.so (the C ABI declared in include/nmfx.h).
+
+The library is the product's only compute path: if it is missing or no MI355X
+is visible, loading fails loudly -- there is no CPU fallback in this package.
+"""
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnmfx.so")
+
+NMFX_OK, NMFX_E_ARG, NMFX_E_HIP, NMFX_E_NOTPD, NMFX_E_STATE, NMFX_E_NOMEM = 0, -1, -2, -3, -4, -5
+F32, F64 = 0, 1
+EU, KL = 0, 1
+PROX = {"nn": 0, "l1n": 1, "l2n": 2}
+
+_i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
+_pd = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/nmfx.h one to one
+SIGNATURES = {
+    "nmfx_create": (_i32, [C.POINTER(_vp), _i32, _i64, _i64, _i32]),
+    "nmfx_destroy": (_i32, [_vp]),
+    "nmfx_last_error": (C.c_char_p, [_vp]),
+    "nmfx_version": (_i32, []),
+    "nmfx_device_count": (_i32, []),
+    "nmfx_set_stream": (_i32, [_vp, _vp]),
+    "nmfx_synchronize": (_i32, [_vp]),
+    "nmfx_upload_v": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64]),
+    "nmfx_set_factors": (_i32, [_vp, _vp, _vp]),
+    "nmfx_get_factors": (_i32, [_vp, _vp, _vp]),
+    "nmfx_get_matrix": (_i32, [_vp, C.c_char_p, _vp]),
+    "nmfx_get_state": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_get_objectives": (_i32, [_vp, _i64, _i64, _vp]),
+    "nmfx_mur_run": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_mur_finish": (_i32, [_vp, _i32, _i64, _dbl, _dbl, _i64]),
+    "nmfx_mur_phase_a": (_i32, [_vp, _i32, _dbl, _i64]),
+    "nmfx_mur_phase_b": (_i32, [_vp, _i32, _dbl, _i64, _dbl, _dbl, _i64]),
+    "nmfx_mur_finish_a": (_i32, [_vp, _i32, _i64]),
+    "nmfx_mur_finish_b": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
+    "nmfx_exchange_sizes": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),
+    "nmfx_get_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "nmfx_aoadmm_run": (_i32, [_vp, _i32, _i32, _dbl, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_get_inner_counts": (_i32, [_vp, _i64, _i64, _vp]),
+    "nmfx_admm_run": (_i32, [_vp, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_anls_run": (_i32, [_vp, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_profile_enable": (_i32, [_vp, _i32]),
+    "nmfx_profile_get": (_i32, [_vp, C.c_char_p, _pd, C.POINTER(_i64)]),
+    "nmfx_profile_reset": (_i32, [_vp]),
+}
+
+_lib = None
+
+
+class NmfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libnmfx error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """dlopen libnmfx.so once.  When torch is installed it is imported first so
+    that both share ONE HIP runtime (torch bundles its own libamdhip64.so.7;
+    loading ours first would map a second copy and break pointer sharing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m nmf_amd.build` "
+            "(hipcc, gfx950).  nmf_amd has no CPU fallback.")
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None \
+            and os.environ.get("NMF_AMD_NO_TORCH") != "1":
+        import torch  # noqa: F401  (ordering only)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc == NMFX_OK:
+        return
+    msg = load().nmfx_last_error(handle)
+    raise NmfxError(rc, msg.decode() if msg else "")
+
+
+def require_gpu():
+    lib = load()
+    if lib.nmfx_device_count() <= 0:
+        raise RuntimeError("nmf_amd: no HIP device visible; the solvers run only on an "
+                           "MI355X (gfx950) and there is no CPU fallback")
+    return lib

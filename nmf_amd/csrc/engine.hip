@@ -1,0 +1,423 @@
+// C ABI of libnmfx.so: handle lifecycle, data movement, iteration state.
+#include "nmfx_internal.h"
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <tuple>
+
+int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
+int nmfx_mur_eu_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_mur_eu_finish_a(nmfx_engine* E, int64_t j);
+int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_mur_kl_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
+int nmfx_mur_kl_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j);
+
+static thread_local std::string g_err;
+
+static int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+__global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t n, float* __restrict__ dst,
+                                    int64_t ldd, int64_t rows)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c < n && r < rows) dst[r * ldd + c] = (float)src[r * n + c];
+}
+
+__global__ void init_state_kernel(DevState* st) {
+    st->flag = 0; st->stop_i = -1; st->n_obj = 0; st->obj_prev = 0.0;
+    st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0;
+}
+
+template <typename T>
+static int dev_alloc(nmfx_engine* E, T** p, int64_t count) {
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T)));
+    NMFX_HIP(hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), E->stream));
+    return NMFX_OK;
+}
+
+static int ensure_obj_capacity(nmfx_engine* E, int64_t need) {
+    if (need <= E->obj_cap) return NMFX_OK;
+    int64_t cap = E->obj_cap ? E->obj_cap : 4096;
+    while (cap < need) cap *= 2;
+    double* nbuf = nullptr;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&nbuf), (size_t)cap * sizeof(double)));
+    NMFX_HIP(hipMemsetAsync(nbuf, 0, (size_t)cap * sizeof(double), E->stream));
+    if (E->obj_hist) {
+        NMFX_HIP(hipMemcpyAsync(nbuf, E->obj_hist, (size_t)E->obj_cap * sizeof(double),
+                                hipMemcpyDeviceToDevice, E->stream));
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+        NMFX_HIP(hipFree(E->obj_hist));
+    }
+    E->obj_hist = nbuf;
+    E->obj_cap = cap;
+    return NMFX_OK;
+}
+
+int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need) {
+    if (need <= E->inner_cap) return NMFX_OK;
+    int64_t cap = E->inner_cap ? E->inner_cap : 4096;
+    while (cap < need) cap *= 2;
+    int32_t* nbuf = nullptr;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&nbuf), (size_t)cap * 2 * sizeof(int32_t)));
+    NMFX_HIP(hipMemsetAsync(nbuf, 0, (size_t)cap * 2 * sizeof(int32_t), E->stream));
+    if (E->inner_hist) {
+        NMFX_HIP(hipMemcpyAsync(nbuf, E->inner_hist, (size_t)E->inner_cap * 2 * sizeof(int32_t),
+                                hipMemcpyDeviceToDevice, E->stream));
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+        NMFX_HIP(hipFree(E->inner_hist));
+    }
+    E->inner_hist = nbuf;
+    E->inner_cap = cap;
+    return NMFX_OK;
+}
+
+extern "C" {
+
+int nmfx_version(void) { return 100; }
+
+int nmfx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* nmfx_last_error(nmfx_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
+    if (!out) { g_err = "out is NULL"; return NMFX_E_ARG; }
+    *out = nullptr;
+    if (m <= 0 || n <= 0 || k <= 0) { g_err = "m, n, k must be positive"; return NMFX_E_ARG; }
+    if (k > 128) { g_err = "k > 128 is not supported by this build"; return NMFX_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device"; return NMFX_E_HIP; }
+    if (device < 0 || device >= ndev) { g_err = "device index out of range"; return NMFX_E_ARG; }
+    nmfx_engine* E = new nmfx_engine();
+    E->device = device; E->m = m; E->n = n; E->k = k;
+    E->kp = k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 128;
+    E->mp = round_up(m, NMFX_TILE); E->np = round_up(n, NMFX_TILE);
+    auto fail = [&](int rc) { g_err = E->err; nmfx_destroy(E); return rc; };
+#define TRY(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { E->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(NMFX_E_HIP); } } while (0)
+    TRYHIP(hipSetDevice(device));
+    TRYHIP(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
+    E->stream = E->own_stream;
+    // split configuration: enough workgroups to fill 256 CUs twice over
+    const int64_t rb = E->mp / 64, cb = E->np / 64;
+    int64_t ws = (512 + rb - 1) / rb; ws = std::max<int64_t>(1, std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4)));
+    int64_t hs = (512 + cb - 1) / cb; hs = std::max<int64_t>(1, std::min<int64_t>(hs, rb));
+    int64_t gs = std::min<int64_t>(32, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));
+    E->wsplit = (int)ws; E->hsplit = (int)hs; E->gsplit = (int)gs;
+    const int64_t kp = E->kp, mp = E->mp, np = E->np;
+    TRY(dev_alloc(E, &E->V, mp * np));
+    TRY(dev_alloc(E, &E->W[0], mp * kp));
+    TRY(dev_alloc(E, &E->W[1], mp * kp));
+    TRY(dev_alloc(E, &E->H, kp * np));
+    TRY(dev_alloc(E, &E->HHt, kp * kp));
+    TRY(dev_alloc(E, &E->HHt_part, gs * kp * kp));
+    TRY(dev_alloc(E, &E->G_part, gs * kp * kp));
+    TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
+    TRY(dev_alloc(E, &E->B_part, hs * kp * np));
+    TRY(dev_alloc(E, &E->obj_part, std::max<int64_t>(rb * ws, cb * hs) + 64));
+    TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp));
+    TRY(dev_alloc(E, &E->xf64, 4));
+    TRY(dev_alloc(E, &E->state, 1));
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
+    TRY(ensure_obj_capacity(E, 4096));
+    TRYHIP(hipStreamSynchronize(E->stream));
+#undef TRY
+#undef TRYHIP
+    *out = E;
+    return NMFX_OK;
+}
+
+int nmfx_destroy(nmfx_handle_t E) {
+    if (!E) return NMFX_OK;
+    hipSetDevice(E->device);
+    if (E->stream) hipStreamSynchronize(E->stream);
+    for (auto& t : E->prof_pending) { hipEventDestroy(std::get<1>(t)); hipEventDestroy(std::get<2>(t)); }
+    void* bufs[] = {E->V, E->W[0], E->W[1], E->H, E->HHt, E->HHt_part, E->G_part, E->A_part, E->B_part,
+                    E->obj_part, E->own_x ? (void*)E->xf32 : nullptr, E->own_x ? (void*)E->xf64 : nullptr,
+                    E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
+                    E->inner_hist};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (E->own_stream) hipStreamDestroy(E->own_stream);
+    delete E;
+    return NMFX_OK;
+}
+
+int nmfx_set_stream(nmfx_handle_t E, void* s) {
+    if (!E) return NMFX_E_ARG;
+    hipStreamSynchronize(E->stream);
+    E->stream = s ? reinterpret_cast<hipStream_t>(s) : E->own_stream;
+    return NMFX_OK;
+}
+
+int nmfx_synchronize(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int64_t row0, int64_t rows) {
+    if (!E) return NMFX_E_ARG;
+    if (!host || row0 < 0 || rows < 0 || row0 + rows > E->m || ld < E->n) {
+        E->err = "upload_v: bad row range or leading dimension"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    if (rows == 0) return NMFX_OK;
+    float* dst = E->V + row0 * E->np;
+    if (dtype == NMFX_F32) {
+        NMFX_HIP(hipMemcpy2DAsync(dst, (size_t)E->np * 4, host, (size_t)ld * 4, (size_t)E->n * 4,
+                                  (size_t)rows, hipMemcpyHostToDevice, E->stream));
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+    } else if (dtype == NMFX_F64) {
+        const int64_t chunk = std::max<int64_t>(1, (int64_t)(64 << 20) / (E->n * 8));
+        double* stage = nullptr;
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&stage), (size_t)std::min(chunk, rows) * E->n * 8));
+        const double* src = static_cast<const double*>(host);
+        for (int64_t r = 0; r < rows; r += chunk) {
+            const int64_t cnt = std::min(chunk, rows - r);
+            hipError_t e = hipMemcpy2DAsync(stage, (size_t)E->n * 8, src + r * ld, (size_t)ld * 8,
+                                            (size_t)E->n * 8, (size_t)cnt, hipMemcpyHostToDevice, E->stream);
+            if (e != hipSuccess) { hipFree(stage); E->err = hipGetErrorString(e); return NMFX_E_HIP; }
+            dim3 grid((unsigned)((E->n + 255) / 256), (unsigned)cnt);
+            hipLaunchKernelGGL(cvt_f64_rows_kernel, grid, dim3(256), 0, E->stream, stage, E->n,
+                               dst + r * E->np, E->np, cnt);
+            e = hipStreamSynchronize(E->stream);
+            if (e != hipSuccess) { hipFree(stage); E->err = hipGetErrorString(e); return NMFX_E_HIP; }
+        }
+        hipFree(stage);
+    } else { E->err = "upload_v: dtype must be NMFX_F32 or NMFX_F64"; return NMFX_E_ARG; }
+    if (row0 + rows == E->m || true) E->have_v = true;
+    return NMFX_OK;
+}
+
+static int put_padded(nmfx_engine* E, float* dst, const double* src, int64_t rows, int64_t cols,
+                      int64_t prow, int64_t pcol) {
+    std::vector<float> tmp((size_t)prow * pcol, 0.f);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) tmp[(size_t)r * pcol + c] = (float)src[r * cols + c];
+    NMFX_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+static int get_padded(nmfx_engine* E, const float* src, double* dst, int64_t rows, int64_t cols,
+                      int64_t prow, int64_t pcol) {
+    std::vector<float> tmp((size_t)prow * pcol);
+    NMFX_HIP(hipMemcpyAsync(tmp.data(), src, tmp.size() * 4, hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) dst[r * cols + c] = (double)tmp[(size_t)r * pcol + c];
+    return NMFX_OK;
+}
+
+int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if (w) {
+        if ((rc = put_padded(E, E->W[0], w, E->m, E->k, E->mp, E->kp))) return rc;
+        NMFX_HIP(hipMemsetAsync(E->W[1], 0, (size_t)E->mp * E->kp * 4, E->stream));
+    }
+    if (hmat) { if ((rc = put_padded(E, E->H, hmat, E->k, E->n, E->kp, E->np))) return rc; }
+    float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH};
+    const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np};
+    for (int i = 0; i < 4; ++i)
+        if (zero[i]) NMFX_HIP(hipMemsetAsync(zero[i], 0, (size_t)zc[i] * 4, E->stream));
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
+    E->wsel = 0;
+    E->have_f = true;
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+static int read_state(nmfx_engine* E, DevState* hs) {
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipMemcpyAsync(hs, E->state, sizeof(DevState), hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+int nmfx_get_factors(nmfx_handle_t E, double* w, double* hmat) {
+    if (!E) return NMFX_E_ARG;
+    DevState hs; int rc;
+    if ((rc = read_state(E, &hs))) return rc;
+    if (hs.flag) E->wsel = (int)((hs.stop_i + 1) & 1);
+    if (w) { if ((rc = get_padded(E, E->W[E->wsel], w, E->m, E->k, E->mp, E->kp))) return rc; }
+    if (hmat) { if ((rc = get_padded(E, E->H, hmat, E->k, E->n, E->kp, E->np))) return rc; }
+    return NMFX_OK;
+}
+
+int nmfx_get_matrix(nmfx_handle_t E, const char* name, double* out) {
+    if (!E || !name || !out) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    const std::string s(name);
+    const float* src = nullptr; bool wlike = false;
+    if (s == "dual_w") { src = E->dualW; wlike = true; }
+    else if (s == "dual_h") { src = E->dualH; }
+    else if (s == "w_aux") { src = E->auxW; wlike = true; }
+    else if (s == "h_aux") { src = E->auxH; }
+    else { E->err = "get_matrix: unknown name"; return NMFX_E_ARG; }
+    if (!src) { E->err = "get_matrix: matrix not allocated for this solver"; return NMFX_E_STATE; }
+    return wlike ? get_padded(E, src, out, E->m, E->k, E->mp, E->kp)
+                 : get_padded(E, src, out, E->k, E->n, E->kp, E->np);
+}
+
+int nmfx_get_state(nmfx_handle_t E, int* stop_rule, int64_t* stop_i, int64_t* n_obj) {
+    if (!E) return NMFX_E_ARG;
+    DevState hs; int rc;
+    if ((rc = read_state(E, &hs))) return rc;
+    if (hs.notpd) { E->err = "Gram + rho I is not positive definite"; return NMFX_E_NOTPD; }
+    if (stop_rule) *stop_rule = hs.flag;
+    if (stop_i) *stop_i = hs.stop_i;
+    if (n_obj) *n_obj = hs.n_obj;
+    // the iterate the reference would return: W_{stop_i+1} once stopped
+    if (hs.flag) E->wsel = (int)((hs.stop_i + 1) & 1);
+    return NMFX_OK;
+}
+
+int nmfx_get_objectives(nmfx_handle_t E, int64_t first, int64_t count, double* out) {
+    if (!E || !out || first < 0 || count < 0 || first + count > E->obj_cap) {
+        if (E) E->err = "get_objectives: range"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    if (count == 0) return NMFX_OK;
+    NMFX_HIP(hipMemcpyAsync(out, E->obj_hist + first, (size_t)count * 8, hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+int nmfx_get_inner_counts(nmfx_handle_t E, int64_t first, int64_t count, int32_t* out) {
+    if (!E || !out || first < 0 || count < 0 || first + count > E->inner_cap) {
+        if (E) E->err = "get_inner_counts: range"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    if (count == 0) return NMFX_OK;
+    NMFX_HIP(hipMemcpyAsync(out, E->inner_hist + first * 2, (size_t)count * 8, hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+// ---- exchange buffers ----------------------------------------------------
+int nmfx_exchange_sizes(nmfx_handle_t E, int64_t* n_f32, int64_t* n_f64) {
+    if (!E) return NMFX_E_ARG;
+    if (n_f32) *n_f32 = (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp;
+    if (n_f64) *n_f64 = 4;
+    return NMFX_OK;
+}
+
+int nmfx_set_exchange_buffers(nmfx_handle_t E, void* f32, void* f64) {
+    if (!E || !f32 || !f64) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    if (E->own_x) { hipFree(E->xf32); hipFree(E->xf64); }
+    E->xf32 = static_cast<float*>(f32); E->xf64 = static_cast<double*>(f64); E->own_x = false;
+    return NMFX_OK;
+}
+
+int nmfx_get_exchange_buffers(nmfx_handle_t E, void** f32, void** f64) {
+    if (!E) return NMFX_E_ARG;
+    if (f32) *f32 = E->xf32;
+    if (f64) *f64 = E->xf64;
+    return NMFX_OK;
+}
+
+// ---- MUR -------------------------------------------------------------------
+static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    return ensure_obj_capacity(E, first + count + 2);
+}
+
+int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    if (distance == NMFX_EU) return nmfx_mur_eu_phase_a(E, lambda_w, j);
+    if (distance == NMFX_KL) return nmfx_mur_kl_phase_a(E, lambda_w, j);
+    E->err = "Unknown distance type."; return NMFX_E_ARG;
+}
+
+int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min_iter, double tol1,
+                     double tol2, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    E->wsel = (int)((j + 1) & 1);
+    if (distance == NMFX_EU) return nmfx_mur_eu_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
+    if (distance == NMFX_KL) return nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
+    E->err = "Unknown distance type."; return NMFX_E_ARG;
+}
+
+int nmfx_mur_finish_a(nmfx_handle_t E, int distance, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    if (distance == NMFX_EU) return nmfx_mur_eu_finish_a(E, j);
+    if (distance == NMFX_KL) return nmfx_mur_kl_finish_a(E, j);
+    E->err = "Unknown distance type."; return NMFX_E_ARG;
+}
+
+int nmfx_mur_finish_b(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    return nmfx_finish_b(E, min_iter, tol1, tol2, j);
+}
+
+int nmfx_mur_run(nmfx_handle_t E, int distance, double lambda_w, double lambda_h, int64_t min_iter,
+                 double tol1, double tol2, int64_t first, int64_t count) {
+    if (!E) return NMFX_E_ARG;
+    int rc = check_ready(E, first, count); if (rc) return rc;
+    for (int64_t j = first; j < first + count; ++j) {
+        if ((rc = nmfx_mur_phase_a(E, distance, lambda_w, j))) return rc;
+        if ((rc = nmfx_mur_phase_b(E, distance, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    }
+    return NMFX_OK;
+}
+
+int nmfx_mur_finish(nmfx_handle_t E, int distance, int64_t min_iter, double tol1, double tol2,
+                    int64_t iters_done) {
+    int rc;
+    if ((rc = nmfx_mur_finish_a(E, distance, iters_done))) return rc;
+    return nmfx_mur_finish_b(E, min_iter, tol1, tol2, iters_done);
+}
+
+// ---- profiling -------------------------------------------------------------
+static void drain_profile(nmfx_engine* E) {
+    if (E->prof_pending.empty()) return;
+    hipStreamSynchronize(E->stream);
+    for (auto& t : E->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, std::get<1>(t), std::get<2>(t)) == hipSuccess) {
+            ProfSlot& s = E->prof_slots[std::get<0>(t)];
+            s.ms += ms; s.n += 1;
+        }
+        hipEventDestroy(std::get<1>(t)); hipEventDestroy(std::get<2>(t));
+    }
+    E->prof_pending.clear();
+}
+
+int nmfx_profile_enable(nmfx_handle_t E, int on) {
+    if (!E) return NMFX_E_ARG;
+    drain_profile(E);
+    E->prof = on != 0;
+    return NMFX_OK;
+}
+
+int nmfx_profile_get(nmfx_handle_t E, const char* name, double* total_ms, int64_t* launches) {
+    if (!E || !name) return NMFX_E_ARG;
+    drain_profile(E);
+    auto it = E->prof_slots.find(name);
+    if (total_ms) *total_ms = it == E->prof_slots.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == E->prof_slots.end() ? 0 : it->second.n;
+    return NMFX_OK;
+}
+
+int nmfx_profile_reset(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    drain_profile(E);
+    E->prof_slots.clear();
+    return NMFX_OK;
+}
+
+}  // extern "C"

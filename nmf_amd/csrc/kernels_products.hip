@@ -1,0 +1,449 @@
+// V-sized contractions of the NMF hot path, hand-written for gfx950.
+//
+//   wphase : A = V H^T  (m x k, contraction over n)  [+ fused residual objective]
+//            reference: `x @ h.T` nmf/mur.py:29, `w.T @ y` on transposes
+//            nmf/ao_admm.py:56,265; objective nmf/utils.py:29.
+//   hphase : B = W^T V  (k x n, contraction over m)
+//            reference: `w.T @ x` nmf/mur.py:45, nmf/ao_admm.py:56.
+//   gram   : W^T W, H H^T (k x k)   reference: nmf/ao_admm.py:53, and the
+//            reassociated `wh @ h.T` = W (H H^T), `w.T @ wh` = (W^T W) H of
+//            nmf/mur.py:29,45.
+//
+// All use v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).  The operand maps are
+//   A-operand lane l: A[i = l&15][kk = l>>4],  B-operand: B[kk = l>>4][j = l&15],
+//   C/D: D[row = 4*(l>>4) + reg][col = l&15].
+// Because a contraction may visit its index in any order, each lane feeds the
+// four elements of ONE 16-byte load to four consecutive MFMA k-steps (wphase) or
+// to four different output tiles (hphase); both operands use the same
+// permutation, so every global/LDS access is a full dwordx4.
+#include "nmfx_internal.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// XOR swizzle of the 16-byte slot inside a 64-float LDS row; conflict-free for
+// both read patterns of wphase (derivation in DESIGN.md, "H tile image").
+__device__ __forceinline__ int swz(int row) {
+    const int r = row & 15;
+    return r ^ ((((r >> 2) ^ (r >> 3)) & 1) << 2);
+}
+
+// --------------------------------------------------------------------------
+// wphase: one block = 64 rows (4 waves x 16 rows) x column groups [g0, g1).
+// Per 64-column group a wave holds its 16x64 slice of V in 16 VGPRs (loaded
+// straight from HBM, read exactly once), the H tile [KP][64] is shared through
+// LDS (double buffered).
+//   A-product : acc[jt] += V(16x64) . Htile^T         -> A[16][KP]
+//   D-product : d[e]    = (W Htile) transposed tiles  -> residual V - W H
+// The D tiles come out of the MFMA in exactly the register layout the V slice
+// already has (row on lane&15, column 16q+4reg+e), so the residual needs no
+// data movement.
+// --------------------------------------------------------------------------
+template <int KP, bool WITH_A, bool WITH_OBJ>
+__global__ __launch_bounds__(256) void wphase_kernel(
+    const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
+    const float* __restrict__ H, int64_t ldh, float* __restrict__ Apart,
+    double* __restrict__ objpart, int64_t mp, int ngroups, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int JT = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x KP x 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, q = lane >> 4;
+    const int S = gridDim.y, sp = blockIdx.y;
+    const int g0 = (int)((int64_t)ngroups * sp / S);
+    const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    const float* vrow = V + (r0 + x) * ldv + 16 * q;
+
+    float4 wf[JT];
+#pragma unroll
+    for (int u = 0; u < JT; ++u)
+        wf[u] = *reinterpret_cast<const float4*>(W + (r0 + x) * KP + 16 * u + 4 * q);
+
+    f32x4 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double osum = 0.0;
+
+    // staging map: thread -> (row = 16 p + tid/16, 16-byte column chunk tid%16)
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const int sdst = srow * 64 + 4 * (sc4 ^ swz(srow));
+    const float* hsrc = H + (int64_t)srow * ldh + 4 * sc4;
+    // read maps
+    const int gx = swz(x);                 // A-product: rows jt*16 + x
+    int dslot[4];                          // D-product: rows 16u + 4q + s
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dslot[s] = (4 * q + s) * 64 + 4 * (x ^ swz(4 * q + s));
+
+    float4 hn[JT], vf[4], vn[4];
+    if (g0 < g1) {
+#pragma unroll
+        for (int p = 0; p < JT; ++p)
+            hn[p] = *reinterpret_cast<const float4*>(hsrc + (int64_t)p * 16 * ldh + (int64_t)g0 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            vf[i] = *reinterpret_cast<const float4*>(vrow + (int64_t)g0 * 64 + 4 * i);
+#pragma unroll
+        for (int p = 0; p < JT; ++p)
+            *reinterpret_cast<float4*>(lds + p * 16 * 64 + sdst) = hn[p];
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int g = g0; g < g1; ++g) {
+        const bool more = (g + 1 < g1);
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < JT; ++p)
+                hn[p] = *reinterpret_cast<const float4*>(hsrc + (int64_t)p * 16 * ldh + (int64_t)(g + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                vn[i] = *reinterpret_cast<const float4*>(vrow + (int64_t)(g + 1) * 64 + 4 * i);
+        }
+        const float* buf = lds + cur * (KP * 64);
+
+        if (WITH_A) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 hb = *reinterpret_cast<const float4*>(
+                        buf + (jt * 16 + x) * 64 + 4 * ((4 * q + i) ^ gx));
+                    acc[jt] = MFMA(vf[i].x, hb.x, acc[jt]);
+                    acc[jt] = MFMA(vf[i].y, hb.y, acc[jt]);
+                    acc[jt] = MFMA(vf[i].z, hb.z, acc[jt]);
+                    acc[jt] = MFMA(vf[i].w, hb.w, acc[jt]);
+                }
+            }
+        }
+        if (WITH_OBJ) {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
+#pragma unroll
+            for (int u = 0; u < JT; ++u) {
+                const float wv[4] = {wf[u].x, wf[u].y, wf[u].z, wf[u].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float4 ha = *reinterpret_cast<const float4*>(buf + u * 16 * 64 + dslot[s]);
+                    d0 = MFMA(ha.x, wv[s], d0);
+                    d1 = MFMA(ha.y, wv[s], d1);
+                    d2 = MFMA(ha.z, wv[s], d2);
+                    d3 = MFMA(ha.w, wv[s], d3);
+                }
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rx = vf[i].x - d0[i], ry = vf[i].y - d1[i];
+                const float rz = vf[i].z - d2[i], rw = vf[i].w - d3[i];
+                part += rx * rx + ry * ry + rz * rz + rw * rw;
+            }
+            osum += (double)part;
+        }
+        if (more) {
+            float* nb = lds + (cur ^ 1) * (KP * 64);
+#pragma unroll
+            for (int p = 0; p < JT; ++p)
+                *reinterpret_cast<float4*>(nb + p * 16 * 64 + sdst) = hn[p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf[i] = vn[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (WITH_A) {
+        float* out = Apart + ((int64_t)sp * mp + r0) * KP;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(int64_t)(4 * q + r) * KP + jt * 16 + x] = acc[jt][r];
+    }
+    if (WITH_OBJ) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
+        double* red = reinterpret_cast<double*>(lds);      // all tile reads are done
+        if (lane == 0) red[wave] = osum;
+        __syncthreads();
+        if (tid == 0)
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] =
+                0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    }
+}
+
+// --------------------------------------------------------------------------
+// hphase: one block = 64 columns x the rows of split sr; its 4 waves take a
+// quarter of those rows each and are summed through LDS in a fixed order
+// (run-to-run bit-stable).  Per k-step (4 rows) a lane loads 16 B of V
+// (4 rows x 256 B per wave instruction) and KP/16 dwords of W (L2-resident).
+// Output tile e of the MFMA holds columns 4x+e, so one lane owns 4 adjacent
+// columns of a B row and stores them as one dwordx4.
+// --------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void hphase_kernel(
+    const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
+    float* __restrict__ Bpart, int64_t np, int64_t mp, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int JT = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // KP*4*64 floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, q = lane >> 4;
+    const int SR = gridDim.y, sr = blockIdx.y;
+    const int64_t n16 = mp / 16;                       // 16-row units
+    const int64_t u0 = n16 * sr / SR, u1 = n16 * (sr + 1) / SR;
+    const int64_t steps = (u1 - u0) * 4;               // 4-row k-steps in this split
+    const int64_t s0 = steps * wave / 4, s1 = steps * (wave + 1) / 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const float* vp = V + (u0 * 16 + s0 * 4 + q) * ldv + c0 + 4 * x;
+    const float* wp = W + (u0 * 16 + s0 * 4 + q) * KP + x;
+
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int UN = 4;                              // k-steps per software-pipeline stage
+    float4 vb[UN], vbn[UN];
+    float wa[UN][JT], wan[UN][JT];
+    int64_t s = s0;
+    const int64_t sfull = s0 + ((s1 - s0) / UN) * UN;
+    if (s < sfull) {
+#pragma unroll
+        for (int t = 0; t < UN; ++t) {
+            vb[t] = *reinterpret_cast<const float4*>(vp + (int64_t)t * 4 * ldv);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) wa[t][j] = wp[(int64_t)t * 4 * KP + 16 * j];
+        }
+    }
+    for (; s < sfull; s += UN) {
+        const bool more = (s + UN < sfull);
+        if (more) {
+            const float* vq = vp + (int64_t)UN * 4 * ldv;
+            const float* wq = wp + (int64_t)UN * 4 * KP;
+#pragma unroll
+            for (int t = 0; t < UN; ++t) {
+                vbn[t] = *reinterpret_cast<const float4*>(vq + (int64_t)t * 4 * ldv);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) wan[t][j] = wq[(int64_t)t * 4 * KP + 16 * j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < UN; ++t) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                acc[j][0] = MFMA(wa[t][j], vb[t].x, acc[j][0]);
+                acc[j][1] = MFMA(wa[t][j], vb[t].y, acc[j][1]);
+                acc[j][2] = MFMA(wa[t][j], vb[t].z, acc[j][2]);
+                acc[j][3] = MFMA(wa[t][j], vb[t].w, acc[j][3]);
+            }
+        }
+        vp += (int64_t)UN * 4 * ldv;
+        wp += (int64_t)UN * 4 * KP;
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < UN; ++t) {
+                vb[t] = vbn[t];
+#pragma unroll
+                for (int j = 0; j < JT; ++j) wa[t][j] = wan[t][j];
+            }
+        }
+    }
+    for (; s < s1; ++s) {                               // remainder k-steps
+        const float4 v1 = *reinterpret_cast<const float4*>(vp);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const float a = wp[16 * j];
+            acc[j][0] = MFMA(a, v1.x, acc[j][0]);
+            acc[j][1] = MFMA(a, v1.y, acc[j][1]);
+            acc[j][2] = MFMA(a, v1.z, acc[j][2]);
+            acc[j][3] = MFMA(a, v1.w, acc[j][3]);
+        }
+        vp += 4 * ldv;
+        wp += 4 * KP;
+    }
+
+    // cross-wave sum in wave order 0,1,2,3 (each lane owns its LDS words)
+    float4* red = reinterpret_cast<float4*>(lds);      // [JT*4][64] float4
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            if (w == 0) {
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(j * 4 + r) * 64 + lane] =
+                            make_float4(acc[j][0][r], acc[j][1][r], acc[j][2][r], acc[j][3][r]);
+            } else if (w < 3) {
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float4 t = red[(j * 4 + r) * 64 + lane];
+                        t.x += acc[j][0][r]; t.y += acc[j][1][r]; t.z += acc[j][2][r]; t.w += acc[j][3][r];
+                        red[(j * 4 + r) * 64 + lane] = t;
+                    }
+            } else {
+                float* out = Bpart + (int64_t)sr * KP * np + c0 + 4 * x;
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float4 t = red[(j * 4 + r) * 64 + lane];
+                        t.x += acc[j][0][r]; t.y += acc[j][1][r]; t.z += acc[j][2][r]; t.w += acc[j][3][r];
+                        *reinterpret_cast<float4*>(out + (int64_t)(16 * j + 4 * q + r) * np) = t;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
+// Gram kernels (k x k outputs; tiny next to the V-sized products).  One wave
+// per block; block (split s, tile row jt) writes rows [16 jt, 16 jt + 16) of
+// its partial Gram matrix.
+// --------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(64) void gram_tn_kernel(     // X^T X, X [rows][KP]
+    const float* __restrict__ X, int64_t rows, float* __restrict__ out, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int JT = KP / 16;
+    const int lane = threadIdx.x, x = lane & 15, q = lane >> 4;
+    const int S = gridDim.x, s = blockIdx.x, jt = blockIdx.y;
+    const int64_t n4 = rows / 4;
+    const int64_t t0 = n4 * s / S, t1 = n4 * (s + 1) / S;
+    f32x4 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* p = X + (t0 * 4 + q) * KP + x;
+    for (int64_t t = t0; t < t1; ++t, p += 4 * KP) {
+        const float a = p[16 * jt];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = MFMA(a, p[16 * j], acc[j]);
+    }
+    float* o = out + (int64_t)s * KP * KP;
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o[(int64_t)(16 * jt + 4 * q + r) * KP + 16 * j + x] = acc[j][r];
+}
+
+template <int KP>
+__global__ __launch_bounds__(64) void gram_nt_kernel(     // X X^T, X [KP][ld]
+    const float* __restrict__ X, int64_t cols, int64_t ld, float* __restrict__ out,
+    const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int JT = KP / 16;
+    const int lane = threadIdx.x, x = lane & 15, q = lane >> 4;
+    const int S = gridDim.x, s = blockIdx.x, jt = blockIdx.y;
+    const int64_t n16 = cols / 16;
+    const int64_t t0 = n16 * s / S, t1 = n16 * (s + 1) / S;
+    f32x4 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* p = X + (int64_t)x * ld + t0 * 16 + 4 * q;
+    for (int64_t t = t0; t < t1; ++t, p += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)16 * jt * ld);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)16 * j * ld);
+            acc[j] = MFMA(a.x, b.x, acc[j]);
+            acc[j] = MFMA(a.y, b.y, acc[j]);
+            acc[j] = MFMA(a.z, b.z, acc[j]);
+            acc[j] = MFMA(a.w, b.w, acc[j]);
+        }
+    }
+    float* o = out + (int64_t)s * KP * KP;
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o[(int64_t)(16 * jt + 4 * q + r) * KP + 16 * j + x] = acc[j][r];
+}
+
+// --------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------
+template <int KP>
+static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj) {
+    dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
+    const size_t shm = (size_t)2 * KP * 64 * sizeof(float);
+    const int ng = (int)(E->np / 64);
+#define NMFX_WLAUNCH(A, O)                                                                  \
+    hipLaunchKernelGGL((wphase_kernel<KP, A, O>), grid, block, shm, E->stream, E->V, E->np, W, \
+                       E->H, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag)
+    if (with_a && with_obj) NMFX_WLAUNCH(true, true);
+    else if (with_a) NMFX_WLAUNCH(true, false);
+    else NMFX_WLAUNCH(false, true);
+#undef NMFX_WLAUNCH
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj) {
+    ProfScope ps(E, with_a ? (with_obj ? "wphase" : "wphase_noobj") : "objective");
+    switch (E->kp) {
+        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj);
+        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj);
+        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj);
+        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj);
+    }
+    E->err = "unsupported padded rank";
+    return NMFX_E_ARG;
+}
+
+template <int KP>
+static int hphase_dispatch(nmfx_engine* E, const float* W) {
+    dim3 grid((unsigned)(E->np / 64), (unsigned)E->hsplit), block(256);
+    const size_t shm = (size_t)KP * 4 * 64 * sizeof(float);
+    hipLaunchKernelGGL((hphase_kernel<KP>), grid, block, shm, E->stream, E->V, E->np, W,
+                       E->B_part, E->np, E->mp, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_launch_hphase(nmfx_engine* E, const float* W) {
+    ProfScope ps(E, "hphase");
+    switch (E->kp) {
+        case 16: return hphase_dispatch<16>(E, W);
+        case 32: return hphase_dispatch<32>(E, W);
+        case 64: return hphase_dispatch<64>(E, W);
+        case 128: return hphase_dispatch<128>(E, W);
+    }
+    E->err = "unsupported padded rank";
+    return NMFX_E_ARG;
+}
+
+int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out, int splits) {
+    ProfScope ps(E, "gram_tn");
+    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(64);
+    switch (E->kp) {
+        case 16: hipLaunchKernelGGL((gram_tn_kernel<16>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
+        case 32: hipLaunchKernelGGL((gram_tn_kernel<32>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
+        case 64: hipLaunchKernelGGL((gram_tn_kernel<64>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
+        case 128: hipLaunchKernelGGL((gram_tn_kernel<128>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
+        default: E->err = "unsupported padded rank"; return NMFX_E_ARG;
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld, float* out, int splits) {
+    ProfScope ps(E, "gram_nt");
+    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(64);
+    switch (E->kp) {
+        case 16: hipLaunchKernelGGL((gram_nt_kernel<16>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;
+        case 32: hipLaunchKernelGGL((gram_nt_kernel<32>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;
+        case 64: hipLaunchKernelGGL((gram_nt_kernel<64>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;
+        case 128: hipLaunchKernelGGL((gram_nt_kernel<128>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;
+        default: E->err = "unsupported padded rank"; return NMFX_E_ARG;
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}

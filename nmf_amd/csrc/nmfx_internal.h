@@ -1,0 +1,95 @@
+// Internal declarations shared by the translation units of libnmfx.so.
+// gfx950 only: 64-lane wavefronts, f32-input MFMA (v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/nmfx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Geometry of the padded device layout.  All big kernels are written without
+// bounds checks: V is stored zero-padded to multiples of 64 in both dimensions
+// and the factor rank is padded to KP in {16, 32, 64, 128}.  Zero padding is a
+// fixed point of every update rule implemented here ("padding").
+#define NMFX_TILE 64
+
+struct DevState {          // lives in device memory, written by kernels
+    int flag;              // 0 running, 1/2 = convergence_check branch (utils.py:8-11)
+    int pad0;
+    long long stop_i;      // reference loop index at which the check fired
+    long long n_obj;       // objectives recorded
+    double obj_prev;       // obj[j-1]
+    // AO-ADMM inner loop
+    int inner_stop;        // set when `terminate` (ao_admm.py:33-43) fires
+    int inner_count;       // inner iterations executed in the current sub-problem
+    int notpd;             // Cholesky hit a non-positive pivot
+    int pad1;
+    double rho;            // trace(G)/k of the current sub-problem
+};
+
+struct ProfSlot { double ms = 0; int64_t n = 0; };
+
+struct nmfx_engine {
+    int device = 0;
+    int64_t m = 0, n = 0;          // logical local shape
+    int k = 0, kp = 0;             // logical / padded rank
+    int64_t mp = 0, np = 0;        // padded shape (multiples of 64)
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // device buffers
+    float* V = nullptr;            // [mp][np]
+    float* W[2] = {nullptr, nullptr};   // [mp][kp], double buffered
+    float* H = nullptr;            // [kp][np]
+    float* HHt = nullptr;          // [kp][kp]
+    float* HHt_part = nullptr;     // [gram_splits][kp][kp]
+    float* G_part = nullptr;       // [gram_splits][kp][kp]
+    float* A_part = nullptr;       // [wsplit][mp][kp]
+    float* B_part = nullptr;       // [hsplit][kp][np]
+    double* obj_part = nullptr;    // [max blocks]
+    float* xf32 = nullptr;         // exchange: [kp*np | kp*kp | kp]
+    double* xf64 = nullptr;        // exchange: [4]
+    bool own_x = true;
+    double* obj_hist = nullptr;    // device, capacity obj_cap
+    int64_t obj_cap = 0;
+    DevState* state = nullptr;
+    // AO-ADMM / ADMM state
+    float* dualW = nullptr; float* dualH = nullptr;     // like W / H
+    float* auxW = nullptr;  float* auxH = nullptr;
+    float* Minv = nullptr;         // [kp][kp] (G + rho I)^-1
+    double* nrm_part = nullptr;    // [blocks][4]
+    int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
+    // split configuration
+    int wsplit = 1, hsplit = 1, gsplit = 1;
+    bool have_v = false, have_f = false;
+    int wsel = 0;                  // W buffer holding the current iterate
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfSlot> prof_slots;
+    std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> prof_pending;
+    std::string err;
+};
+
+#define NMFX_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    E->err = std::string(#expr) + ": " + hipGetErrorString(e_); return NMFX_E_HIP; } } while (0)
+
+// ---- launch helpers implemented in the kernel translation units ---------
+// A_part[sp] = V(rows, cols of split sp) * H^T ; optionally the residual
+// objective 0.5*sum (V - W H)^2 into obj_part (one double per block).
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj);
+// B_part[sr] = W^T V over the rows of split sr.
+int nmfx_launch_hphase(nmfx_engine* E, const float* W);
+// out_part[s] = X^T X  (X [rows][kp])  /  X X^T (X [kp][cols])
+int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out_part, int splits);
+int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld, float* out_part, int splits);
+
+struct ProfScope {
+    nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    ProfScope(nmfx_engine* e, const char* nm) : E(e), name(nm) {
+        if (E->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, E->stream); }
+    }
+    ~ProfScope() {
+        if (E->prof) { (void)hipEventRecord(b, E->stream); E->prof_pending.emplace_back(name, a, b); }
+    }
+};

@@ -1,0 +1,152 @@
+"""Thin object wrapper over the C handle (include/nmfx.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One device-resident factorisation problem: V (or a row shard of it), W, H
+    and all scratch live in HBM for the lifetime of the object."""
+
+    def __init__(self, m, n, k, device=0):
+        self.lib = L.require_gpu()
+        self.m, self.n, self.k = int(m), int(n), int(k)
+        h = C.c_void_p()
+        L.check(self.lib.nmfx_create(C.byref(h), int(device), self.m, self.n, self.k))
+        self.h = h
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmfx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        L.check(rc, self.h)
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.nmfx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.nmfx_synchronize(self.h))
+
+    # -- data --------------------------------------------------------------
+    def upload_v(self, v, row0=0):
+        v = np.asarray(v)
+        if v.dtype not in (np.float32, np.float64):
+            v = v.astype(np.float64)
+        if v.ndim != 2 or v.shape[1] != self.n:
+            raise ValueError("V block has the wrong shape")
+        if not (v.strides[1] == v.itemsize and v.strides[0] % v.itemsize == 0 and v.strides[0] > 0):
+            v = np.ascontiguousarray(v)
+        ld = v.strides[0] // v.itemsize
+        self._ck(self.lib.nmfx_upload_v(self.h, _ptr(v), L.F32 if v.dtype == np.float32 else L.F64,
+                                        ld, int(row0), v.shape[0]))
+
+    def set_factors(self, w, h):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        if w.shape != (self.m, self.k) or h.shape != (self.k, self.n):
+            raise ValueError("factor shapes do not match the engine")
+        self._ck(self.lib.nmfx_set_factors(self.h, _ptr(w), _ptr(h)))
+
+    def get_factors(self):
+        w = np.empty((self.m, self.k), dtype=np.float64)
+        h = np.empty((self.k, self.n), dtype=np.float64)
+        self._ck(self.lib.nmfx_get_factors(self.h, _ptr(w), _ptr(h)))
+        return w, h
+
+    def get_matrix(self, name):
+        wlike = name in ("dual_w", "w_aux")
+        out = np.empty((self.m, self.k) if wlike else (self.k, self.n), dtype=np.float64)
+        self._ck(self.lib.nmfx_get_matrix(self.h, name.encode(), _ptr(out)))
+        return out
+
+    # -- state -------------------------------------------------------------
+    def state(self):
+        rule, stop_i, n_obj = C.c_int(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_get_state(self.h, C.byref(rule), C.byref(stop_i), C.byref(n_obj)))
+        return rule.value, stop_i.value, n_obj.value
+
+    def objectives(self, first, count):
+        out = np.empty(int(count), dtype=np.float64)
+        if count:
+            self._ck(self.lib.nmfx_get_objectives(self.h, int(first), int(count), _ptr(out)))
+        return out
+
+    def inner_counts(self, first, count):
+        out = np.zeros((int(count), 2), dtype=np.int32)
+        if count:
+            self._ck(self.lib.nmfx_get_inner_counts(self.h, int(first), int(count), _ptr(out)))
+        return out
+
+    # -- solvers -----------------------------------------------------------
+    def mur_run(self, dist, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
+        self._ck(self.lib.nmfx_mur_run(self.h, dist, float(lambda_w), float(lambda_h), int(min_iter),
+                                       float(tol1), float(tol2), int(first), int(count)))
+
+    def mur_finish(self, dist, min_iter, tol1, tol2, iters_done):
+        self._ck(self.lib.nmfx_mur_finish(self.h, dist, int(min_iter), float(tol1), float(tol2),
+                                          int(iters_done)))
+
+    def mur_phase_a(self, dist, lambda_w, j):
+        self._ck(self.lib.nmfx_mur_phase_a(self.h, dist, float(lambda_w), int(j)))
+
+    def mur_phase_b(self, dist, lambda_h, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_mur_phase_b(self.h, dist, float(lambda_h), int(min_iter), float(tol1),
+                                           float(tol2), int(j)))
+
+    def mur_finish_a(self, dist, j):
+        self._ck(self.lib.nmfx_mur_finish_a(self.h, dist, int(j)))
+
+    def mur_finish_b(self, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_mur_finish_b(self.h, int(min_iter), float(tol1), float(tol2), int(j)))
+
+    def aoadmm_run(self, dist, prox_w, lam_w, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, first, count):
+        self._ck(self.lib.nmfx_aoadmm_run(self.h, dist, prox_w, float(lam_w), prox_h, float(lam_h),
+                                          int(admm_iter), int(min_iter), float(tol1), float(tol2),
+                                          int(first), int(count)))
+
+    def admm_run(self, dist, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, first, count):
+        self._ck(self.lib.nmfx_admm_run(self.h, dist, float(rho), prox_w, float(lam_w), prox_h,
+                                        float(lam_h), int(min_iter), float(tol1), float(tol2),
+                                        int(first), int(count)))
+
+    def anls_run(self, lam_w, lam_h, min_iter, tol1, tol2, first, count):
+        self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
+                                        float(tol2), int(first), int(count)))
+
+    # -- exchange buffers (row-sharded runs) ---------------------------------
+    def exchange_sizes(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_exchange_sizes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_exchange_buffers(self, f32_ptr, f64_ptr):
+        self._ck(self.lib.nmfx_set_exchange_buffers(self.h, C.c_void_p(f32_ptr), C.c_void_p(f64_ptr)))
+
+    # -- measurement -------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(self.lib.nmfx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self.lib.nmfx_profile_reset(self.h))
+
+    def profile_get(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.lib.nmfx_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,87 @@
+"""Host-side utilities of the reference API surface (nmf/utils.py).
+
+Only `nndsvd` (initialisation, SURVEY 2b K21: host LAPACK, not on the
+per-iteration path) and `save_results` (the .npz on-disk format) live on the
+host.  The per-iteration objective and the convergence test run on the device
+(csrc/kernels_small.h); `convergence_message` only reproduces the reference's
+stdout line for a stop rule the device already decided.
+"""
+import os
+
+import numpy as np
+
+QUIET = os.environ.get("NMF_AMD_QUIET", "0") == "1"
+
+
+def say(*a):
+    if not QUIET:
+        print(*a)
+
+
+def convergence_message(rule):
+    """stdout of nmf/utils.py:8-11 for stop rule 1 or 2."""
+    if rule in (1, 2):
+        say('Algorithm converged ({}).'.format(rule))
+
+
+def tol_digits(tol1, tol2):
+    """Decimal places of the per-iteration print (nmf/mur.py:93-95)."""
+    tol = min(tol1, tol2)
+    return int(format(tol, 'e').split('-')[1]) if tol < 1 else 2
+
+
+def nndsvd(x, rank=None, variant='zero'):
+    """SVD based initialisation (Boutsidis & Gallopoulos), same call signature
+    and RNG consumption as nmf/utils.py:36-93.  Returns float64 (w, h)."""
+    u, s, vt = np.linalg.svd(x, full_matrices=False)
+    if rank is None:
+        rank = x.shape[1]
+    w = np.zeros((x.shape[0], rank))
+    h = np.zeros((rank, x.shape[1]))
+    root = np.sqrt(s[:rank])
+    w[:, 0] = root[0] * np.abs(u[:, 0])
+    h[0, :] = root[0] * np.abs(vt[0, :])
+    for c in range(1, rank):
+        col, row = u[:, c], vt[c, :]
+        cp, cn = np.maximum(col, 0), np.maximum(-col, 0)
+        rp, rn = np.maximum(row, 0), np.maximum(-row, 0)
+        ncp, ncn = np.linalg.norm(cp), np.linalg.norm(cn)
+        nrp, nrn = np.linalg.norm(rp), np.linalg.norm(rn)
+        if ncp * nrp >= ncn * nrn:
+            scale = np.sqrt(s[c] * ncp * nrp)
+            w[:, c], h[c, :] = scale / ncp * cp, scale / nrp * rp
+        else:
+            scale = np.sqrt(s[c] * ncn * nrn)
+            w[:, c], h[c, :] = scale / ncn * cn, scale / nrn * rn
+    if variant == 'mean':
+        mu = np.mean(x)
+        w[w == 0] = mu
+        h[h == 0] = mu
+    elif variant == 'random':
+        mu = np.mean(x)
+        fill = mu * np.random.random_sample(w.shape) / 100
+        w = np.where(w == 0, fill, w)
+        fill = mu * np.random.random_sample(h.shape) / 100
+        h = np.where(h == 0, fill, h)
+    return w, h
+
+
+def initial_factors(x, k, nndsvd_init, uniform=False):
+    """W then H from the GLOBAL numpy RNG in the reference's order
+    (nmf/mur.py:105-109, nmf/ao_admm.py:19-23, nmf/admm.py:20-24 use |randn|;
+    nmf/anls.py:101-105 uses rand), so identical seeds give identical starts."""
+    if nndsvd_init[0]:
+        return nndsvd(x, k, variant=nndsvd_init[1])
+    if uniform:
+        w = np.random.rand(x.shape[0], k)
+        h = np.random.rand(k, x.shape[1])
+    else:
+        w = np.abs(np.random.randn(x.shape[0], k))
+        h = np.abs(np.random.randn(k, x.shape[1]))
+    return w, h
+
+
+def save_results(save_str, w, h, i, obj_history, experiment):
+    """Same .npz keys as nmf/utils.py:96-105 (w, h, i, obj_history, experiment)."""
+    np.savez(save_str, w=w, h=h, i=i, obj_history=obj_history, experiment=experiment)
+    say('Results saved in {}.'.format(save_str))

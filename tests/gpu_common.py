@@ -1,0 +1,37 @@
+"""Helpers for the GPU parity tests (HIP path vs oracle / golden fixtures)."""
+import numpy as np
+
+from conftest import fix_kwargs, load_golden
+from oracle import nmf_ref as R
+
+WH_TOL = 1e-4     # north_star: ||W_g H_g - W_r H_r||_F / ||V||_F < 1e-4
+
+
+def wh_error(w, h, w_ref, h_ref, v):
+    return np.linalg.norm(w @ h - w_ref @ h_ref) / np.linalg.norm(np.asarray(v, dtype=np.float64))
+
+
+def run_fixture(name, solver, **override):
+    z, meta = load_golden(name)
+    v = R.fixture_matrix(meta["vspec"])
+    kw = fix_kwargs(meta["kwargs"])
+    kw.update(override)
+    np.random.seed(meta["seed"])
+    res = solver(v, meta["k"], **kw)
+    return z, meta, v, res
+
+
+def snapshot_errors(name, solver):
+    """WH error after 1, 2, 10 ... iterations (localises a divergence)."""
+    z, meta = load_golden(name)
+    out = {}
+    for key in z.files:
+        if key.startswith("snap") and key.endswith("_w"):
+            s = int(key[4:-2])
+            v = R.fixture_matrix(meta["vspec"])
+            kw = fix_kwargs(meta["kwargs"])
+            kw.update(max_iter=s, min_iter=s + 5)
+            np.random.seed(meta["seed"])
+            res = solver(v, meta["k"], **kw)
+            out[s] = wh_error(res.w, res.h, z[f"snap{s}_w"], z[f"snap{s}_h"], v)
+    return out

@@ -1,0 +1,57 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what
+include/nmfx.h declares; the product path refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from nmf_amd import _lib
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "nmfx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nmfx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in nmfx.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.nmfx_version() >= 100
+
+
+def test_error_codes_without_device():
+    lib = _lib.load()
+    if lib.nmfx_device_count() > 0:
+        pytest.skip("GPU present")
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.nmfx_create(C.byref(h), 0, 8, 8, 2) == _lib.NMFX_E_HIP
+    assert lib.nmfx_create(C.byref(h), 0, 8, 8, 500) == _lib.NMFX_E_ARG
+    assert b"k > 128" in lib.nmfx_last_error(None)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    lib = _lib.load()
+    if lib.nmfx_device_count() > 0:
+        pytest.skip("GPU present")
+    from nmf_amd import NMF
+    v = np.random.RandomState(0).rand(16, 12)
+    for method, kw in (("mur", dict(distance_type="eu", max_iter=2)),):
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            NMF(v, 3).factorize(method=method, **kw)
+
+
+def test_unknown_method_and_distance_raise_like_reference():
+    from nmf_amd import NMF
+    v = np.random.RandomState(0).rand(16, 12)
+    with pytest.raises(Exception, match="Method not known"):      # nmf/nmf.py:76
+        NMF(v, 3).factorize(method="nope")
+    with pytest.raises(KeyError):                                   # nmf/utils.py:31
+        NMF(v, 3).factorize(method="mur", distance_type="xx")

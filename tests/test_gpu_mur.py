@@ -1,0 +1,71 @@
+"""MUR on the HIP engine vs the reference's golden outputs and the oracle.
+Runs only on a real MI355X (`-m gpu`); everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
+from oracle import nmf_ref as R
+
+pytestmark = pytest.mark.gpu
+
+OBJ_RTOL = 2e-4   # f32 MFMA factors vs the f64 reference, objective summed in f64
+
+EU = ["mur_eu_cfg1_random", "mur_eu_cfg1_nndsvdz", "mur_eu_lambda", "mur_eu_f32v",
+      "mur_eu_signed", "mur_eu_ragged"]
+
+
+@pytest.mark.parametrize("name", EU)
+def test_mur_eu_matches_reference(name):
+    from nmf_amd.mur import mur
+    z, meta, v, res = run_fixture(name, mur)
+    assert res.w.dtype == np.float64 and res.h.dtype == np.float64
+    assert res.i == int(z["i"]) and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, z["w"], z["h"], v)
+    snaps = snapshot_errors(name, mur) if err >= WH_TOL else {}
+    assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=OBJ_RTOL)
+    assert (res.w >= 0).all() and (res.h >= 0).all()
+    assert res.experiment.method == "mur" and res.experiment.components == meta["k"]
+    # the in-place lift of negative data (mur.py:99-101) happened on OUR array too
+    assert np.isclose(np.asarray(v, dtype=np.float64).sum(), float(z["v_after_sum"]), rtol=1e-6)
+
+
+def test_mur_eu_stops_at_the_reference_iteration():
+    from nmf_amd.mur import mur
+    z, meta, v, res = run_fixture("mur_eu_converge", mur)
+    assert int(z["stop_rule"]) == 2
+    assert res.i == int(z["i"]), (res.i, int(z["i"]))
+    assert len(res.obj_history) == res.i + 2
+    assert wh_error(res.w, res.h, z["w"], z["h"], v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=OBJ_RTOL)
+
+
+def test_class_api_sets_w_h_and_saves(tmp_path, capsys):
+    from nmf_amd import NMF
+    v = R.planted_matrix(96, 80, 4, seed=3, dtype=np.float64)
+    np.random.seed(0)
+    model = NMF(v, 4)
+    model.factorize(method="mur", distance_type="eu", min_iter=5, max_iter=5)
+    out = capsys.readouterr().out
+    assert "[4]: " in out and "Factorization done." in out
+    assert model.w is model.results.w and model.h.shape == (4, 80)
+    model.save_factorization(save_dir=str(tmp_path))
+    saved = np.load(tmp_path / "nmf_mur_4_eu_0.0_0.0_random.npz", allow_pickle=True)
+    assert sorted(saved.files) == ["experiment", "h", "i", "obj_history", "w"]
+    np.random.seed(0)
+    ref = R.mur(v.copy(), 4, distance_type="eu", min_iter=5, max_iter=5)
+    assert wh_error(model.w, model.h, ref.w, ref.h, v) < WH_TOL
+
+
+def test_large_shape_properties():
+    """At a size the oracle cannot follow: monotone objective, non-negativity,
+    objective equals the directly evaluated residual."""
+    from nmf_amd.mur import mur
+    v = R.planted_matrix(4096, 2048, 64, seed=0, dtype=np.float32)
+    np.random.seed(0)
+    res = mur(v, 64, distance_type="eu", min_iter=20, max_iter=20)
+    obj = np.asarray(res.obj_history)
+    assert np.all(np.diff(obj) < 0), "MUR-eu objective must decrease monotonically"
+    direct = 0.5 * np.sum((v.astype(np.float64) - res.w @ res.h) ** 2)
+    assert abs(direct - obj[-1]) <= 1e-5 * direct
+    assert (res.w >= 0).all() and (res.h >= 0).all()
