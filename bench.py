@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NMF outer iterations/sec, MUR-Euclidean,
+V = 16384 x 8192 float32, k = 64 (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one outer iteration of the reference's loop (nmf/mur.py:122-127):
+W update, H update with the new W, objective of the result.  V is resident in
+HBM before the timed region.  For N > 1 the SAME matrix is row-sharded over the
+ranks (strong scaling) with one RCCL all-reduce of [W^T V | W^T W | objective]
+per iteration.  Rank 0 prints one JSON line.
+
+`roofline`: the dominant kernel (wphase: A = V H^T with the fused residual
+objective) priced with its ALGORITHMIC flops 2*m*n*k (the objective's second
+MFMA product is not counted) over its mean launch time, measured
+with HIP events on the engine's stream in a separate profiled pass.
+`cpu_baseline`: the numpy oracle (the reference's literal evaluation order:
+six m*n*k GEMMs per iteration, float64 factors) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("NMF_AMD_QUIET", "1")
+
+import numpy as np  # noqa: E402
+
+M, N, K = 16384, 8192, 64
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=M)
+    ap.add_argument("--n", type=int, default=N)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(v, k, iters):
+    """The oracle's MUR-eu loop body (reference evaluation order) on the host."""
+    from oracle import nmf_ref as R
+    rs = np.random.RandomState(0)
+    w = np.abs(rs.randn(v.shape[0], k))
+    h = np.abs(rs.randn(k, v.shape[1]))
+    wh = w @ h
+
+    def one(w, h, wh):
+        w = R.mur_w_step("eu", v, w, h, wh, 0.0)
+        h = R.mur_h_step("eu", v, w, h, w @ h, 0.0)
+        wh = w @ h
+        return w, h, wh, R.objective(v, wh, "eu")
+
+    w, h, wh, _ = one(w, h, wh)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        w, h, wh, _ = one(w, h, wh)
+    dt = time.perf_counter() - t0
+    return iters / dt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch
+    import torch.distributed as dist
+    from oracle.nmf_ref import planted_matrix
+    from nmf_amd import dist as nd
+
+    m, n, k = args.m, args.n, args.k
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+        comm = nd.TorchComm()
+    else:
+        comm = None
+
+    r0, r1 = nd.row_range(m, rank, world)
+    v_local = planted_matrix(m, n, k, seed=0, dtype=np.float32, rows=(r0, r1))
+    rs = np.random.RandomState(0)
+    w0 = np.abs(rs.randn(m, k))[r0:r1]
+    h0 = np.abs(rs.randn(k, n))
+
+    NEVER = 10 ** 12          # min_iter: the stop rule is evaluated but cannot fire
+    if world > 1:
+        shard = nd.DeviceShard(v_local, k, w0, h0, local_rank)
+
+        def run(first, count):
+            nd.run_iterations(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
+        eng = shard.eng
+    else:
+        from nmf_amd.engine import Engine
+        eng = Engine(m, n, k, device=local_rank)
+        eng.upload_v(v_local)
+        eng.set_factors(w0, h0)
+
+        def run(first, count):
+            eng.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(0, args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    done = args.warmup + args.steps
+
+    # sanity: objective history is finite and decreasing
+    _, _, n_obj = eng.state()
+    obj = eng.objectives(0, n_obj)
+    assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], "bench run produced a bad objective"
+
+    # profiled pass: per-kernel device time from HIP events on the engine's stream
+    roof = None
+    prof = {}
+    if args.profile_steps > 0:
+        eng.profile_enable(True)
+        eng.profile_reset()
+        run(done, args.profile_steps)
+        fence()
+        for name in ("wphase", "hphase", "gram_tn", "gram_nt", "sum_hht", "w_update", "pack", "h_update", "small"):
+            ms, cnt = eng.profile_get(name)
+            if cnt:
+                prof[name] = {"ms_per_launch": ms / cnt, "launches": cnt}
+        eng.profile_enable(False)
+        ml = r1 - r0
+        if "wphase" in prof:
+            sec = prof["wphase"]["ms_per_launch"] * 1e-3
+            flops = 2.0 * ml * n * k
+            ach = flops / sec / 1e12
+            roof = {"kernel": "wphase_kernel", "bound": "mfma", "achieved": ach,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "executed_flops_per_launch": 4.0 * ml * n * k,
+                    "hbm_gbs": (ml * n * 4.0 + 2.0 * ml * k * 4) / sec / 1e9}
+        if "hphase" in prof:
+            sec = prof["hphase"]["ms_per_launch"] * 1e-3
+            prof["hphase"]["tflops"] = 2.0 * ml * n * k / sec / 1e12
+            prof["hphase"]["hbm_gbs"] = ml * n * 4.0 / sec / 1e9
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        v_full = v_local if (r0, r1) == (0, m) else planted_matrix(m, n, k, seed=0, dtype=np.float32)
+        val = cpu_baseline(v_full, k, args.cpu_iters)
+        cpu = {"value": val, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"full {m}x{n} k={k} shape, {args.cpu_iters} iterations after 1 warm-up, "
+                         f"numpy {np.__version__} default BLAS threading"}
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        iter_flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
+        line = {
+            "metric": "NMF outer iterations/sec (MUR-eu, V=16384x8192 f32, k=64)",
+            "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
+                                   "|randn| init, objective every iteration",
+                       "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "iteration": {"algorithmic_gflop": iter_flops / 1e9,
+                          "tflops": iter_flops / (dt / args.steps) / 1e12,
+                          "frac_of_f32_mfma_peak": iter_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS / world},
+            "kernels": prof,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

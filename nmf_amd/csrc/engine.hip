@@ -105,9 +105,12 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     E->stream = E->own_stream;
     // split configuration: enough workgroups to fill 256 CUs twice over
     const int64_t rb = E->mp / 64, cb = E->np / 64;
-    int64_t ws = (512 + rb - 1) / rb; ws = std::max<int64_t>(1, std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4)));
-    int64_t hs = (512 + cb - 1) / cb; hs = std::max<int64_t>(1, std::min<int64_t>(hs, rb));
-    int64_t gs = std::min<int64_t>(32, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));
+    const char* ev;
+    const int64_t wtarget = (ev = getenv("NMFX_WBLOCKS")) ? atoll(ev) : 1024;
+    const int64_t htarget = (ev = getenv("NMFX_HBLOCKS")) ? atoll(ev) : 512;
+    int64_t ws = (wtarget + rb - 1) / rb; ws = std::max<int64_t>(1, std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4)));
+    int64_t hs = (htarget + cb - 1) / cb; hs = std::max<int64_t>(1, std::min<int64_t>(hs, rb));
+    int64_t gs = std::min<int64_t>(8, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));
     E->wsplit = (int)ws; E->hsplit = (int)hs; E->gsplit = (int)gs;
     const int64_t kp = E->kp, mp = E->mp, np = E->np;
     TRY(dev_alloc(E, &E->V, mp * np));
@@ -116,7 +119,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->H, kp * np));
     TRY(dev_alloc(E, &E->HHt, kp * kp));
     TRY(dev_alloc(E, &E->HHt_part, gs * kp * kp));
-    TRY(dev_alloc(E, &E->G_part, gs * kp * kp));
+    TRY(dev_alloc(E, &E->G_part, std::max(gs, hs) * kp * kp));
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));
     TRY(dev_alloc(E, &E->obj_part, std::max<int64_t>(rb * ws, cb * hs) + 64));

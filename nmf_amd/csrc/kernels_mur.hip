@@ -36,7 +36,7 @@ __device__ double block_sum_f64(const double* __restrict__ src, int64_t count, d
 }
 
 // pack: xf32 = [ sum_sr B_part | sum_s G_part ], xf64[0] = sum obj_part.
-// Blocks [0, nb) do B, block nb does G, block nb+1 does the objective.
+// Blocks [0, nb) do B, the next ceil(gcount/256) do G, the last one the objective.
 __global__ __launch_bounds__(256) void mur_pack_kernel(
     const float* __restrict__ Bpart, int hsplit, int64_t bcount,
     const float* __restrict__ Gpart, int gsplit, int64_t gcount,
@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
             }
             *reinterpret_cast<float4*>(xf32 + i4 * 4) = s;
         }
-    } else if (b == nb) {
-        for (int64_t i = threadIdx.x; i < gcount; i += 256) {
+    } else if (b < nb + (int)((gcount + 255) / 256)) {
+        const int64_t i = (int64_t)(b - nb) * 256 + threadIdx.x;
+        if (i < gcount) {
             float s = Gpart[i];
             for (int p = 1; p < gsplit; ++p) s += Gpart[(int64_t)p * gcount + i];
             xf32[bcount + i] = s;
@@ -204,10 +205,10 @@ int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
     float* Wnew = E->W[(j + 1) & 1];
     int rc;
     // HHt of the current H (partials were produced by the previous phase B / set_factors)
-    { ProfScope ps(E, "small");
+    { ProfScope ps(E, "sum_hht");
       if ((rc = launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
     if ((rc = nmfx_launch_wphase(E, Wold, true, true))) return rc;
-    { ProfScope ps(E, "small");
+    { ProfScope ps(E, "w_update");
       switch (E->kp) {
         case 16: rc = launch_w_update<16>(E, Wold, Wnew, (float)lambda_w); break;
         case 32: rc = launch_w_update<32>(E, Wold, Wnew, (float)lambda_w); break;
@@ -215,13 +216,15 @@ int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
         default: rc = launch_w_update<128>(E, Wold, Wnew, (float)lambda_w); break;
       }
       if (rc) return rc; }
-    if ((rc = nmfx_launch_gram_tn(E, Wnew, E->mp, E->G_part, E->gsplit))) return rc;
-    if ((rc = nmfx_launch_hphase(E, Wnew))) return rc;
-    { ProfScope ps(E, "small");
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, Wnew, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, Wnew, fuse_g))) return rc;
+    { ProfScope ps(E, "pack");
       const int nb = 256;
       const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
-      hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + 2), dim3(256), 0, E->stream, E->B_part, E->hsplit,
-                         (int64_t)E->kp * E->np, E->G_part, E->gsplit, (int64_t)E->kp * E->kp,
+      const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
+      hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, E->B_part, E->hsplit,
+                         (int64_t)E->kp * E->np, E->G_part, nmfx_g_slabs(E), (int64_t)E->kp * E->kp,
                          E->obj_part, nobj, E->xf32, E->xf64, nb, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     return NMFX_OK;
@@ -229,7 +232,7 @@ int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
 
 int nmfx_mur_eu_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
-    { ProfScope ps(E, "small");
+    { ProfScope ps(E, "h_update");
       switch (E->kp) {
         case 16: rc = launch_h_update<16>(E, (float)lambda_h, j, min_iter, tol1, tol2); break;
         case 32: rc = launch_h_update<32>(E, (float)lambda_h, j, min_iter, tol1, tol2); break;

@@ -104,16 +104,20 @@ __global__ __launch_bounds__(256) void wphase_kernel(
 
         if (WITH_A) {
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
+            for (int i = 0; i < 4; ++i) {
+                float4 hb[JT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 hb = *reinterpret_cast<const float4*>(
+                for (int jt = 0; jt < JT; ++jt)
+                    hb[jt] = *reinterpret_cast<const float4*>(
                         buf + (jt * 16 + x) * 64 + 4 * ((4 * q + i) ^ gx));
-                    acc[jt] = MFMA(vf[i].x, hb.x, acc[jt]);
-                    acc[jt] = MFMA(vf[i].y, hb.y, acc[jt]);
-                    acc[jt] = MFMA(vf[i].z, hb.z, acc[jt]);
-                    acc[jt] = MFMA(vf[i].w, hb.w, acc[jt]);
-                }
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].x, hb[jt].x, acc[jt]);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].y, hb[jt].y, acc[jt]);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].z, hb[jt].z, acc[jt]);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].w, hb[jt].w, acc[jt]);
             }
         }
         if (WITH_OBJ) {
@@ -179,13 +183,20 @@ __global__ __launch_bounds__(256) void wphase_kernel(
 // Output tile e of the MFMA holds columns 4x+e, so one lane owns 4 adjacent
 // columns of a B row and stores them as one dwordx4.
 // --------------------------------------------------------------------------
-template <int KP>
+template <int KP, bool WITH_G>
 __global__ __launch_bounds__(256) void hphase_kernel(
     const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
-    float* __restrict__ Bpart, int64_t np, int64_t mp, const int* __restrict__ flag)
+    float* __restrict__ Bpart, float* __restrict__ Gpart, int64_t np, int64_t mp,
+    const int* __restrict__ flag)
 {
     if (*flag) return;
     constexpr int JT = KP / 16;
+    // WITH_G: column block t < JT*JT also accumulates tile (t / JT, t % JT) of
+    // W^T W from the W fragments it loads anyway (one extra MFMA per k-step).
+    const int gt = WITH_G ? (int)blockIdx.x : JT * JT;
+    const bool do_g = WITH_G && gt < JT * JT;
+    const int ga = gt / JT, gb = gt % JT;
+    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
     extern __shared__ __attribute__((aligned(16))) float lds[];   // KP*4*64 floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, q = lane >> 4;
@@ -238,6 +249,12 @@ __global__ __launch_bounds__(256) void hphase_kernel(
                 acc[j][2] = MFMA(wa[t][j], vb[t].z, acc[j][2]);
                 acc[j][3] = MFMA(wa[t][j], vb[t].w, acc[j][3]);
             }
+            if (do_g) {
+                float fa = 0.f, fb = 0.f;
+#pragma unroll
+                for (int j = 0; j < JT; ++j) { fa = (j == ga) ? wa[t][j] : fa; fb = (j == gb) ? wa[t][j] : fb; }
+                gacc = MFMA(fa, fb, gacc);
+            }
         }
         vp += (int64_t)UN * 4 * ldv;
         wp += (int64_t)UN * 4 * KP;
@@ -252,14 +269,17 @@ __global__ __launch_bounds__(256) void hphase_kernel(
     }
     for (; s < s1; ++s) {                               // remainder k-steps
         const float4 v1 = *reinterpret_cast<const float4*>(vp);
+        float fa = 0.f, fb = 0.f;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const float a = wp[16 * j];
+            fa = (j == ga) ? a : fa; fb = (j == gb) ? a : fb;
             acc[j][0] = MFMA(a, v1.x, acc[j][0]);
             acc[j][1] = MFMA(a, v1.y, acc[j][1]);
             acc[j][2] = MFMA(a, v1.z, acc[j][2]);
             acc[j][3] = MFMA(a, v1.w, acc[j][3]);
         }
+        if (do_g) gacc = MFMA(fa, fb, gacc);
         vp += 4 * ldv;
         wp += 4 * KP;
     }
@@ -299,6 +319,24 @@ __global__ __launch_bounds__(256) void hphase_kernel(
         }
         __syncthreads();
     }
+    if (do_g) {                                         // same fixed-order sum for the Gram tile
+        f32x4* gred = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+                if (w == 0) gred[lane] = gacc;
+                else if (w < 3) gred[lane] += gacc;
+                else {
+                    const f32x4 t = gred[lane] + gacc;
+                    float* o = Gpart + (int64_t)sr * KP * KP;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[(int64_t)(16 * ga + 4 * q + r) * KP + 16 * gb + x] = t[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -306,65 +344,103 @@ __global__ __launch_bounds__(256) void hphase_kernel(
 // per block; block (split s, tile row jt) writes rows [16 jt, 16 jt + 16) of
 // its partial Gram matrix.
 // --------------------------------------------------------------------------
+// Fixed-order sum of the 4 waves' tile rows through LDS, then the store.
 template <int KP>
-__global__ __launch_bounds__(64) void gram_tn_kernel(     // X^T X, X [rows][KP]
+__device__ __forceinline__ void gram_block_store(f32x4 (&acc)[KP / 16], float* __restrict__ o, int jt,
+                                                 f32x4* red)
+{
+    constexpr int JT = KP / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                if (w == 0) red[j * 64 + lane] = acc[j];
+                else if (w < 3) red[j * 64 + lane] += acc[j];
+                else {
+                    const f32x4 t = red[j * 64 + lane] + acc[j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[(int64_t)(16 * jt + 4 * q + r) * KP + 16 * j + x] = t[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void gram_tn_kernel(    // X^T X, X [rows][KP]
     const float* __restrict__ X, int64_t rows, float* __restrict__ out, const int* __restrict__ flag)
 {
     if (*flag) return;
     constexpr int JT = KP / 16;
-    const int lane = threadIdx.x, x = lane & 15, q = lane >> 4;
+    __shared__ f32x4 red[JT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
     const int S = gridDim.x, s = blockIdx.x, jt = blockIdx.y;
     const int64_t n4 = rows / 4;
-    const int64_t t0 = n4 * s / S, t1 = n4 * (s + 1) / S;
+    const int64_t b0 = n4 * s / S, b1 = n4 * (s + 1) / S;
+    const int64_t t0 = b0 + (b1 - b0) * wave / 4, t1 = b0 + (b1 - b0) * (wave + 1) / 4;
     f32x4 acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* p = X + (t0 * 4 + q) * KP + x;
-    for (int64_t t = t0; t < t1; ++t, p += 4 * KP) {
+    int64_t t = t0;
+    for (; t + 4 <= t1; t += 4, p += 16 * KP) {
+        float a[4], b[4][JT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = p[u * 4 * KP + 16 * jt];
+#pragma unroll
+            for (int j = 0; j < JT; ++j) b[u][j] = p[u * 4 * KP + 16 * j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) acc[j] = MFMA(a[u], b[u][j], acc[j]);
+    }
+    for (; t < t1; ++t, p += 4 * KP) {
         const float a = p[16 * jt];
 #pragma unroll
         for (int j = 0; j < JT; ++j) acc[j] = MFMA(a, p[16 * j], acc[j]);
     }
-    float* o = out + (int64_t)s * KP * KP;
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            o[(int64_t)(16 * jt + 4 * q + r) * KP + 16 * j + x] = acc[j][r];
+    gram_block_store<KP>(acc, out + (int64_t)s * KP * KP, jt, red);
 }
 
 template <int KP>
-__global__ __launch_bounds__(64) void gram_nt_kernel(     // X X^T, X [KP][ld]
+__global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
     const float* __restrict__ X, int64_t cols, int64_t ld, float* __restrict__ out,
     const int* __restrict__ flag)
 {
     if (*flag) return;
     constexpr int JT = KP / 16;
-    const int lane = threadIdx.x, x = lane & 15, q = lane >> 4;
+    __shared__ f32x4 red[JT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
     const int S = gridDim.x, s = blockIdx.x, jt = blockIdx.y;
     const int64_t n16 = cols / 16;
-    const int64_t t0 = n16 * s / S, t1 = n16 * (s + 1) / S;
+    const int64_t b0 = n16 * s / S, b1 = n16 * (s + 1) / S;
+    const int64_t t0 = b0 + (b1 - b0) * wave / 4, t1 = b0 + (b1 - b0) * (wave + 1) / 4;
     f32x4 acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* p = X + (int64_t)x * ld + t0 * 16 + 4 * q;
+#pragma unroll 2
     for (int64_t t = t0; t < t1; ++t, p += 16) {
         const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)16 * jt * ld);
+        float4 b[JT];
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)16 * j * ld);
-            acc[j] = MFMA(a.x, b.x, acc[j]);
-            acc[j] = MFMA(a.y, b.y, acc[j]);
-            acc[j] = MFMA(a.z, b.z, acc[j]);
-            acc[j] = MFMA(a.w, b.w, acc[j]);
-        }
+        for (int j = 0; j < JT; ++j) b[j] = *reinterpret_cast<const float4*>(p + (int64_t)16 * j * ld);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = MFMA(a.x, b[j].x, acc[j]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = MFMA(a.y, b[j].y, acc[j]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = MFMA(a.z, b[j].z, acc[j]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = MFMA(a.w, b[j].w, acc[j]);
     }
-    float* o = out + (int64_t)s * KP * KP;
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            o[(int64_t)(16 * jt + 4 * q + r) * KP + 16 * j + x] = acc[j][r];
+    gram_block_store<KP>(acc, out + (int64_t)s * KP * KP, jt, red);
 }
 
 // --------------------------------------------------------------------------
@@ -399,30 +475,41 @@ int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_ob
 }
 
 template <int KP>
-static int hphase_dispatch(nmfx_engine* E, const float* W) {
+static int hphase_dispatch(nmfx_engine* E, const float* W, bool with_g) {
     dim3 grid((unsigned)(E->np / 64), (unsigned)E->hsplit), block(256);
-    const size_t shm = (size_t)KP * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((hphase_kernel<KP>), grid, block, shm, E->stream, E->V, E->np, W,
-                       E->B_part, E->np, E->mp, &E->state->flag);
+    const size_t shm = (size_t)KP * 64 * sizeof(float);
+    if (with_g)
+        hipLaunchKernelGGL((hphase_kernel<KP, true>), grid, block, shm, E->stream, E->V, E->np, W,
+                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag);
+    else
+        hipLaunchKernelGGL((hphase_kernel<KP, false>), grid, block, shm, E->stream, E->V, E->np, W,
+                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
-int nmfx_launch_hphase(nmfx_engine* E, const float* W) {
+// B_part[sr] = W^T V; with_g: also G_part[sr] = W^T W (needs np/64 >= (kp/16)^2,
+// see nmfx_hphase_can_fuse_gram).
+int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g) {
     ProfScope ps(E, "hphase");
     switch (E->kp) {
-        case 16: return hphase_dispatch<16>(E, W);
-        case 32: return hphase_dispatch<32>(E, W);
-        case 64: return hphase_dispatch<64>(E, W);
-        case 128: return hphase_dispatch<128>(E, W);
+        case 16: return hphase_dispatch<16>(E, W, with_g);
+        case 32: return hphase_dispatch<32>(E, W, with_g);
+        case 64: return hphase_dispatch<64>(E, W, with_g);
+        case 128: return hphase_dispatch<128>(E, W, with_g);
     }
     E->err = "unsupported padded rank";
     return NMFX_E_ARG;
 }
 
+bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E) {
+    const int64_t jt = E->kp / 16;
+    return E->np / 64 >= jt * jt;
+}
+
 int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out, int splits) {
     ProfScope ps(E, "gram_tn");
-    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(64);
+    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(256);
     switch (E->kp) {
         case 16: hipLaunchKernelGGL((gram_tn_kernel<16>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
         case 32: hipLaunchKernelGGL((gram_tn_kernel<32>), grid, block, 0, E->stream, X, rows, out, &E->state->flag); break;
@@ -436,7 +523,7 @@ int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out
 
 int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld, float* out, int splits) {
     ProfScope ps(E, "gram_nt");
-    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(64);
+    dim3 grid((unsigned)splits, (unsigned)(E->kp / 16)), block(256);
     switch (E->kp) {
         case 16: hipLaunchKernelGGL((gram_nt_kernel<16>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;
         case 32: hipLaunchKernelGGL((gram_nt_kernel<32>), grid, block, 0, E->stream, X, cols, ld, out, &E->state->flag); break;

@@ -79,7 +79,10 @@ struct nmfx_engine {
 // objective 0.5*sum (V - W H)^2 into obj_part (one double per block).
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj);
 // B_part[sr] = W^T V over the rows of split sr.
-int nmfx_launch_hphase(nmfx_engine* E, const float* W);
+int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g);
+bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E);
+// number of W^T W partial slabs the H phase leaves in G_part
+inline int nmfx_g_slabs(const nmfx_engine* E) { return nmfx_hphase_can_fuse_gram(E) ? E->hsplit : E->gsplit; }
 // out_part[s] = X^T X  (X [rows][kp])  /  X X^T (X [kp][cols])
 int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out_part, int splits);
 int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld, float* out_part, int splits);

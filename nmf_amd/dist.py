@@ -1,0 +1,143 @@
+"""Row-sharded MUR over several GPUs of one node (one process per GPU).
+
+Rank p holds the rows [r0, r1) of V and of W; H (k x n) and H H^T are
+replicated.  The W update is row-local (nmf/mur.py:29: row i of W depends only
+on row i of V).  The H update (nmf/mur.py:45) needs W^T V = sum_p W_p^T V_p and
+W^T W = sum_p W_p^T W_p: ONE sum-all-reduce per outer iteration of the packed
+f32 buffer [W^T V | W^T W] (k*n + k*k elements) plus the f64 objective partial.
+Every rank then applies the identical H update, so no broadcast is needed and
+the device-side stop flag agrees on all ranks.
+
+The collective is `torch.distributed.all_reduce` (backend "nccl" = RCCL over
+xGMI on the GPU box; "gloo" in the CPU tests, where a numpy stand-in engine
+from the test-suite replaces the HIP engine).  The loop below only talks to an
+object with phase_a / phase_b / finish_a / finish_b / state / objectives, so the
+sharding logic is the same code in both cases.
+"""
+import logging
+
+import numpy as np
+
+from . import utils
+from ._driver import Results
+
+
+def row_range(m, rank, world):
+    """Contiguous, balanced row block of `rank` (any m, any world)."""
+    return (m * rank) // world, (m * (rank + 1)) // world
+
+
+class TorchComm:
+    """Sum-all-reduce of the engine's exchange buffers through torch.distributed."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, *tensors):
+        for t in tensors:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class DeviceShard:
+    """HIP engine for one row shard, with exchange buffers allocated by torch so
+    that RCCL can reduce them in place, and running on torch's current stream so
+    the collective is ordered after phase A and before phase B."""
+
+    def __init__(self, v_local, k, w0_local, h0, device):
+        import torch
+        from .engine import Engine
+        self.torch = torch
+        torch.cuda.set_device(device)
+        self.eng = Engine(v_local.shape[0], v_local.shape[1], k, device=device)
+        n32, n64 = self.eng.exchange_sizes()
+        self.xf32 = torch.zeros(n32, dtype=torch.float32, device=f"cuda:{device}")
+        self.xf64 = torch.zeros(n64, dtype=torch.float64, device=f"cuda:{device}")
+        torch.cuda.synchronize()
+        self.eng.set_exchange_buffers(self.xf32.data_ptr(), self.xf64.data_ptr())
+        self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.eng.upload_v(v_local)
+        self.eng.set_factors(w0_local, h0)
+
+    def buffers(self):
+        return self.xf32, self.xf64
+
+    def phase_a(self, dist_code, lambda_w, j):
+        self.eng.mur_phase_a(dist_code, lambda_w, j)
+
+    def phase_b(self, dist_code, lambda_h, min_iter, tol1, tol2, j):
+        self.eng.mur_phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+
+    def finish_a(self, dist_code, j):
+        self.eng.mur_finish_a(dist_code, j)
+
+    def finish_b(self, min_iter, tol1, tol2, j):
+        self.eng.mur_finish_b(min_iter, tol1, tol2, j)
+
+    def state(self):
+        return self.eng.state()
+
+    def objectives(self, first, count):
+        return self.eng.objectives(first, count)
+
+    def get_factors(self):
+        return self.eng.get_factors()
+
+    def synchronize(self):
+        self.eng.synchronize()
+
+    def close(self):
+        self.eng.close()
+
+
+def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
+    """Queue `count` sharded outer iterations (no host sync)."""
+    bufs = shard.buffers()
+    for j in range(first, first + count):
+        shard.phase_a(dist_code, lambda_w, j)
+        comm.all_reduce(*bufs)
+        shard.phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+
+
+def finish(shard, comm, dist_code, min_iter, tol1, tol2, done):
+    shard.finish_a(dist_code, done)
+    comm.all_reduce(shard.buffers()[1])
+    shard.finish_b(min_iter, tol1, tol2, done)
+
+
+def mur_sharded(shard, comm, *, distance_type='eu', min_iter=100, max_iter=100000, tol1=1e-5,
+                tol2=1e-5, lambda_w=0.0, lambda_h=0.0, batch=32, experiment=None):
+    """The reference's MUR loop (nmf/mur.py:119-145) over a row-sharded V.
+    Returns Results whose `w` is THIS rank's row block; h, i and obj_history
+    are identical on every rank."""
+    if distance_type not in ('eu', 'kl'):
+        raise KeyError('Distance type unknown: use "kl" or "eu"')
+    if max_iter <= 0:
+        raise UnboundLocalError("local variable 'i' referenced before assignment")
+    code = 0 if distance_type == 'eu' else 1
+    digits = utils.tol_digits(tol1, tol2)
+    history, done, rule, stop_i = [], 0, 0, -1
+    while done < max_iter and not rule:
+        count = min(batch, max_iter - done)
+        run_iterations(shard, comm, code, lambda_w, lambda_h, min_iter, tol1, tol2, done, count)
+        done += count
+        if done == max_iter:
+            finish(shard, comm, code, min_iter, tol1, tol2, done)
+        rule, stop_i, n_obj = shard.state()
+        for val in shard.objectives(len(history), n_obj - len(history)):
+            history.append(np.float64(val))
+            if len(history) >= 2 and comm.rank == 0:
+                utils.say('[{}]: {:.{}f}'.format(len(history) - 2, val, digits))
+    w, h = shard.get_factors()
+    if rule:
+        if comm.rank == 0:
+            utils.convergence_message(rule)
+        logging.warning('Converged.')
+        return Results(w, h, stop_i, history[:stop_i + 2], experiment)
+    return Results(w, h, max_iter - 1, history, experiment)
