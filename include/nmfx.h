@@ -127,6 +127,10 @@ int nmfx_aoadmm_run(nmfx_handle_t h, int distance, int prox_w, double lambda_w,
                     int prox_h, double lambda_h, int admm_iter,
                     int64_t min_iter, double tol1, double tol2,
                     int64_t first, int64_t count);
+/* Record the objective / convergence test of the last queued iteration.       */
+int nmfx_aoadmm_finish(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t iters_done);
+/* Per outer iteration two int32: (H sub-problem, W sub-problem); low 16 bits =
+ * inner rounds run, bit 16 = the inner stop test fired ("ADMM break after").  */
 int nmfx_get_inner_counts(nmfx_handle_t h, int64_t first, int64_t count, int32_t* out_pairs);
 
 /* ---- ADMM (replaces nmf/admm.py:292-334) -------------------------------- */

@@ -13,9 +13,10 @@ Results = namedtuple('Results', 'w h i obj_history experiment')
 BATCH = 64     # outer iterations queued between two host syncs
 
 
-def drive(engine, run_batch, finish, max_iter, tol1, tol2):
+def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None):
     """run_batch(first, count) queues iterations; finish(done) completes the
-    bookkeeping of the last one.  Returns (i, obj_history) like the reference
+    bookkeeping of the last one; before_line(i) may print what the reference
+    prints inside iteration i before its objective line.  Returns (i, obj_history) like the reference
     loops (nmf/mur.py:119-145): obj_history has i + 2 entries."""
     if max_iter <= 0:
         # reference: `for i in range(0)` never binds i -> UnboundLocalError at mur.py:145
@@ -35,6 +36,8 @@ def drive(engine, run_batch, finish, max_iter, tol1, tol2):
         for val in fresh:
             history.append(np.float64(val))
             if len(history) >= 2:
+                if before_line is not None:
+                    before_line(len(history) - 2)
                 utils.say('[{}]: {:.{}f}'.format(len(history) - 2, val, digits))
     if rule:
         utils.convergence_message(rule)

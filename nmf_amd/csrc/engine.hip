@@ -8,7 +8,6 @@
 int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_mur_eu_finish_a(nmfx_engine* E, int64_t j);
-int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_mur_kl_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_kl_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j);
@@ -37,7 +36,7 @@ static int dev_alloc(nmfx_engine* E, T** p, int64_t count) {
     return NMFX_OK;
 }
 
-static int ensure_obj_capacity(nmfx_engine* E, int64_t need) {
+int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need) {
     if (need <= E->obj_cap) return NMFX_OK;
     int64_t cap = E->obj_cap ? E->obj_cap : 4096;
     while (cap < need) cap *= 2;
@@ -127,7 +126,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->xf64, 4));
     TRY(dev_alloc(E, &E->state, 1));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
-    TRY(ensure_obj_capacity(E, 4096));
+    TRY(nmfx_ensure_obj_capacity(E, 4096));
     TRYHIP(hipStreamSynchronize(E->stream));
 #undef TRY
 #undef TRYHIP
@@ -249,7 +248,7 @@ int nmfx_get_factors(nmfx_handle_t E, double* w, double* hmat) {
     if (!E) return NMFX_E_ARG;
     DevState hs; int rc;
     if ((rc = read_state(E, &hs))) return rc;
-    if (hs.flag) E->wsel = (int)((hs.stop_i + 1) & 1);
+    if (hs.flag && !E->w_in_place) E->wsel = (int)((hs.stop_i + 1) & 1);
     if (w) { if ((rc = get_padded(E, E->W[E->wsel], w, E->m, E->k, E->mp, E->kp))) return rc; }
     if (hmat) { if ((rc = get_padded(E, E->H, hmat, E->k, E->n, E->kp, E->np))) return rc; }
     return NMFX_OK;
@@ -279,7 +278,7 @@ int nmfx_get_state(nmfx_handle_t E, int* stop_rule, int64_t* stop_i, int64_t* n_
     if (stop_i) *stop_i = hs.stop_i;
     if (n_obj) *n_obj = hs.n_obj;
     // the iterate the reference would return: W_{stop_i+1} once stopped
-    if (hs.flag) E->wsel = (int)((hs.stop_i + 1) & 1);
+    if (hs.flag && !E->w_in_place) E->wsel = (int)((hs.stop_i + 1) & 1);
     return NMFX_OK;
 }
 
@@ -332,7 +331,7 @@ static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
-    return ensure_obj_capacity(E, first + count + 2);
+    return nmfx_ensure_obj_capacity(E, first + count + 2);
 }
 
 int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
@@ -348,6 +347,7 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     E->wsel = (int)((j + 1) & 1);
+    E->w_in_place = false;
     if (distance == NMFX_EU) return nmfx_mur_eu_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
     if (distance == NMFX_KL) return nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;

@@ -1,0 +1,447 @@
+// AO-ADMM (Huang, Sidiropoulos, Liavas) sub-problem kernels.
+//   reference: admm_ls_update nmf/ao_admm.py:46-68, prox nn/l1n :113-124,
+//   terminate :33-43, driver :259-301.
+//
+// Per sub-problem:  G = F^T F (k x k), rho = trace(G)/k, then up to admm_iter
+// rounds of   aux = (G + rho I)^-1 (B + rho (X + U));  X = prox(aux - U);
+// U += X - aux;  stop when ||X-aux||/||X|| < 1e-2 and ||X-X_prev||/||U|| < 1e-2.
+//
+// The reference factors G + rho I once (Cholesky) and back-substitutes every
+// round.  Here the k x k inverse is formed once per sub-problem in float64 by a
+// single workgroup (in-place Gauss-Jordan in LDS; the pivots are the Cholesky
+// pivots squared, so "not positive definite" is detected on the same
+// condition), rounded to f32, and every round is then ONE fused kernel: an MFMA
+// product with that inverse + prox + dual update + the four norm partials.
+// cond(G + rho I) <= k + 1 because rho >= lambda_max / k, so the explicit
+// inverse is benign.
+//
+// The inner stop test runs on the device: round i first re-derives the decision
+// of round i-1 from the per-block norm partials (every block sums the same
+// numbers in the same order, so all agree) and turns into a no-op once it fired.
+#include "nmfx_internal.h"
+#include "kernels_small.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---- k x k inverse -------------------------------------------------------
+// src: summed Gram matrix (f32, [KP][KP], zero beyond the logical k).
+// record_obj: also publish obj[j] and run the outer convergence test first.
+template <int KP>
+__global__ __launch_bounds__(1024) void ao_prepare_kernel(
+    const float* __restrict__ src, int k, float* __restrict__ Minv, DevState* __restrict__ st,
+    int record_obj, const double* __restrict__ xf64, long long j, long long min_iter,
+    double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho)
+{
+    if (st->flag) return;
+    if (record_obj) {
+        const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
+                                               threadIdx.x == 0);
+        if (rule) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double S[];     // [KP][KP] + 2*KP
+    double* colp = S + KP * KP;
+    double* rowp = colp + KP;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP * KP; i += 1024) S[i] = (double)src[i];
+    __syncthreads();
+    if (tid == 0) {
+        double rho = fixed_rho;
+        if (!(fixed_rho >= 0.0)) {                 // AO-ADMM: rho = trace(G) / k  (ao_admm.py:54)
+            double tr = 0.0;
+            for (int i = 0; i < k; ++i) tr += S[i * KP + i];
+            rho = tr / (double)k;
+        }
+        colp[0] = rho;
+    }
+    __syncthreads();
+    const double rho = colp[0];
+    __syncthreads();
+    if (tid < KP) S[tid * KP + tid] += rho;
+    if (tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
+    __syncthreads();
+    for (int p = 0; p < KP; ++p) {
+        const double piv = S[p * KP + p];
+        if (!(piv > 0.0)) {                        // scipy cholesky would raise LinAlgError
+            if (tid == 0) { st->notpd = 1; st->flag = 3; }
+            return;
+        }
+        if (tid < KP) { colp[tid] = S[tid * KP + p]; rowp[tid] = S[p * KP + tid] / piv; }
+        __syncthreads();
+        for (int e = tid; e < KP * KP; e += 1024) {
+            const int i = e / KP, c = e % KP;
+            double v;
+            if (i == p) v = (c == p) ? 1.0 / piv : rowp[c];
+            else if (c == p) v = -colp[i] / piv;
+            else v = S[e] - colp[i] * rowp[c];
+            S[e] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < KP * KP; i += 1024) Minv[i] = (float)S[i];
+}
+
+// ---- inner stop test -------------------------------------------------------
+// Sum the four norm partials of the previous round; identical in every block.
+__device__ __forceinline__ bool inner_round_fired(const double* __restrict__ part, int nblk, double* sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // wave w sums component w
+    double s = 0.0;
+    if (wave < 4)
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * 4 + wave];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0 && wave < 4) sh[wave] = s;
+    __syncthreads();
+    const double r = sqrt(sh[0]) / sqrt(sh[1]);        // ||X - aux|| / ||X||
+    const double d = sqrt(sh[2]) / sqrt(sh[3]);        // ||X - X_prev|| / ||U||   (x/0 -> inf/nan -> false)
+    __syncthreads();
+    return (r < 1e-2) && (d < 1e-2);
+}
+
+__device__ __forceinline__ float prox_apply(float aux, float dual, float shift) {
+    const float d = (aux - dual) - shift;              // nn: shift = 0; l1n: lambda / rho
+    return (d < 0.f) ? 0.f : d;                        // np.where(d < 0, 0, d): NaN stays NaN
+}
+
+template <int NW>
+__device__ __forceinline__ void block_store_norms(float n0, float n1, float n2, float n3,
+                                                  double* __restrict__ out, double* sh)
+{
+    double v[4] = {(double)n0, (double)n1, (double)n2, (double)n3};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if (lane == 0) sh[wave * 4 + c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += sh[w * 4 + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// ---- H-side round: X is [KP][np] (columns independent), aux = Minv * RHS ---
+// block = 64 columns; wave w owns row tiles {w, w+4, ...}; RHS tile through LDS.
+template <int KP>
+__global__ __launch_bounds__(256) void ao_inner_cols_kernel(
+    const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U,
+    const float* __restrict__ Minv, int64_t np, int prox, float lam, int round,
+    DevState* __restrict__ st, double* __restrict__ nrm)       // nrm: [2][nblk][4]
+{
+    if (st->flag || st->inner_stop) return;
+    constexpr int JT = KP / 16;
+    constexpr int ITW = (JT + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [KP][64] RHS + 16 doubles
+    double* sh = reinterpret_cast<double*>(lds + KP * 64);
+    const int nblk = gridDim.x;
+    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_count = round + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+
+    {   // RHS = B + rho (X + U)
+        const int srow = tid >> 4, sc = tid & 15;
+#pragma unroll
+        for (int p = 0; p < JT; ++p) {
+            const int64_t g = (int64_t)(p * 16 + srow) * np + c0 + 4 * sc;
+            const float4 b = *reinterpret_cast<const float4*>(Bsum + g);
+            const float4 h = *reinterpret_cast<const float4*>(X + g);
+            const float4 u = *reinterpret_cast<const float4*>(U + g);
+            float4 r;
+            r.x = b.x + rho * (h.x + u.x); r.y = b.y + rho * (h.y + u.y);
+            r.z = b.z + rho * (h.z + u.z); r.w = b.w + rho * (h.w + u.w);
+            *reinterpret_cast<float4*>(lds + (p * 16 + srow) * 64 + 4 * sc) = r;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[ITW][4];
+#pragma unroll
+    for (int r = 0; r < ITW; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < ITW; ++r) {
+        const int it = wave + 4 * r;
+        if (it < JT) {
+            float4 mf[JT];
+#pragma unroll
+            for (int u = 0; u < JT; ++u)
+                mf[u] = *reinterpret_cast<const float4*>(Minv + (int64_t)(16 * it + x) * KP + 16 * u + 4 * q);
+#pragma unroll
+            for (int u = 0; u < JT; ++u) {
+                const float ma[4] = {mf[u].x, mf[u].y, mf[u].z, mf[u].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float4 rb = *reinterpret_cast<const float4*>(lds + (16 * u + 4 * q + s) * 64 + 4 * x);
+                    acc[r][0] = MFMA(ma[s], rb.x, acc[r][0]);
+                    acc[r][1] = MFMA(ma[s], rb.y, acc[r][1]);
+                    acc[r][2] = MFMA(ma[s], rb.z, acc[r][2]);
+                    acc[r][3] = MFMA(ma[s], rb.w, acc[r][3]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
+                const float4 h = *reinterpret_cast<const float4*>(X + idx);
+                const float4 u = *reinterpret_cast<const float4*>(U + idx);
+                const float ax[4] = {acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                const float hx[4] = {h.x, h.y, h.z, h.w}, ux[4] = {u.x, u.y, u.z, u.w};
+                float hn[4], un[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hn[e] = prox_apply(ax[e], ux[e], shift);
+                    un[e] = ux[e] + hn[e] - ax[e];
+                    const float d0 = hn[e] - ax[e], d2 = hn[e] - hx[e];
+                    n0 += d0 * d0; n1 += hn[e] * hn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
+                }
+                *reinterpret_cast<float4*>(X + idx) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                *reinterpret_cast<float4*>(U + idx) = make_float4(un[0], un[1], un[2], un[3]);
+            }
+        }
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+}
+
+// ---- W-side round: X is [mp][KP] (rows independent), aux = RHS * Minv ------
+// block = 64 rows (4 waves x 16); Minv through LDS (row stride KP + 4).
+template <int KP>
+__global__ __launch_bounds__(256) void ao_inner_rows_kernel(
+    const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U,
+    const float* __restrict__ Minv, int prox, float lam, int round,
+    DevState* __restrict__ st, double* __restrict__ nrm)
+{
+    if (st->flag || st->inner_stop) return;
+    constexpr int JT = KP / 16;
+    constexpr int LDM = KP + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [KP][LDM] + 16 doubles
+    double* sh = reinterpret_cast<double*>(lds + KP * LDM);
+    const int nblk = gridDim.x;
+    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_count = round + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    for (int i = tid; i < KP * (KP / 4); i += 256) {
+        const int r = i / (KP / 4), c4 = i % (KP / 4);
+        *reinterpret_cast<float4*>(lds + r * LDM + 4 * c4) =
+            *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    float4 xf[JT];
+#pragma unroll
+    for (int u = 0; u < JT; ++u) {
+        const int64_t g = (r0 + x) * KP + 16 * u + 4 * q;
+        const float4 a = *reinterpret_cast<const float4*>(Asum + g);
+        const float4 w = *reinterpret_cast<const float4*>(X + g);
+        const float4 d = *reinterpret_cast<const float4*>(U + g);
+        xf[u].x = a.x + rho * (w.x + d.x); xf[u].y = a.y + rho * (w.y + d.y);
+        xf[u].z = a.z + rho * (w.z + d.z); xf[u].w = a.w + rho * (w.w + d.w);
+    }
+    __syncthreads();
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+    for (int it = 0; it < JT; ++it) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < JT; ++u) {
+            const float4 mb = *reinterpret_cast<const float4*>(lds + (16 * it + x) * LDM + 16 * u + 4 * q);
+            acc = MFMA(xf[u].x, mb.x, acc);
+            acc = MFMA(xf[u].y, mb.y, acc);
+            acc = MFMA(xf[u].z, mb.z, acc);
+            acc = MFMA(xf[u].w, mb.w, acc);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
+            const float w = X[idx], d = U[idx], ax = acc[g];
+            const float wn = prox_apply(ax, d, shift);
+            const float dn = d + wn - ax;
+            const float d0 = wn - ax, d2 = wn - w;
+            n0 += d0 * d0; n1 += wn * wn; n2 += d2 * d2; n3 += dn * dn;
+            X[idx] = wn; U[idx] = dn;
+        }
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+}
+
+// After the last round: record (rounds run | fired << 16) for this sub-problem.
+__global__ __launch_bounds__(256) void ao_inner_finish_kernel(
+    DevState* __restrict__ st, const double* __restrict__ nrm, int nblk, int admm_iter,
+    int32_t* __restrict__ slot)
+{
+    if (st->flag) return;
+    __shared__ double sh[16];
+    int fired = st->inner_stop;
+    const int count = st->inner_count;
+    if (!fired && count == admm_iter && admm_iter > 0)
+        fired = inner_round_fired(nrm + (int64_t)((admm_iter - 1) & 1) * nblk * 4, nblk, sh) ? 1 : 0;
+    if (threadIdx.x == 0) { *slot = count | (fired << 16); st->inner_stop = 0; }
+}
+
+// ---- host sequencing -----------------------------------------------------
+template <typename T>
+static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
+    if (*p) return NMFX_OK;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T)));
+    NMFX_HIP(hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), E->stream));
+    return NMFX_OK;
+}
+
+
+int nmfx_aoadmm_alloc(nmfx_engine* E) {
+    int rc;
+    if ((rc = lazy_alloc(E, &E->dualW, E->mp * E->kp))) return rc;
+    if ((rc = lazy_alloc(E, &E->dualH, (int64_t)E->kp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->auxW, E->mp * E->kp))) return rc;      // A = V H^T summed over splits
+    if ((rc = lazy_alloc(E, &E->Minv, (int64_t)E->kp * E->kp))) return rc;
+    if ((rc = lazy_alloc(E, &E->nrm_part, 2 * std::max(E->mp, E->np) / 64 * 4 + 64))) return rc;
+    return NMFX_OK;
+}
+
+template <int KP>
+static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
+                          double tol1, double tol2, double fixed_rho) {
+    const size_t shm = ((size_t)KP * KP + 2 * KP) * sizeof(double);
+    auto kern = ao_prepare_kernel<KP>;
+    if (shm > 64 * 1024)
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), shm, E->stream, src, E->k, E->Minv, E->state, record_obj,
+                       E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
+                        double tol1, double tol2, double fixed_rho) {
+    ProfScope ps(E, "prepare");
+    switch (E->kp) {
+        case 16: return launch_prepare<16>(E, src, record_obj, j, min_iter, tol1, tol2, fixed_rho);
+        case 32: return launch_prepare<32>(E, src, record_obj, j, min_iter, tol1, tol2, fixed_rho);
+        case 64: return launch_prepare<64>(E, src, record_obj, j, min_iter, tol1, tol2, fixed_rho);
+        default: return launch_prepare<128>(E, src, record_obj, j, min_iter, tol1, tol2, fixed_rho);
+    }
+}
+
+template <int KP>
+static int launch_inner_cols(nmfx_engine* E, int prox, float lam, int round) {
+    const size_t shm = (size_t)KP * 64 * sizeof(float) + 16 * sizeof(double);
+    hipLaunchKernelGGL((ao_inner_cols_kernel<KP>), dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream,
+                       E->xf32, E->H, E->dualH, E->Minv, E->np, prox, lam, round, E->state, E->nrm_part);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+template <int KP>
+static int launch_inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round) {
+    const size_t shm = (size_t)KP * (KP + 4) * sizeof(float) + 16 * sizeof(double);
+    auto kern = ao_inner_rows_kernel<KP>;
+    if (shm > 64 * 1024)
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, E->auxW, W, E->dualW,
+                       E->Minv, prox, lam, round, E->state, E->nrm_part);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static int inner_cols(nmfx_engine* E, int prox, float lam, int round) {
+    switch (E->kp) {
+        case 16: return launch_inner_cols<16>(E, prox, lam, round);
+        case 32: return launch_inner_cols<32>(E, prox, lam, round);
+        case 64: return launch_inner_cols<64>(E, prox, lam, round);
+        default: return launch_inner_cols<128>(E, prox, lam, round);
+    }
+}
+
+static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round) {
+    switch (E->kp) {
+        case 16: return launch_inner_rows<16>(E, W, prox, lam, round);
+        case 32: return launch_inner_rows<32>(E, W, prox, lam, round);
+        case 64: return launch_inner_rows<64>(E, W, prox, lam, round);
+        default: return launch_inner_rows<128>(E, W, prox, lam, round);
+    }
+}
+
+static int inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot) {
+    hipLaunchKernelGGL(ao_inner_finish_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part, nblk,
+                       admm_iter, slot);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// One outer iteration of ao_admm.py:259-292 (Euclidean loss).
+static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
+                               int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    // ---- H sub-problem: admm_ls_update(v, w, h, dual_h) ----
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
+    if ((rc = nmfx_launch_pack(E))) return rc;                       // xf32 = [W^T V | W^T W], xf64 = obj[j]
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+    { ProfScope ps(E, "inner_h");
+      for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
+      if ((rc = inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc; }
+    // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
+    { ProfScope ps(E, "sums");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+      if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->auxW))) return rc; }
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
+    { ProfScope ps(E, "inner_w");
+      for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
+      if ((rc = inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
+    // ---- objective of the new pair (utils.py:29), summed by the next pack / finish ----
+    return nmfx_launch_wphase(E, W, false, true);
+}
+
+extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double lambda_w, int prox_h,
+                               double lambda_h, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                               int64_t first, int64_t count) {
+    if (!E) return NMFX_E_ARG;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (distance != NMFX_EU) { E->err = "AO-ADMM with KL loss is not built yet"; return NMFX_E_ARG; }
+    if ((prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) || (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N)) {
+        E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = nmfx_aoadmm_alloc(E))) return rc;
+    if ((rc = nmfx_ensure_inner_capacity(E, first + count + 1))) return rc;
+    if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
+    E->wsel = 0;
+    E->w_in_place = true;
+    if (first == 0 && count > 0) {                                    // obj[0] of the initial factors (ao_admm.py:256)
+        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;
+    }
+    for (int64_t j = first; j < first + count; ++j)
+        if ((rc = aoadmm_eu_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)))
+            return rc;
+    return NMFX_OK;
+}
+
+// bookkeeping of the last iteration's objective (obj_part is already filled)
+extern "C" int nmfx_aoadmm_finish(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t done) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = nmfx_launch_obj_reduce(E))) return rc;
+    return nmfx_finish_b(E, min_iter, tol1, tol2, done);
+}

@@ -169,7 +169,7 @@ __global__ void finalize_kernel(const double* __restrict__ xf64, long long j, lo
 // --------------------------------------------------------------------------
 // host-side sequencing of one MUR-eu iteration
 // --------------------------------------------------------------------------
-static int launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out) {
+int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out) {
     const int64_t n4 = (count + 3) / 4;
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, E->stream,
                        part, splits, count, out, &E->state->flag);
@@ -200,13 +200,34 @@ static int launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_ite
     return NMFX_OK;
 }
 
+int nmfx_launch_pack(nmfx_engine* E) {
+    ProfScope ps(E, "pack");
+    const int nb = 256;
+    const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
+    const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
+    hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, E->B_part, E->hsplit,
+                       (int64_t)E->kp * E->np, E->G_part, nmfx_g_slabs(E), (int64_t)E->kp * E->kp,
+                       E->obj_part, nobj, E->xf32, E->xf64, nb, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_launch_obj_reduce(nmfx_engine* E) {
+    ProfScope ps(E, "small");
+    const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
+    hipLaunchKernelGGL(obj_reduce_kernel, dim3(1), dim3(256), 0, E->stream, E->obj_part, nobj, E->xf64,
+                       &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[j & 1];
     float* Wnew = E->W[(j + 1) & 1];
     int rc;
     // HHt of the current H (partials were produced by the previous phase B / set_factors)
     { ProfScope ps(E, "sum_hht");
-      if ((rc = launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
     if ((rc = nmfx_launch_wphase(E, Wold, true, true))) return rc;
     { ProfScope ps(E, "w_update");
       switch (E->kp) {
@@ -219,14 +240,7 @@ int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
     const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
     if (!fuse_g && (rc = nmfx_launch_gram_tn(E, Wnew, E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_hphase(E, Wnew, fuse_g))) return rc;
-    { ProfScope ps(E, "pack");
-      const int nb = 256;
-      const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
-      const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
-      hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, E->B_part, E->hsplit,
-                         (int64_t)E->kp * E->np, E->G_part, nmfx_g_slabs(E), (int64_t)E->kp * E->kp,
-                         E->obj_part, nobj, E->xf32, E->xf64, nb, &E->state->flag);
-      NMFX_HIP(hipGetLastError()); }
+    if ((rc = nmfx_launch_pack(E))) return rc;
     return NMFX_OK;
 }
 
@@ -246,12 +260,7 @@ int nmfx_mur_eu_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, doubl
 int nmfx_mur_eu_finish_a(nmfx_engine* E, int64_t j) {
     int rc;
     if ((rc = nmfx_launch_wphase(E, E->W[j & 1], false, true))) return rc;
-    ProfScope ps(E, "small");
-    const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
-    hipLaunchKernelGGL(obj_reduce_kernel, dim3(1), dim3(256), 0, E->stream, E->obj_part, nobj, E->xf64,
-                       &E->state->flag);
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
+    return nmfx_launch_obj_reduce(E);
 }
 
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j) {

@@ -38,7 +38,7 @@ __device__ __forceinline__ int swz(int row) {
 // already has (row on lane&15, column 16q+4reg+e), so the residual needs no
 // data movement.
 // --------------------------------------------------------------------------
-template <int KP, bool WITH_A, bool WITH_OBJ>
+template <int KP, bool WITH_A, bool WITH_OBJ, bool KL>
 __global__ __launch_bounds__(256) void wphase_kernel(
     const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
     const float* __restrict__ H, int64_t ldh, float* __restrict__ Apart,
@@ -102,6 +102,49 @@ __global__ __launch_bounds__(256) void wphase_kernel(
         }
         const float* buf = lds + cur * (KP * 64);
 
+        if (WITH_OBJ || KL) {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
+#pragma unroll
+            for (int u = 0; u < JT; ++u) {
+                const float wv[4] = {wf[u].x, wf[u].y, wf[u].z, wf[u].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float4 ha = *reinterpret_cast<const float4*>(buf + u * 16 * 64 + dslot[s]);
+                    d0 = MFMA(ha.x, wv[s], d0);
+                    d1 = MFMA(ha.y, wv[s], d1);
+                    d2 = MFMA(ha.z, wv[s], d2);
+                    d3 = MFMA(ha.w, wv[s], d3);
+                }
+            }
+            float part = 0.f;
+            if (!KL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float rx = vf[i].x - d0[i], ry = vf[i].y - d1[i];
+                    const float rz = vf[i].z - d2[i], rw = vf[i].w - d3[i];
+                    part += rx * rx + ry * ry + rz * rz + rw * rw;
+                }
+            } else {
+                // KL: objective term v log(v/wh) [inf, nan -> 0] - v + wh (utils.py:23-26) and
+                // the quotient v / (wh + 1e-9) that replaces V in the A-product (mur.py:25)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float vv[4] = {vf[i].x, vf[i].y, vf[i].z, vf[i].w};
+                    const float pp[4] = {d0[i], d1[i], d2[i], d3[i]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (WITH_OBJ) {
+                            float t = vv[e] * __logf(vv[e] / pp[e]);
+                            t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                            part += (t - vv[e]) + pp[e];
+                        }
+                        vv[e] = vv[e] / (pp[e] + 1e-9f);
+                    }
+                    vf[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+            if (WITH_OBJ) osum += (double)part;
+        }
         if (WITH_A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -119,29 +162,6 @@ __global__ __launch_bounds__(256) void wphase_kernel(
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].w, hb[jt].w, acc[jt]);
             }
-        }
-        if (WITH_OBJ) {
-            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
-#pragma unroll
-            for (int u = 0; u < JT; ++u) {
-                const float wv[4] = {wf[u].x, wf[u].y, wf[u].z, wf[u].w};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float4 ha = *reinterpret_cast<const float4*>(buf + u * 16 * 64 + dslot[s]);
-                    d0 = MFMA(ha.x, wv[s], d0);
-                    d1 = MFMA(ha.y, wv[s], d1);
-                    d2 = MFMA(ha.z, wv[s], d2);
-                    d3 = MFMA(ha.w, wv[s], d3);
-                }
-            }
-            float part = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float rx = vf[i].x - d0[i], ry = vf[i].y - d1[i];
-                const float rz = vf[i].z - d2[i], rw = vf[i].w - d3[i];
-                part += rx * rx + ry * ry + rz * rz + rw * rw;
-            }
-            osum += (double)part;
         }
         if (more) {
             float* nb = lds + (cur ^ 1) * (KP * 64);
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(256) void wphase_kernel(
         __syncthreads();
         if (tid == 0)
             objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] =
-                0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+                (KL ? 1.0 : 0.5) * (((red[0] + red[1]) + red[2]) + red[3]);
     }
 }
 
@@ -447,28 +467,34 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
 // launchers
 // --------------------------------------------------------------------------
 template <int KP>
-static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj) {
+static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)2 * KP * 64 * sizeof(float);
     const int ng = (int)(E->np / 64);
-#define NMFX_WLAUNCH(A, O)                                                                  \
-    hipLaunchKernelGGL((wphase_kernel<KP, A, O>), grid, block, shm, E->stream, E->V, E->np, W, \
+#define NMFX_WLAUNCH(A, O, K)                                                                  \
+    hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, E->V, E->np, W, \
                        E->H, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag)
-    if (with_a && with_obj) NMFX_WLAUNCH(true, true);
-    else if (with_a) NMFX_WLAUNCH(true, false);
-    else NMFX_WLAUNCH(false, true);
+    if (kl) {
+        if (with_a && with_obj) NMFX_WLAUNCH(true, true, true);
+        else if (with_a) NMFX_WLAUNCH(true, false, true);
+        else NMFX_WLAUNCH(false, true, true);
+    } else {
+        if (with_a && with_obj) NMFX_WLAUNCH(true, true, false);
+        else if (with_a) NMFX_WLAUNCH(true, false, false);
+        else NMFX_WLAUNCH(false, true, false);
+    }
 #undef NMFX_WLAUNCH
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
-int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj) {
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {
     ProfScope ps(E, with_a ? (with_obj ? "wphase" : "wphase_noobj") : "objective");
     switch (E->kp) {
-        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj);
-        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj);
-        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj);
-        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj);
+        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl);
+        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl);
+        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj, kl);
+        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj, kl);
     }
     E->err = "unsupported padded rank";
     return NMFX_E_ARG;

@@ -64,6 +64,7 @@ struct nmfx_engine {
     int wsplit = 1, hsplit = 1, gsplit = 1;
     bool have_v = false, have_f = false;
     int wsel = 0;                  // W buffer holding the current iterate
+    bool w_in_place = false;       // solver updates W[0] in place (all but MUR, which ping-pongs)
     // profiling
     bool prof = false;
     std::map<std::string, ProfSlot> prof_slots;
@@ -77,7 +78,7 @@ struct nmfx_engine {
 // ---- launch helpers implemented in the kernel translation units ---------
 // A_part[sp] = V(rows, cols of split sp) * H^T ; optionally the residual
 // objective 0.5*sum (V - W H)^2 into obj_part (one double per block).
-int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj);
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false);
 // B_part[sr] = W^T V over the rows of split sr.
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g);
 bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E);
@@ -86,6 +87,14 @@ inline int nmfx_g_slabs(const nmfx_engine* E) { return nmfx_hphase_can_fuse_gram
 // out_part[s] = X^T X  (X [rows][kp])  /  X X^T (X [kp][cols])
 int nmfx_launch_gram_tn(nmfx_engine* E, const float* X, int64_t rows, float* out_part, int splits);
 int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld, float* out_part, int splits);
+
+// shared small launchers (kernels_mur.hip / engine.hip)
+int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out);
+int nmfx_launch_pack(nmfx_engine* E);          // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
+int nmfx_launch_obj_reduce(nmfx_engine* E);    // xf64[0] = sum obj_part
+int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
+int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
 
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;

@@ -1,0 +1,50 @@
+"""AO-ADMM on the HIP engine vs the reference's golden outputs."""
+import numpy as np
+import pytest
+
+from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
+
+pytestmark = pytest.mark.gpu
+
+OBJ_RTOL = 5e-4
+
+CASES = ["aoadmm_eu_nn_planted", "aoadmm_eu_l1n_planted", "aoadmm_eu_nn_uniform", "aoadmm_eu_l1n_uniform"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_aoadmm_eu_matches_reference(name):
+    from nmf_amd.ao_admm import ao_admm
+    z, meta, v, res = run_fixture(name, ao_admm)
+    assert res.i == int(z["i"]) and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, z["w"], z["h"], v)
+    snaps = snapshot_errors(name, ao_admm) if err >= WH_TOL else {}
+    assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=OBJ_RTOL)
+    # inner iteration counts (device-side `terminate`) equal the reference's
+    assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])
+    assert res.experiment.prox_h == meta["kwargs"]["reg_h"][1]
+
+
+def test_aoadmm_converges_at_reference_iteration():
+    from nmf_amd.ao_admm import ao_admm
+    z, meta, v, res = run_fixture("aoadmm_eu_converge", ao_admm)
+    assert int(z["stop_rule"]) == 2
+    assert abs(res.i - int(z["i"])) <= 1, (res.i, int(z["i"]))
+    assert wh_error(res.w, res.h, z["w"], z["h"], v) < WH_TOL
+
+
+def test_aoadmm_error_behaviour():
+    from nmf_amd.ao_admm import ao_admm
+    v = np.random.RandomState(0).rand(40, 30)
+    with pytest.raises(ValueError):          # default reg_h = (0, 'l2n') raises in the reference too
+        ao_admm(v, 3, max_iter=2, nndsvd_init=(False, "zero"))
+    with pytest.raises(TypeError):
+        ao_admm(v, 3, max_iter=2, reg_h=(0, "bogus"), nndsvd_init=(False, "zero"))
+    with pytest.raises(np.linalg.LinAlgError):   # W = 0 -> Gram + rho I = 0 -> not PD (ao_admm.py:55)
+        import nmf_amd.utils as U
+        orig = U.initial_factors
+        U.initial_factors = lambda x, k, init, uniform=False: (np.zeros((40, 3)), np.abs(np.random.randn(3, 30)))
+        try:
+            ao_admm(v, 3, max_iter=3, reg_h=(0, "nn"), nndsvd_init=(False, "zero"))
+        finally:
+            U.initial_factors = orig

@@ -69,3 +69,29 @@ def test_large_shape_properties():
     direct = 0.5 * np.sum((v.astype(np.float64) - res.w @ res.h) ** 2)
     assert abs(direct - obj[-1]) <= 1e-5 * direct
     assert (res.w >= 0).all() and (res.h >= 0).all()
+
+
+KL = ["mur_kl", "mur_kl_lambda", "mur_kl_sparse"]
+
+
+@pytest.mark.parametrize("name", KL)
+def test_mur_kl_matches_reference(name):
+    from nmf_amd.mur import mur
+    z, meta, v, res = run_fixture(name, mur)
+    assert res.i == int(z["i"]) and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, z["w"], z["h"], v)
+    snaps = snapshot_errors(name, mur) if err >= WH_TOL else {}
+    assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
+    # KL objective: sum of v log(v/wh) - v + wh with cancellation between terms; f32 log
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=1e-3)
+
+
+def test_mur_kl_default_distance_is_kl_like_reference():
+    from nmf_amd.mur import mur
+    v = R.planted_matrix(128, 96, 4, seed=5, dtype=np.float64)
+    np.random.seed(2)
+    res = mur(v, 4, min_iter=3, max_iter=3)
+    assert res.experiment.distance_type == "kl"
+    np.random.seed(2)
+    ref = R.mur(v.copy(), 4, min_iter=3, max_iter=3)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
