@@ -57,8 +57,11 @@ const char* nmfx_last_error(nmfx_handle_t h);        /* h may be NULL           
 int nmfx_version(void);
 int nmfx_device_count(void);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of
- * the handle's own stream; NULL restores the internal one.                    */
+ * the handle's own non-blocking stream.  NULL is HIP's default (null) stream --
+ * which is what torch.cuda.current_stream() is unless the caller changed it.
+ * nmfx_reset_stream goes back to the handle's own stream.                      */
 int nmfx_set_stream(nmfx_handle_t h, void* hip_stream);
+int nmfx_reset_stream(nmfx_handle_t h);
 int nmfx_synchronize(nmfx_handle_t h);
 
 /* ---- data --------------------------------------------------------------- */

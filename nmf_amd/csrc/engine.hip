@@ -151,8 +151,17 @@ int nmfx_destroy(nmfx_handle_t E) {
 
 int nmfx_set_stream(nmfx_handle_t E, void* s) {
     if (!E) return NMFX_E_ARG;
-    hipStreamSynchronize(E->stream);
-    E->stream = s ? reinterpret_cast<hipStream_t>(s) : E->own_stream;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    E->stream = reinterpret_cast<hipStream_t>(s);      // NULL = HIP's default (null) stream
+    return NMFX_OK;
+}
+
+int nmfx_reset_stream(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    E->stream = E->own_stream;
     return NMFX_OK;
 }
 

@@ -28,18 +28,30 @@ def row_range(m, rank, world):
 
 
 class TorchComm:
-    """Sum-all-reduce of the engine's exchange buffers through torch.distributed."""
+    """Sum-all-reduce of the engine's exchange buffers through torch.distributed.
 
-    def __init__(self, group=None):
+    `stage_through_host=True` copies device tensors to the host, reduces them
+    with a CPU backend (gloo) and copies back: slow, but lets several ranks
+    share ONE GPU in tests where RCCL refuses duplicate devices."""
+
+    def __init__(self, group=None, stage_through_host=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stage = stage_through_host
 
     def all_reduce(self, *tensors):
         for t in tensors:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.stage and t.is_cuda:
+                import torch
+                torch.cuda.current_stream().synchronize()
+                host = t.cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def barrier(self):
         self.dist.barrier(group=self.group)

@@ -41,6 +41,9 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._ck(self.lib.nmfx_set_stream(self.h, C.c_void_p(stream_ptr)))
 
+    def reset_stream(self):
+        self._ck(self.lib.nmfx_reset_stream(self.h))
+
     def synchronize(self):
         self._ck(self.lib.nmfx_synchronize(self.h))
 
