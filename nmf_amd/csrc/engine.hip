@@ -104,11 +104,15 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     E->stream = E->own_stream;
     // split configuration: enough workgroups to fill 256 CUs twice over
     const int64_t rb = E->mp / 64, cb = E->np / 64;
+    // grids = a whole number of resident rounds: 256 CUs x blocks/CU of each kernel
+    int wocc = 2, hocc = 2, ncu = 256;
+    nmfx_phase_occupancy(E->kp, &wocc, &hocc);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     const char* ev;
-    const int64_t wtarget = (ev = getenv("NMFX_WBLOCKS")) ? atoll(ev) : 1024;
-    const int64_t htarget = (ev = getenv("NMFX_HBLOCKS")) ? atoll(ev) : 512;
-    int64_t ws = (wtarget + rb - 1) / rb; ws = std::max<int64_t>(1, std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4)));
-    int64_t hs = (htarget + cb - 1) / cb; hs = std::max<int64_t>(1, std::min<int64_t>(hs, rb));
+    const int64_t wtarget = (ev = getenv("NMFX_WBLOCKS")) ? atoll(ev) : (int64_t)ncu * wocc;
+    const int64_t htarget = (ev = getenv("NMFX_HBLOCKS")) ? atoll(ev) : (int64_t)ncu * hocc;
+    int64_t ws = std::max<int64_t>(1, (wtarget + rb / 2) / rb); ws = std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4));
+    int64_t hs = std::max<int64_t>(1, (htarget + cb / 2) / cb); hs = std::min<int64_t>(hs, rb);
     int64_t gs = std::min<int64_t>(8, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));
     E->wsplit = (int)ws; E->hsplit = (int)hs; E->gsplit = (int)gs;
     const int64_t kp = E->kp, mp = E->mp, np = E->np;

@@ -20,6 +20,32 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Make a loaded fragment opaque so hipcc keeps it in registers instead of
+// re-issuing the (restrict, read-only) load inside the main loop, where its
+// s_waitcnt vmcnt(0) would drain the software-pipelined prefetch.
+__device__ __forceinline__ void pin(float4& v) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
+// LDS-DMA: 16 bytes per lane from a per-lane global address to wave-uniform LDS base
+// + lane*16 (global_load_lds_dwordx4), asynchronous, tracked by vmcnt.  Issued through
+// inline asm on purpose: with the builtin, hipcc treats the DMA as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of the (single) LDS array,
+// which serialises prefetch and compute.  The asm form is invisible to that
+// bookkeeping, so the caller owns the wait: dma_wait_all() before the barrier that
+// publishes the tile (cdna_hip_programming.md 5.7: M0 is written in the same statement).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst_wave_base) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // XOR swizzle of the 16-byte slot inside a 64-float LDS row; conflict-free for
 // both read patterns of wphase (derivation in DESIGN.md, "H tile image").
 __device__ __forceinline__ int swz(int row) {
@@ -29,9 +55,12 @@ __device__ __forceinline__ int swz(int row) {
 
 // --------------------------------------------------------------------------
 // wphase: one block = 64 rows (4 waves x 16 rows) x column groups [g0, g1).
-// Per 64-column group a wave holds its 16x64 slice of V in 16 VGPRs (loaded
-// straight from HBM, read exactly once), the H tile [KP][64] is shared through
-// LDS (double buffered).
+// Per 64-column group a wave holds its 16x64 slice of V in 16 VGPRs.  V is read
+// from HBM exactly once, with coalesced loads (4 rows x 256 B per wave
+// instruction, prefetched one group ahead) into a wave-private swizzled LDS tile
+// from which the MFMA fragments are read (fragment-shaped global loads -- 16
+// rows x 16 B per quarter wave -- ran at 2 TB/s; this form does not).  The H
+// tile [KP][64] is shared through LDS (double buffered).
 //   A-product : acc[jt] += V(16x64) . Htile^T         -> A[16][KP]
 //   D-product : d[e]    = (W Htile) transposed tiles  -> residual V - W H
 // The D tiles come out of the MFMA in exactly the register layout the V slice
@@ -46,59 +75,75 @@ __global__ __launch_bounds__(256) void wphase_kernel(
 {
     if (*flag) return;
     constexpr int JT = KP / 16;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x KP x 64
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [KP][64] H tiles + 4 x [16][64] V tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, q = lane >> 4;
     const int S = gridDim.y, sp = blockIdx.y;
     const int g0 = (int)((int64_t)ngroups * sp / S);
     const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
     const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
-    const float* vrow = V + (r0 + x) * ldv + 16 * q;
 
     float4 wf[JT];
 #pragma unroll
     for (int u = 0; u < JT; ++u)
         wf[u] = *reinterpret_cast<const float4*>(W + (r0 + x) * KP + 16 * u + 4 * q);
+#pragma unroll
+    for (int u = 0; u < JT; ++u) pin(wf[u]);
 
     f32x4 acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     double osum = 0.0;
 
-    // staging map: thread -> (row = 16 p + tid/16, 16-byte column chunk tid%16)
-    const int srow = tid >> 4, sc4 = tid & 15;
-    const int sdst = srow * 64 + 4 * (sc4 ^ swz(srow));
-    const float* hsrc = H + (int64_t)srow * ldh + 4 * sc4;
+    // Staging by LDS-DMA.  One wave instruction fills 1 KiB of LDS linearly (4 tile rows
+    // of 256 B); the XOR swizzle is applied to the per-lane SOURCE address: lane
+    // (row q of the 4, position x) fetches chunk x ^ swz(row), so position p of a row
+    // holds chunk p ^ swz(row) -- the image the swizzled fragment reads expect.
+    //   H tile [KP][64]: wave w fills rows 4*(JT*w + p) .. +3, p < JT
+    //   V tile [16][64] (wave-private): rows 4t .. 4t+3, t < 4
+    float* vt = lds + 2 * KP * 64 + wave * (16 * 64);
+    const float* hsrc[JT];
+    const float* vsrc[4];
+#pragma unroll
+    for (int p = 0; p < JT; ++p) {
+        const int row = 4 * (JT * wave + p) + q;
+        hsrc[p] = H + (int64_t)row * ldh + 4 * (x ^ swz(row));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = 4 * t + q;
+        vsrc[t] = V + (r0 + row) * ldv + 4 * (x ^ swz(row));
+    }
     // read maps
-    const int gx = swz(x);                 // A-product: rows jt*16 + x
+    const int gx = swz(x);                 // rows with (row & 15) == x: H tile A-product, V tile
     int dslot[4];                          // D-product: rows 16u + 4q + s
 #pragma unroll
     for (int s = 0; s < 4; ++s) dslot[s] = (4 * q + s) * 64 + 4 * (x ^ swz(4 * q + s));
 
-    float4 hn[JT], vf[4], vn[4];
+    float4 vf[4];
     if (g0 < g1) {
 #pragma unroll
-        for (int p = 0; p < JT; ++p)
-            hn[p] = *reinterpret_cast<const float4*>(hsrc + (int64_t)p * 16 * ldh + (int64_t)g0 * 64);
+        for (int p = 0; p < JT; ++p) dma16(hsrc[p] + (int64_t)g0 * 64, lds_addr(lds + (JT * wave + p) * 256));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            vf[i] = *reinterpret_cast<const float4*>(vrow + (int64_t)g0 * 64 + 4 * i);
-#pragma unroll
-        for (int p = 0; p < JT; ++p)
-            *reinterpret_cast<float4*>(lds + p * 16 * 64 + sdst) = hn[p];
+        for (int t = 0; t < 4; ++t) dma16(vsrc[t] + (int64_t)g0 * 64, lds_addr(vt + t * 256));
     }
+    dma_wait_all();
     __syncthreads();
 
     int cur = 0;
     for (int g = g0; g < g1; ++g) {
-        const bool more = (g + 1 < g1);
-        if (more) {
+        // this wave's 16 x 64 slice of V: lane (x, q) holds V[x][16q + 4i + e] in vf[i].e
 #pragma unroll
-            for (int p = 0; p < JT; ++p)
-                hn[p] = *reinterpret_cast<const float4*>(hsrc + (int64_t)p * 16 * ldh + (int64_t)(g + 1) * 64);
+        for (int i = 0; i < 4; ++i)
+            vf[i] = *reinterpret_cast<const float4*>(vt + x * 64 + 4 * ((4 * q + i) ^ gx));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                vn[i] = *reinterpret_cast<const float4*>(vrow + (int64_t)(g + 1) * 64 + 4 * i);
+        for (int i = 0; i < 4; ++i) pin(vf[i]);       // reads retired before the tile is refilled
+        if (g + 1 < g1) {
+            float* nb = lds + (cur ^ 1) * (KP * 64);
+#pragma unroll
+            for (int p = 0; p < JT; ++p) dma16(hsrc[p] + (int64_t)(g + 1) * 64, lds_addr(nb + (JT * wave + p) * 256));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dma16(vsrc[t] + (int64_t)(g + 1) * 64, lds_addr(vt + t * 256));
         }
         const float* buf = lds + cur * (KP * 64);
 
@@ -163,14 +208,7 @@ __global__ __launch_bounds__(256) void wphase_kernel(
                 for (int jt = 0; jt < JT; ++jt) acc[jt] = MFMA(vf[i].w, hb[jt].w, acc[jt]);
             }
         }
-        if (more) {
-            float* nb = lds + (cur ^ 1) * (KP * 64);
-#pragma unroll
-            for (int p = 0; p < JT; ++p)
-                *reinterpret_cast<float4*>(nb + p * 16 * 64 + sdst) = hn[p];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vf[i] = vn[i];
-        }
+        dma_wait_all();          // next tiles have landed (issued a whole group of MFMA work ago)
         __syncthreads();
         cur ^= 1;
     }
@@ -249,10 +287,10 @@ __global__ __launch_bounds__(256) void hphase_kernel(
         }
     }
     for (; s < sfull; s += UN) {
-        const bool more = (s + UN < sfull);
-        if (more) {
-            const float* vq = vp + (int64_t)UN * 4 * ldv;
-            const float* wq = wp + (int64_t)UN * 4 * KP;
+        {   // branch-free prefetch of the next stage (the last one re-reads its own rows)
+            const int64_t adv = (s + UN < sfull) ? UN : 0;
+            const float* vq = vp + adv * 4 * ldv;
+            const float* wq = wp + adv * 4 * KP;
 #pragma unroll
             for (int t = 0; t < UN; ++t) {
                 vbn[t] = *reinterpret_cast<const float4*>(vq + (int64_t)t * 4 * ldv);
@@ -260,6 +298,7 @@ __global__ __launch_bounds__(256) void hphase_kernel(
                 for (int j = 0; j < JT; ++j) wan[t][j] = wq[(int64_t)t * 4 * KP + 16 * j];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < UN; ++t) {
 #pragma unroll
@@ -278,13 +317,11 @@ __global__ __launch_bounds__(256) void hphase_kernel(
         }
         vp += (int64_t)UN * 4 * ldv;
         wp += (int64_t)UN * 4 * KP;
-        if (more) {
 #pragma unroll
-            for (int t = 0; t < UN; ++t) {
-                vb[t] = vbn[t];
+        for (int t = 0; t < UN; ++t) {
+            vb[t] = vbn[t];
 #pragma unroll
-                for (int j = 0; j < JT; ++j) wa[t][j] = wan[t][j];
-            }
+            for (int j = 0; j < JT; ++j) wa[t][j] = wan[t][j];
         }
     }
     for (; s < s1; ++s) {                               // remainder k-steps
@@ -469,11 +506,19 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
 template <int KP>
 static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
-    const size_t shm = (size_t)2 * KP * 64 * sizeof(float);
+    const size_t shm = (size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float);
     const int ng = (int)(E->np / 64);
 #define NMFX_WLAUNCH(A, O, K)                                                                  \
-    hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, E->V, E->np, W, \
-                       E->H, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag)
+    do {                                                                                       \
+        static bool big_lds_ok = false;                                                        \
+        if (shm > 64 * 1024 && !big_lds_ok) {                                                  \
+            NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wphase_kernel<KP, A, O, K>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+            big_lds_ok = true;                                                                 \
+        }                                                                                      \
+        hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, E->V, E->np, W, \
+                           E->H, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag);   \
+    } while (0)
     if (kl) {
         if (with_a && with_obj) NMFX_WLAUNCH(true, true, true);
         else if (with_a) NMFX_WLAUNCH(true, false, true);
@@ -486,6 +531,32 @@ static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool wit
 #undef NMFX_WLAUNCH
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+
+// Resident workgroups per CU of the two V-sized kernels (register / LDS bound);
+// nmfx_create sizes the grids to a whole number of resident waves of blocks so
+// that no partially filled tail round is left.
+template <int KP>
+static void occupancy_of(int* wocc, int* hocc) {
+    int a = 0, b = 0;
+    if ((size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float) > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wphase_kernel<KP, true, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((2 * KP * 64 + 4 * 16 * 64) * sizeof(float)));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, wphase_kernel<KP, true, true, false>, 256,
+                                                     (size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float)) != hipSuccess) a = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, hphase_kernel<KP, true>, 256,
+                                                     (size_t)KP * 64 * sizeof(float)) != hipSuccess) b = 2;
+    *wocc = std::max(1, a); *hocc = std::max(1, b);
+}
+
+void nmfx_phase_occupancy(int kp, int* wocc, int* hocc) {
+    switch (kp) {
+        case 16: occupancy_of<16>(wocc, hocc); break;
+        case 32: occupancy_of<32>(wocc, hocc); break;
+        case 64: occupancy_of<64>(wocc, hocc); break;
+        default: occupancy_of<128>(wocc, hocc); break;
+    }
 }
 
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {

@@ -82,6 +82,7 @@ int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_ob
 // B_part[sr] = W^T V over the rows of split sr.
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g);
 bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E);
+void nmfx_phase_occupancy(int kp, int* wocc, int* hocc);
 // number of W^T W partial slabs the H phase leaves in G_part
 inline int nmfx_g_slabs(const nmfx_engine* E) { return nmfx_hphase_can_fuse_gram(E) ? E->hsplit : E->gsplit; }
 // out_part[s] = X^T X  (X [rows][kp])  /  X X^T (X [kp][cols])
