@@ -137,6 +137,12 @@ int nmfx_aoadmm_finish(nmfx_handle_t h, int64_t min_iter, double tol1, double to
 int nmfx_get_inner_counts(nmfx_handle_t h, int64_t first, int64_t count, int32_t* out_pairs);
 
 /* ---- ADMM (replaces nmf/admm.py:292-334) -------------------------------- */
+/* prox 'l2n' (nmf/admm.py:141-156) solves (1/rho)(lambda T^T T + rho I) X = aux - dual
+ * with the k x k second-difference operator T; since rho and lambda are fixed
+ * for a run the caller supplies the k x k inverse P (float64, row-major) once:
+ * which = 0 for the W regulariser, 1 for H.  The finish call of AO-ADMM
+ * (nmfx_aoadmm_finish) is shared by ADMM.                                     */
+int nmfx_set_l2n_operator(nmfx_handle_t h, int which, const double* p_inverse);
 int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double lambda_w,
                   int prox_h, double lambda_h, int64_t min_iter, double tol1,
                   double tol2, int64_t first, int64_t count);

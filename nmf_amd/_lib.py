@@ -47,6 +47,7 @@ SIGNATURES = {
     "nmfx_aoadmm_run": (_i32, [_vp, _i32, _i32, _dbl, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_aoadmm_finish": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
     "nmfx_get_inner_counts": (_i32, [_vp, _i64, _i64, _vp]),
+    "nmfx_set_l2n_operator": (_i32, [_vp, _i32, _vp]),
     "nmfx_admm_run": (_i32, [_vp, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_anls_run": (_i32, [_vp, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_profile_enable": (_i32, [_vp, _i32]),

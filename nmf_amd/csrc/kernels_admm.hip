@@ -1,0 +1,105 @@
+// ADMM (single-level) outer iteration, Euclidean loss.
+//   reference: nmf/admm.py:292-334; aux_update :216-230 (np.linalg.solve of the
+//   shifted Gram system), prox :117-156, initialize :17-35.
+//
+//   h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T V + rho (h + dual_h))
+//   w_aux = ((h_aux h_aux^T + rho I)^-1 (h_aux V^T + rho (w^T + dual_w^T)))^T
+//   h = prox(h_aux, dual_h);  w = prox(w_aux, dual_w);  duals += x - x_aux
+//
+// Each half is exactly one round of the AO-ADMM kernels (kernels_aoadmm.hip) with a
+// fixed rho and the aux matrix kept; prox 'l2n' (a k x k banded solve in the
+// reference, admm.py:141-156) is a second product with the fixed k x k inverse
+// P = ((lambda T^T T + rho I) / rho)^-1 supplied by the host (nmfx_set_l2n_operator).
+#include "nmfx_internal.h"
+#include "kernels_small.h"
+#include <vector>
+
+template <typename T>
+static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
+    if (*p) return NMFX_OK;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T)));
+    NMFX_HIP(hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), E->stream));
+    return NMFX_OK;
+}
+
+static int admm_alloc(nmfx_engine* E) {
+    int rc;
+    if ((rc = nmfx_aoadmm_alloc(E))) return rc;
+    if ((rc = lazy_alloc(E, &E->auxH, (int64_t)E->kp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->Asum, E->mp * E->kp))) return rc;
+    return NMFX_OK;
+}
+
+static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                             int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    // ---- h_aux and the H half ----
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, E->auxW, fuse_g))) return rc;
+    if ((rc = nmfx_launch_pack(E))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
+    { ProfScope ps(E, "inner_h");
+      if (prox_h == NMFX_PROX_L2N) {
+          if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+          if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
+      } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc; }
+    // ---- w_aux (from the NEW h_aux) and the W half ----
+    if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->auxH))) return rc;
+    { ProfScope ps(E, "sums");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+      if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc; }
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, rho))) return rc;
+    { ProfScope ps(E, "inner_w");
+      if (prox_w == NMFX_PROX_L2N) {
+          if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+          if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
+      } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc; }
+    // ---- objective of (w, h) (admm.py:324) ----
+    return nmfx_launch_wphase(E, W, false, true);
+}
+
+extern "C" int nmfx_set_l2n_operator(nmfx_handle_t E, int which, const double* p) {
+    if (!E || !p || (which != 0 && which != 1)) { if (E) E->err = "set_l2n_operator: bad argument"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    float** dst = which == 0 ? &E->Pw : &E->Ph;
+    int rc;
+    if ((rc = lazy_alloc(E, dst, (int64_t)E->kp * E->kp))) return rc;
+    std::vector<float> tmp((size_t)E->kp * E->kp, 0.f);
+    for (int i = 0; i < E->k; ++i)
+        for (int c = 0; c < E->k; ++c) tmp[(size_t)i * E->kp + c] = (float)p[(size_t)i * E->k + c];
+    NMFX_HIP(hipMemcpyAsync(*dst, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
+                             double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
+                             int64_t count) {
+    if (!E) return NMFX_E_ARG;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (distance != NMFX_EU) { E->err = "ADMM with KL loss is not built yet"; return NMFX_E_ARG; }
+    auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N; };
+    if (bad(prox_w) || bad(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (first < 0 || count < 0 || !(rho > 0.0)) { E->err = "bad range or rho"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = admm_alloc(E))) return rc;
+    if ((prox_w == NMFX_PROX_L2N && !E->Pw) || (prox_h == NMFX_PROX_L2N && !E->Ph)) {
+        E->err = "l2n prox needs nmfx_set_l2n_operator first"; return NMFX_E_STATE; }
+    if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
+    E->wsel = 0;
+    E->w_in_place = true;
+    if (first == 0 && count > 0) {
+        // w_aux = w, h_aux = h (admm.py:27-28); obj[0] (admm.py:289)
+        NMFX_HIP(hipMemcpyAsync(E->auxW, E->W[0], (size_t)E->mp * E->kp * 4, hipMemcpyDeviceToDevice, E->stream));
+        NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
+        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;
+    }
+    for (int64_t j = first; j < first + count; ++j)
+        if ((rc = admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    return NMFX_OK;
+}

@@ -125,11 +125,15 @@ __device__ __forceinline__ void block_store_norms(float n0, float n1, float n2, 
 
 // ---- H-side round: X is [KP][np] (columns independent), aux = Minv * RHS ---
 // block = 64 columns; wave w owns row tiles {w, w+4, ...}; RHS tile through LDS.
+// mode 0: the round described above (aux additionally stored when AUX != null);
+// mode 1: aux = Minv * (B + rho (X + U)) stored to AUX only            (ADMM, l2n step 1)
+// mode 2: X = max(P * (AUX - U), 0), U += X - AUX with P in `Minv`     (ADMM, l2n step 2:
+//         prox 'l2n' of nmf/admm.py:141-156 is a k x k solve = product with a fixed inverse)
 template <int KP>
 __global__ __launch_bounds__(256) void ao_inner_cols_kernel(
     const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U,
-    const float* __restrict__ Minv, int64_t np, int prox, float lam, int round,
-    DevState* __restrict__ st, double* __restrict__ nrm)       // nrm: [2][nblk][4]
+    const float* __restrict__ Minv, float* __restrict__ AUX, int mode, int64_t np, int prox, float lam,
+    int round, DevState* __restrict__ st, double* __restrict__ nrm)       // nrm: [2][nblk][4]
 {
     if (st->flag || st->inner_stop) return;
     constexpr int JT = KP / 16;
@@ -152,12 +156,17 @@ __global__ __launch_bounds__(256) void ao_inner_cols_kernel(
 #pragma unroll
         for (int p = 0; p < JT; ++p) {
             const int64_t g = (int64_t)(p * 16 + srow) * np + c0 + 4 * sc;
-            const float4 b = *reinterpret_cast<const float4*>(Bsum + g);
-            const float4 h = *reinterpret_cast<const float4*>(X + g);
             const float4 u = *reinterpret_cast<const float4*>(U + g);
             float4 r;
-            r.x = b.x + rho * (h.x + u.x); r.y = b.y + rho * (h.y + u.y);
-            r.z = b.z + rho * (h.z + u.z); r.w = b.w + rho * (h.w + u.w);
+            if (mode == 2) {
+                const float4 a = *reinterpret_cast<const float4*>(AUX + g);
+                r.x = a.x - u.x; r.y = a.y - u.y; r.z = a.z - u.z; r.w = a.w - u.w;
+            } else {
+                const float4 b = *reinterpret_cast<const float4*>(Bsum + g);
+                const float4 h = *reinterpret_cast<const float4*>(X + g);
+                r.x = b.x + rho * (h.x + u.x); r.y = b.y + rho * (h.y + u.y);
+                r.z = b.z + rho * (h.z + u.z); r.w = b.w + rho * (h.w + u.w);
+            }
             *reinterpret_cast<float4*>(lds + (p * 16 + srow) * 64 + 4 * sc) = r;
         }
     }
@@ -192,14 +201,25 @@ __global__ __launch_bounds__(256) void ao_inner_cols_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
+                float ax[4] = {acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                if (mode == 1) {
+                    *reinterpret_cast<float4*>(AUX + idx) = make_float4(ax[0], ax[1], ax[2], ax[3]);
+                    continue;
+                }
                 const float4 h = *reinterpret_cast<const float4*>(X + idx);
                 const float4 u = *reinterpret_cast<const float4*>(U + idx);
-                const float ax[4] = {acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
                 const float hx[4] = {h.x, h.y, h.z, h.w}, ux[4] = {u.x, u.y, u.z, u.w};
                 float hn[4], un[4];
+                float zx[4] = {ax[0], ax[1], ax[2], ax[3]};          // mode 2: P (aux - U)
+                if (mode == 2) {
+                    const float4 a = *reinterpret_cast<const float4*>(AUX + idx);
+                    ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w;
+                } else if (AUX) {
+                    *reinterpret_cast<float4*>(AUX + idx) = make_float4(ax[0], ax[1], ax[2], ax[3]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    hn[e] = prox_apply(ax[e], ux[e], shift);
+                    hn[e] = (mode == 2) ? ((zx[e] < 0.f) ? 0.f : zx[e]) : prox_apply(ax[e], ux[e], shift);
                     un[e] = ux[e] + hn[e] - ax[e];
                     const float d0 = hn[e] - ax[e], d2 = hn[e] - hx[e];
                     n0 += d0 * d0; n1 += hn[e] * hn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(256) void ao_inner_cols_kernel(
 template <int KP>
 __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
     const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U,
-    const float* __restrict__ Minv, int prox, float lam, int round,
+    const float* __restrict__ Minv, float* __restrict__ AUX, int mode, int prox, float lam, int round,
     DevState* __restrict__ st, double* __restrict__ nrm)
 {
     if (st->flag || st->inner_stop) return;
@@ -244,11 +264,16 @@ __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
 #pragma unroll
     for (int u = 0; u < JT; ++u) {
         const int64_t g = (r0 + x) * KP + 16 * u + 4 * q;
-        const float4 a = *reinterpret_cast<const float4*>(Asum + g);
-        const float4 w = *reinterpret_cast<const float4*>(X + g);
         const float4 d = *reinterpret_cast<const float4*>(U + g);
-        xf[u].x = a.x + rho * (w.x + d.x); xf[u].y = a.y + rho * (w.y + d.y);
-        xf[u].z = a.z + rho * (w.z + d.z); xf[u].w = a.w + rho * (w.w + d.w);
+        if (mode == 2) {
+            const float4 a = *reinterpret_cast<const float4*>(AUX + g);
+            xf[u].x = a.x - d.x; xf[u].y = a.y - d.y; xf[u].z = a.z - d.z; xf[u].w = a.w - d.w;
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(Asum + g);
+            const float4 w = *reinterpret_cast<const float4*>(X + g);
+            xf[u].x = a.x + rho * (w.x + d.x); xf[u].y = a.y + rho * (w.y + d.y);
+            xf[u].z = a.z + rho * (w.z + d.z); xf[u].w = a.w + rho * (w.w + d.w);
+        }
     }
     __syncthreads();
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
@@ -266,8 +291,13 @@ __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
-            const float w = X[idx], d = U[idx], ax = acc[g];
-            const float wn = prox_apply(ax, d, shift);
+            if (mode == 1) { AUX[idx] = acc[g]; continue; }
+            const float w = X[idx], d = U[idx];
+            float ax = acc[g];
+            const float z = ax;
+            if (mode == 2) ax = AUX[idx];
+            else if (AUX) AUX[idx] = ax;
+            const float wn = (mode == 2) ? ((z < 0.f) ? 0.f : z) : prox_apply(ax, d, shift);
             const float dn = d + wn - ax;
             const float d0 = wn - ax, d2 = wn - w;
             n0 += d0 * d0; n1 += wn * wn; n2 += d2 * d2; n3 += dn * dn;
@@ -337,46 +367,56 @@ int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_
 }
 
 template <int KP>
-static int launch_inner_cols(nmfx_engine* E, int prox, float lam, int round) {
+static int launch_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int prox, float lam, int round) {
     const size_t shm = (size_t)KP * 64 * sizeof(float) + 16 * sizeof(double);
     hipLaunchKernelGGL((ao_inner_cols_kernel<KP>), dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream,
-                       E->xf32, E->H, E->dualH, E->Minv, E->np, prox, lam, round, E->state, E->nrm_part);
+                       E->xf32, E->H, E->dualH, M, aux, mode, E->np, prox, lam, round, E->state, E->nrm_part);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
 template <int KP>
-static int launch_inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round) {
+static int launch_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode,
+                             int prox, float lam, int round) {
     const size_t shm = (size_t)KP * (KP + 4) * sizeof(float) + 16 * sizeof(double);
     auto kern = ao_inner_rows_kernel<KP>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, E->auxW, W, E->dualW,
-                       E->Minv, prox, lam, round, E->state, E->nrm_part);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, Asum, W, E->dualW,
+                       M, aux, mode, prox, lam, round, E->state, E->nrm_part);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
-static int inner_cols(nmfx_engine* E, int prox, float lam, int round) {
+int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int prox, float lam, int round) {
     switch (E->kp) {
-        case 16: return launch_inner_cols<16>(E, prox, lam, round);
-        case 32: return launch_inner_cols<32>(E, prox, lam, round);
-        case 64: return launch_inner_cols<64>(E, prox, lam, round);
-        default: return launch_inner_cols<128>(E, prox, lam, round);
+        case 16: return launch_inner_cols<16>(E, M, aux, mode, prox, lam, round);
+        case 32: return launch_inner_cols<32>(E, M, aux, mode, prox, lam, round);
+        case 64: return launch_inner_cols<64>(E, M, aux, mode, prox, lam, round);
+        default: return launch_inner_cols<128>(E, M, aux, mode, prox, lam, round);
     }
+}
+
+int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
+                    float lam, int round) {
+    switch (E->kp) {
+        case 16: return launch_inner_rows<16>(E, Asum, W, M, aux, mode, prox, lam, round);
+        case 32: return launch_inner_rows<32>(E, Asum, W, M, aux, mode, prox, lam, round);
+        case 64: return launch_inner_rows<64>(E, Asum, W, M, aux, mode, prox, lam, round);
+        default: return launch_inner_rows<128>(E, Asum, W, M, aux, mode, prox, lam, round);
+    }
+}
+
+static int inner_cols(nmfx_engine* E, int prox, float lam, int round) {
+    return nmfx_inner_cols(E, E->Minv, nullptr, 0, prox, lam, round);
 }
 
 static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round) {
-    switch (E->kp) {
-        case 16: return launch_inner_rows<16>(E, W, prox, lam, round);
-        case 32: return launch_inner_rows<32>(E, W, prox, lam, round);
-        case 64: return launch_inner_rows<64>(E, W, prox, lam, round);
-        default: return launch_inner_rows<128>(E, W, prox, lam, round);
-    }
+    return nmfx_inner_rows(E, E->auxW, W, E->Minv, nullptr, 0, prox, lam, round);
 }
 
-static int inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot) {
+int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot) {
     hipLaunchKernelGGL(ao_inner_finish_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part, nblk,
                        admm_iter, slot);
     NMFX_HIP(hipGetLastError());
@@ -397,7 +437,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
     { ProfScope ps(E, "inner_h");
       for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
-      if ((rc = inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc; }
+      if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc; }
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
@@ -407,7 +447,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
     { ProfScope ps(E, "inner_w");
       for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
-      if ((rc = inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
+      if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
     // ---- objective of the new pair (utils.py:29), summed by the next pack / finish ----
     return nmfx_launch_wphase(E, W, false, true);
 }

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
 // launchers
 // --------------------------------------------------------------------------
 template <int KP>
-static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {
+static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc) {
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float);
     const int ng = (int)(E->np / 64);
@@ -517,7 +517,7 @@ static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool wit
             big_lds_ok = true;                                                                 \
         }                                                                                      \
         hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, E->V, E->np, W, \
-                           E->H, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag);   \
+                           Hsrc, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag);   \
     } while (0)
     if (kl) {
         if (with_a && with_obj) NMFX_WLAUNCH(true, true, true);
@@ -559,13 +559,14 @@ void nmfx_phase_occupancy(int kp, int* wocc, int* hocc) {
     }
 }
 
-int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl) {
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc) {
     ProfScope ps(E, with_a ? (with_obj ? "wphase" : "wphase_noobj") : "objective");
+    if (!Hsrc) Hsrc = E->H;
     switch (E->kp) {
-        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl);
-        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl);
-        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj, kl);
-        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj, kl);
+        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl, Hsrc);
+        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl, Hsrc);
+        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj, kl, Hsrc);
+        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj, kl, Hsrc);
     }
     E->err = "unsupported padded rank";
     return NMFX_E_ARG;

@@ -58,6 +58,8 @@ struct nmfx_engine {
     float* dualW = nullptr; float* dualH = nullptr;     // like W / H
     float* auxW = nullptr;  float* auxH = nullptr;
     float* Minv = nullptr;         // [kp][kp] (G + rho I)^-1
+    float* Pw = nullptr; float* Ph = nullptr;   // [kp][kp] fixed l2n prox operators (ADMM)
+    float* Asum = nullptr;         // [mp][kp] summed V H^T (ADMM)
     double* nrm_part = nullptr;    // [blocks][4]
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
@@ -78,7 +80,8 @@ struct nmfx_engine {
 // ---- launch helpers implemented in the kernel translation units ---------
 // A_part[sp] = V(rows, cols of split sp) * H^T ; optionally the residual
 // objective 0.5*sum (V - W H)^2 into obj_part (one double per block).
-int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false);
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false,
+                       const float* Hsrc = nullptr);   // Hsrc: use this [kp][np] matrix instead of E->H
 // B_part[sr] = W^T V over the rows of split sr.
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g);
 bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E);
@@ -96,6 +99,15 @@ int nmfx_launch_obj_reduce(nmfx_engine* E);    // xf64[0] = sum obj_part
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
+
+// AO-ADMM / ADMM building blocks (kernels_aoadmm.hip)
+int nmfx_aoadmm_alloc(nmfx_engine* E);
+int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
+                        double tol1, double tol2, double fixed_rho);
+int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int prox, float lam, int round);
+int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
+                    float lam, int round);
+int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot);
 
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;

@@ -1,8 +1,6 @@
 // Entry points declared in include/nmfx.h whose device path is not built yet.
 #include "nmfx_internal.h"
 extern "C" {
-int nmfx_admm_run(nmfx_handle_t E, int, double, int, double, int, double, int64_t, double, double, int64_t, int64_t) {
-    if (E) E->err = "ADMM: not built yet"; return NMFX_E_ARG; }
 int nmfx_anls_run(nmfx_handle_t E, double, double, int64_t, double, double, int64_t, int64_t) {
     if (E) E->err = "ANLS: not built yet"; return NMFX_E_ARG; }
 }

@@ -127,6 +127,10 @@ class Engine:
     def aoadmm_finish(self, min_iter, tol1, tol2, done):
         self._ck(self.lib.nmfx_aoadmm_finish(self.h, int(min_iter), float(tol1), float(tol2), int(done)))
 
+    def set_l2n_operator(self, which, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self._ck(self.lib.nmfx_set_l2n_operator(self.h, int(which), _ptr(p)))
+
     def admm_run(self, dist, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, first, count):
         self._ck(self.lib.nmfx_admm_run(self.h, dist, float(rho), prox_w, float(lam_w), prox_h,
                                         float(lam_h), int(min_iter), float(tol1), float(tol2),
