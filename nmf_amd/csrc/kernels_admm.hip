@@ -62,6 +62,35 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     return nmfx_launch_wphase(E, W, false, true);
 }
 
+// KL loss (admm.py:303-315): the Gram right-hand sides multiply S = v_aux + dual_v, and
+// v_aux / dual_v are refreshed from w_aux @ h_aux at the end of the iteration.
+static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                             int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, E->auxW, fuse_g, E->S))) return rc;
+    if ((rc = nmfx_launch_pack(E))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
+    if (prox_h == NMFX_PROX_L2N) {
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+        if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
+    } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc;
+    if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->auxH, E->S))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, rho))) return rc;
+    if (prox_w == NMFX_PROX_L2N) {
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
+    } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc;
+    if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->auxH))) return rc;
+    return nmfx_launch_wphase(E, W, false, true, true);
+}
+
 extern "C" int nmfx_set_l2n_operator(nmfx_handle_t E, int which, const double* p) {
     if (!E || !p || (which != 0 && which != 1)) { if (E) E->err = "set_l2n_operator: bad argument"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
@@ -81,13 +110,14 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
                              int64_t count) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
-    if (distance != NMFX_EU) { E->err = "ADMM with KL loss is not built yet"; return NMFX_E_ARG; }
+    if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
     auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N; };
     if (bad(prox_w) || bad(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || !(rho > 0.0)) { E->err = "bad range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
     if ((rc = admm_alloc(E))) return rc;
+    if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
     if ((prox_w == NMFX_PROX_L2N && !E->Pw) || (prox_h == NMFX_PROX_L2N && !E->Ph)) {
         E->err = "l2n prox needs nmfx_set_l2n_operator first"; return NMFX_E_STATE; }
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
@@ -97,9 +127,13 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
         // w_aux = w, h_aux = h (admm.py:27-28); obj[0] (admm.py:289)
         NMFX_HIP(hipMemcpyAsync(E->auxW, E->W[0], (size_t)E->mp * E->kp * 4, hipMemcpyDeviceToDevice, E->stream));
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
-        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;
+        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
     }
-    for (int64_t j = first; j < first + count; ++j)
-        if ((rc = admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    for (int64_t j = first; j < first + count; ++j) {
+        rc = distance == NMFX_EU
+            ? admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)
+            : admm_kl_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
+        if (rc) return rc;
+    }
     return NMFX_OK;
 }

@@ -331,6 +331,15 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 }
 
 
+int nmfx_kl_state_alloc(nmfx_engine* E) {      // m x n auxiliaries of the KL-loss ADMM variants
+    int rc;
+    if ((rc = lazy_alloc(E, &E->S, E->mp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->DV, E->mp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->auxH, (int64_t)E->kp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->Asum, E->mp * E->kp))) return rc;
+    return NMFX_OK;
+}
+
 int nmfx_aoadmm_alloc(nmfx_engine* E) {
     int rc;
     if ((rc = lazy_alloc(E, &E->dualW, E->mp * E->kp))) return rc;
@@ -452,28 +461,70 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     return nmfx_launch_wphase(E, W, false, true);
 }
 
+// One outer iteration of ao_admm.py:272-285 (KL loss, admm_kl_update :71-101).  The
+// m x n state is S = v_aux + dual_v and dual_v; every inner round costs one W^T S (or
+// S H^T) pass plus the fused v_aux / dual_v update.
+static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
+                               int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const int* stop = &E->state->inner_stop;
+    // ---- H sub-problem ----
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, W, fuse_g, E->S))) return rc;
+    if ((rc = nmfx_launch_pack(E))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+    for (int r = 0; r < admm_iter; ++r) {
+        if (r > 0) {
+            if ((rc = nmfx_launch_hphase(E, W, false, E->S, stop))) return rc;
+            if ((rc = nmfx_launch_pack(E, stop))) return rc;
+        }
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, r))) return rc;
+        if ((rc = nmfx_launch_kl_vaux(E, W, E->auxH, stop))) return rc;
+    }
+    if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
+    // ---- W sub-problem (transposed data) ----
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
+    for (int r = 0; r < admm_iter; ++r) {
+        if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->H, E->S, stop))) return rc;
+        if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, r))) return rc;
+        if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->H, stop))) return rc;
+    }
+    if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+    return nmfx_launch_wphase(E, W, false, true, true);            // KL objective (utils.py:21-26)
+}
+
 extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double lambda_w, int prox_h,
                                double lambda_h, int admm_iter, int64_t min_iter, double tol1, double tol2,
                                int64_t first, int64_t count) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
-    if (distance != NMFX_EU) { E->err = "AO-ADMM with KL loss is not built yet"; return NMFX_E_ARG; }
+    if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss function type."; return NMFX_E_ARG; }
     if ((prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) || (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N)) {
         E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
+    if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, first + count + 1))) return rc;
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
     E->wsel = 0;
     E->w_in_place = true;
     if (first == 0 && count > 0) {                                    // obj[0] of the initial factors (ao_admm.py:256)
-        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;
+        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
     }
-    for (int64_t j = first; j < first + count; ++j)
-        if ((rc = aoadmm_eu_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)))
-            return rc;
+    for (int64_t j = first; j < first + count; ++j) {
+        rc = distance == NMFX_EU
+            ? aoadmm_eu_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
+            : aoadmm_kl_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
+        if (rc) return rc;
+    }
     return NMFX_OK;
 }
 

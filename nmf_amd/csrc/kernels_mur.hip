@@ -41,9 +41,10 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
     const float* __restrict__ Bpart, int hsplit, int64_t bcount,
     const float* __restrict__ Gpart, int gsplit, int64_t gcount,
     const double* __restrict__ objpart, int64_t nobj,
-    float* __restrict__ xf32, double* __restrict__ xf64, int nb, const int* __restrict__ flag)
+    float* __restrict__ xf32, double* __restrict__ xf64, int nb, const int* __restrict__ flag,
+    const int* __restrict__ flag2)
 {
-    if (*flag) return;
+    if (*flag || (flag2 && *flag2)) return;
     __shared__ double sh[4];
     const int b = blockIdx.x;
     if (b < nb) {
@@ -200,14 +201,14 @@ static int launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_ite
     return NMFX_OK;
 }
 
-int nmfx_launch_pack(nmfx_engine* E) {
+int nmfx_launch_pack(nmfx_engine* E, const int* flag2) {
     ProfScope ps(E, "pack");
     const int nb = 256;
     const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
     const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
     hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, E->B_part, E->hsplit,
                        (int64_t)E->kp * E->np, E->G_part, nmfx_g_slabs(E), (int64_t)E->kp * E->kp,
-                       E->obj_part, nobj, E->xf32, E->xf64, nb, &E->state->flag);
+                       E->obj_part, nobj, E->xf32, E->xf64, nb, &E->state->flag, flag2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -71,9 +71,10 @@ template <int KP, bool WITH_A, bool WITH_OBJ, bool KL>
 __global__ __launch_bounds__(256) void wphase_kernel(
     const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
     const float* __restrict__ H, int64_t ldh, float* __restrict__ Apart,
-    double* __restrict__ objpart, int64_t mp, int ngroups, const int* __restrict__ flag)
+    double* __restrict__ objpart, int64_t mp, int ngroups, const int* __restrict__ flag,
+    const int* __restrict__ flag2)
 {
-    if (*flag) return;
+    if (*flag || (flag2 && *flag2)) return;
     constexpr int JT = KP / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [KP][64] H tiles + 4 x [16][64] V tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,6 +235,122 @@ __global__ __launch_bounds__(256) void wphase_kernel(
 }
 
 // --------------------------------------------------------------------------
+// KL-loss ADMM: elementwise update of the m x n auxiliaries (nmf/ao_admm.py:90-95,
+// nmf/admm.py:312-315) fused with the product it needs:
+//   P = Wsrc Hsrc;  v_bar = P - dual_v;  v_aux = ((v_bar-1) + sqrt((v_bar-1)^2 + 4 V)) / 2
+//   dual_v += v_aux - P
+// Only dual_v and S = v_aux + dual_v (the matrix the next Gram right-hand side
+// multiplies, ao_admm.py:85) are stored.  Same tiling as wphase; the P tile comes out
+// of the MFMA in the register layout of the V / dual_v slices.
+// --------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void kl_vaux_kernel(
+    const float* __restrict__ V, float* __restrict__ DV, float* __restrict__ S, int64_t ldv,
+    const float* __restrict__ W, const float* __restrict__ H, int64_t ldh, int ngroups,
+    const int* __restrict__ flag, const int* __restrict__ flag2)
+{
+    if (*flag || (flag2 && *flag2)) return;
+    constexpr int JT = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 H tiles + 4 V tiles + 4 dual_v tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, q = lane >> 4;
+    const int Sg = gridDim.y, sp = blockIdx.y;
+    const int g0 = (int)((int64_t)ngroups * sp / Sg);
+    const int g1 = (int)((int64_t)ngroups * (sp + 1) / Sg);
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    float4 wf[JT];
+#pragma unroll
+    for (int u = 0; u < JT; ++u)
+        wf[u] = *reinterpret_cast<const float4*>(W + (r0 + x) * KP + 16 * u + 4 * q);
+#pragma unroll
+    for (int u = 0; u < JT; ++u) pin(wf[u]);
+    float* vt = lds + 2 * KP * 64 + wave * (16 * 64);
+    float* dt = lds + 2 * KP * 64 + 4 * (16 * 64) + wave * (16 * 64);
+    const float* hsrc[JT];
+    int64_t voff[4];
+#pragma unroll
+    for (int p = 0; p < JT; ++p) {
+        const int row = 4 * (JT * wave + p) + q;
+        hsrc[p] = H + (int64_t)row * ldh + 4 * (x ^ swz(row));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = 4 * t + q;
+        voff[t] = (r0 + row) * ldv + 4 * (x ^ swz(row));
+    }
+    const int gx = swz(x);
+    int dslot[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dslot[s] = (4 * q + s) * 64 + 4 * (x ^ swz(4 * q + s));
+    if (g0 < g1) {
+#pragma unroll
+        for (int p = 0; p < JT; ++p) dma16(hsrc[p] + (int64_t)g0 * 64, lds_addr(lds + (JT * wave + p) * 256));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dma16(V + voff[t] + (int64_t)g0 * 64, lds_addr(vt + t * 256));
+            dma16(DV + voff[t] + (int64_t)g0 * 64, lds_addr(dt + t * 256));
+        }
+    }
+    dma_wait_all();
+    __syncthreads();
+    int cur = 0;
+    for (int g = g0; g < g1; ++g) {
+        float4 vf[4], df[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vf[i] = *reinterpret_cast<const float4*>(vt + x * 64 + 4 * ((4 * q + i) ^ gx));
+            df[i] = *reinterpret_cast<const float4*>(dt + x * 64 + 4 * ((4 * q + i) ^ gx));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pin(vf[i]); pin(df[i]); }
+        if (g + 1 < g1) {
+            float* nb = lds + (cur ^ 1) * (KP * 64);
+#pragma unroll
+            for (int p = 0; p < JT; ++p) dma16(hsrc[p] + (int64_t)(g + 1) * 64, lds_addr(nb + (JT * wave + p) * 256));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dma16(V + voff[t] + (int64_t)(g + 1) * 64, lds_addr(vt + t * 256));
+                dma16(DV + voff[t] + (int64_t)(g + 1) * 64, lds_addr(dt + t * 256));
+            }
+        }
+        const float* buf = lds + cur * (KP * 64);
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
+#pragma unroll
+        for (int u = 0; u < JT; ++u) {
+            const float wv[4] = {wf[u].x, wf[u].y, wf[u].z, wf[u].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 ha = *reinterpret_cast<const float4*>(buf + u * 16 * 64 + dslot[s]);
+                d0 = MFMA(ha.x, wv[s], d0);
+                d1 = MFMA(ha.y, wv[s], d1);
+                d2 = MFMA(ha.z, wv[s], d2);
+                d3 = MFMA(ha.w, wv[s], d3);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float vv[4] = {vf[i].x, vf[i].y, vf[i].z, vf[i].w};
+            const float dd[4] = {df[i].x, df[i].y, df[i].z, df[i].w};
+            const float pp[4] = {d0[i], d1[i], d2[i], d3[i]};
+            float dn[4], sn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (pp[e] - dd[e]) - 1.f;
+                const float va = 0.5f * (t + sqrtf(t * t + 4.f * vv[e]));
+                dn[e] = dd[e] + va - pp[e];
+                sn[e] = va + dn[e];
+            }
+            const int64_t o = (r0 + x) * ldv + (int64_t)g * 64 + 16 * q + 4 * i;
+            *reinterpret_cast<float4*>(DV + o) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+            *reinterpret_cast<float4*>(S + o) = make_float4(sn[0], sn[1], sn[2], sn[3]);
+        }
+        dma_wait_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// --------------------------------------------------------------------------
 // hphase: one block = 64 columns x the rows of split sr; its 4 waves take a
 // quarter of those rows each and are summed through LDS in a fixed order
 // (run-to-run bit-stable).  Per k-step (4 rows) a lane loads 16 B of V
@@ -245,9 +362,9 @@ template <int KP, bool WITH_G>
 __global__ __launch_bounds__(256) void hphase_kernel(
     const float* __restrict__ V, int64_t ldv, const float* __restrict__ W,
     float* __restrict__ Bpart, float* __restrict__ Gpart, int64_t np, int64_t mp,
-    const int* __restrict__ flag)
+    const int* __restrict__ flag, const int* __restrict__ flag2)
 {
-    if (*flag) return;
+    if (*flag || (flag2 && *flag2)) return;
     constexpr int JT = KP / 16;
     // WITH_G: column block t < JT*JT also accumulates tile (t / JT, t % JT) of
     // W^T W from the W fragments it loads anyway (one extra MFMA per k-step).
@@ -504,7 +621,8 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
 // launchers
 // --------------------------------------------------------------------------
 template <int KP>
-static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc) {
+static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc,
+                           const float* Vsrc, const int* flag2) {
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float);
     const int ng = (int)(E->np / 64);
@@ -516,8 +634,8 @@ static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool wit
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
             big_lds_ok = true;                                                                 \
         }                                                                                      \
-        hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, E->V, E->np, W, \
-                           Hsrc, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag);   \
+        hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, Vsrc, E->np, W, \
+                           Hsrc, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag, flag2); \
     } while (0)
     if (kl) {
         if (with_a && with_obj) NMFX_WLAUNCH(true, true, true);
@@ -559,42 +677,45 @@ void nmfx_phase_occupancy(int kp, int* wocc, int* hocc) {
     }
 }
 
-int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc) {
+int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc,
+                       const float* Vsrc, const int* flag2) {
     ProfScope ps(E, with_a ? (with_obj ? "wphase" : "wphase_noobj") : "objective");
     if (!Hsrc) Hsrc = E->H;
+    if (!Vsrc) Vsrc = E->V;
     switch (E->kp) {
-        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl, Hsrc);
-        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl, Hsrc);
-        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj, kl, Hsrc);
-        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj, kl, Hsrc);
+        case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
+        case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
+        case 64: return wphase_dispatch<64>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
+        case 128: return wphase_dispatch<128>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
     }
     E->err = "unsupported padded rank";
     return NMFX_E_ARG;
 }
 
 template <int KP>
-static int hphase_dispatch(nmfx_engine* E, const float* W, bool with_g) {
+static int hphase_dispatch(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc, const int* flag2) {
     dim3 grid((unsigned)(E->np / 64), (unsigned)E->hsplit), block(256);
     const size_t shm = (size_t)KP * 64 * sizeof(float);
     if (with_g)
-        hipLaunchKernelGGL((hphase_kernel<KP, true>), grid, block, shm, E->stream, E->V, E->np, W,
-                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag);
+        hipLaunchKernelGGL((hphase_kernel<KP, true>), grid, block, shm, E->stream, Vsrc, E->np, W,
+                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag, flag2);
     else
-        hipLaunchKernelGGL((hphase_kernel<KP, false>), grid, block, shm, E->stream, E->V, E->np, W,
-                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag);
+        hipLaunchKernelGGL((hphase_kernel<KP, false>), grid, block, shm, E->stream, Vsrc, E->np, W,
+                           E->B_part, E->G_part, E->np, E->mp, &E->state->flag, flag2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
 // B_part[sr] = W^T V; with_g: also G_part[sr] = W^T W (needs np/64 >= (kp/16)^2,
 // see nmfx_hphase_can_fuse_gram).
-int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g) {
+int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc, const int* flag2) {
     ProfScope ps(E, "hphase");
+    if (!Vsrc) Vsrc = E->V;
     switch (E->kp) {
-        case 16: return hphase_dispatch<16>(E, W, with_g);
-        case 32: return hphase_dispatch<32>(E, W, with_g);
-        case 64: return hphase_dispatch<64>(E, W, with_g);
-        case 128: return hphase_dispatch<128>(E, W, with_g);
+        case 16: return hphase_dispatch<16>(E, W, with_g, Vsrc, flag2);
+        case 32: return hphase_dispatch<32>(E, W, with_g, Vsrc, flag2);
+        case 64: return hphase_dispatch<64>(E, W, with_g, Vsrc, flag2);
+        case 128: return hphase_dispatch<128>(E, W, with_g, Vsrc, flag2);
     }
     E->err = "unsupported padded rank";
     return NMFX_E_ARG;
@@ -631,4 +752,31 @@ int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+
+template <int KP>
+static int kl_vaux_dispatch(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2) {
+    dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
+    const size_t shm = (size_t)(2 * KP * 64 + 8 * 16 * 64) * sizeof(float);
+    static bool big_lds_ok = false;
+    if (shm > 64 * 1024 && !big_lds_ok) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kl_vaux_kernel<KP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL((kl_vaux_kernel<KP>), grid, block, shm, E->stream, E->V, E->DV, E->S, E->np, Wsrc, Hsrc,
+                       E->np, (int)(E->np / 64), &E->state->flag, flag2);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// dual_v, S <- KL-ADMM update with P = Wsrc Hsrc (see kl_vaux_kernel)
+int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2) {
+    ProfScope ps(E, "kl_vaux");
+    switch (E->kp) {
+        case 16: return kl_vaux_dispatch<16>(E, Wsrc, Hsrc, flag2);
+        case 32: return kl_vaux_dispatch<32>(E, Wsrc, Hsrc, flag2);
+        case 64: return kl_vaux_dispatch<64>(E, Wsrc, Hsrc, flag2);
+        default: return kl_vaux_dispatch<128>(E, Wsrc, Hsrc, flag2);
+    }
 }

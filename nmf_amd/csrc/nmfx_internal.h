@@ -60,6 +60,7 @@ struct nmfx_engine {
     float* Minv = nullptr;         // [kp][kp] (G + rho I)^-1
     float* Pw = nullptr; float* Ph = nullptr;   // [kp][kp] fixed l2n prox operators (ADMM)
     float* Asum = nullptr;         // [mp][kp] summed V H^T (ADMM)
+    float* S = nullptr; float* DV = nullptr;    // [mp][np] KL-ADMM: v_aux + dual_v, dual_v
     double* nrm_part = nullptr;    // [blocks][4]
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
@@ -80,10 +81,13 @@ struct nmfx_engine {
 // ---- launch helpers implemented in the kernel translation units ---------
 // A_part[sp] = V(rows, cols of split sp) * H^T ; optionally the residual
 // objective 0.5*sum (V - W H)^2 into obj_part (one double per block).
+// Hsrc / Vsrc: use these instead of E->H / E->V; flag2: optional second "skip" flag
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false,
-                       const float* Hsrc = nullptr);   // Hsrc: use this [kp][np] matrix instead of E->H
+                       const float* Hsrc = nullptr, const float* Vsrc = nullptr, const int* flag2 = nullptr);
+int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2 = nullptr);
 // B_part[sr] = W^T V over the rows of split sr.
-int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g);
+int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc = nullptr,
+                       const int* flag2 = nullptr);
 bool nmfx_hphase_can_fuse_gram(const nmfx_engine* E);
 void nmfx_phase_occupancy(int kp, int* wocc, int* hocc);
 // number of W^T W partial slabs the H phase leaves in G_part
@@ -94,7 +98,7 @@ int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld
 
 // shared small launchers (kernels_mur.hip / engine.hip)
 int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out);
-int nmfx_launch_pack(nmfx_engine* E);          // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
+int nmfx_launch_pack(nmfx_engine* E, const int* flag2 = nullptr);   // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
 int nmfx_launch_obj_reduce(nmfx_engine* E);    // xf64[0] = sum obj_part
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
@@ -102,6 +106,7 @@ int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
 
 // AO-ADMM / ADMM building blocks (kernels_aoadmm.hip)
 int nmfx_aoadmm_alloc(nmfx_engine* E);
+int nmfx_kl_state_alloc(nmfx_engine* E);
 int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
                         double tol1, double tol2, double fixed_rho);
 int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int prox, float lam, int round);

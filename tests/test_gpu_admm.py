@@ -6,7 +6,7 @@ from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["admm_eu_nn", "admm_eu_l1n", "admm_eu_l2n"]
+CASES = ["admm_eu_nn", "admm_eu_l1n", "admm_eu_l2n", "admm_kl_nn"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -17,7 +17,7 @@ def test_admm_eu_matches_reference(name):
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors(name, admm) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-3 if "kl" in name else 5e-4)
     assert res.experiment.rho == meta["kwargs"]["rho"]
 
 

@@ -48,3 +48,14 @@ def test_aoadmm_error_behaviour():
             ao_admm(v, 3, max_iter=3, reg_h=(0, "nn"), nndsvd_init=(False, "zero"))
         finally:
             U.initial_factors = orig
+
+
+def test_aoadmm_kl_matches_reference():
+    from nmf_amd.ao_admm import ao_admm
+    z, meta, v, res = run_fixture("aoadmm_kl_nn", ao_admm)
+    assert res.i == int(z["i"]) and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, z["w"], z["h"], v)
+    snaps = snapshot_errors("aoadmm_kl_nn", ao_admm) if err >= WH_TOL else {}
+    assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-3)
+    assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])

@@ -38,12 +38,12 @@ int main(int argc, char** argv) {
     const double f2 = 2.0 * m * n * KP, vb = (double)m * n * 4;
     dim3 wg((unsigned)(m / 64), ws), hg((unsigned)(n / 64), hs), blk(256);
     const size_t wshm = (2 * KP * 64 + 4 * 16 * 64) * 4, hshm = KP * 64 * 4;
-    time_it("wphase A+obj", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, true, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag); }, 2 * f2, vb);
-    time_it("wphase A only", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, false, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag); }, f2, vb);
-    time_it("wphase obj only", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, false, true, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag); }, f2, vb);
-    time_it("wphase KL A+obj", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, true, true>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag); }, 2 * f2, vb);
-    time_it("hphase +G", 20, [&] { hipLaunchKernelGGL((hphase_kernel<KP, true>), hg, blk, hshm, 0, V, ldv, W, B, G, n, m, flag); }, f2, vb);
-    time_it("hphase", 20, [&] { hipLaunchKernelGGL((hphase_kernel<KP, false>), hg, blk, hshm, 0, V, ldv, W, B, G, n, m, flag); }, f2, vb);
+    time_it("wphase A+obj", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, true, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag, (const int*)nullptr); }, 2 * f2, vb);
+    time_it("wphase A only", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, false, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag, (const int*)nullptr); }, f2, vb);
+    time_it("wphase obj only", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, false, true, false>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag, (const int*)nullptr); }, f2, vb);
+    time_it("wphase KL A+obj", 20, [&] { hipLaunchKernelGGL((wphase_kernel<KP, true, true, true>), wg, blk, wshm, 0, V, ldv, W, H, n, A, obj, m, (int)(n / 64), flag, (const int*)nullptr); }, 2 * f2, vb);
+    time_it("hphase +G", 20, [&] { hipLaunchKernelGGL((hphase_kernel<KP, true>), hg, blk, hshm, 0, V, ldv, W, B, G, n, m, flag, (const int*)nullptr); }, f2, vb);
+    time_it("hphase", 20, [&] { hipLaunchKernelGGL((hphase_kernel<KP, false>), hg, blk, hshm, 0, V, ldv, W, B, G, n, m, flag, (const int*)nullptr); }, f2, vb);
 #ifdef LAB_EXTRA
     LAB_EXTRA
 #endif
