@@ -1,0 +1,42 @@
+"""ANLS on the MI355X engine.
+
+Same call signature, defaults and return value as the reference's `anls.anls`
+(nmf/anls.py:50-135).  Per outer iteration every row of W and then every column
+of H is the exact solution of a regularised NNLS problem (anls.py:18-47); the
+device solves them from the shared Gram matrix by block principal pivoting
+(csrc/kernels_anls.hip).  `use_fcnnls` selects between two solvers of the SAME
+strictly convex problems in the reference (scipy's Lawson-Hanson vs
+nmf/fcnnls.py); here it is recorded in the experiment tuple (and therefore in
+the save-file name) and otherwise has no effect.  `distance_type` only selects
+the reported objective, exactly as in the reference."""
+from collections import namedtuple
+
+from . import _lib as L
+from . import utils
+from ._driver import Results, drive
+from .engine import Engine
+
+Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_init max_iter tol1 tol2 lambda_w lambda_h fcnnls')
+
+
+def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, min_iter=10,
+         max_iter=1000, tol1=1e-3, tol2=1e-3, nndsvd_init=(True, 'zero'), save_dir='./results/',
+         device=0):
+    experiment = Experiment('anls', k, distance_type, nndsvd_init, max_iter, tol1, tol2, lambda_w,
+                            lambda_h, use_fcnnls)
+    if distance_type not in ('eu', 'kl'):
+        raise KeyError('Distance type unknown: use "kl" or "eu"')   # nmf/utils.py:31 via anls.py:108
+    if distance_type == 'kl':
+        raise NotImplementedError("anls with distance_type='kl' (KL objective of least-squares "
+                                  "iterates) is not built in nmf_amd")
+    w0, h0 = utils.initial_factors(x, k, nndsvd_init, uniform=True)
+    with Engine(x.shape[0], x.shape[1], k, device=device) as eng:
+        eng.upload_v(x)
+        eng.set_factors(w0, h0)
+        i, history = drive(
+            eng,
+            lambda first, count: eng.anls_run(lambda_w, lambda_h, min_iter, tol1, tol2, first, count),
+            lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
+            max_iter, tol1, tol2)
+        w, h = eng.get_factors()
+    return Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)

@@ -1,0 +1,225 @@
+// ANLS: alternating non-negative least squares.
+//   reference: nmf/anls.py:18-47 (w_update / h_update: one NNLS per row of W /
+//   column of H on the stacked system [F; sqrt(2 lambda) I]), driver :111-122;
+//   scipy.optimize.nnls (Lawson-Hanson) or nmf/fcnnls.py (Van Benthem-Keenan).
+//
+// Every NNLS problem of one half-step shares the Gram matrix G = F^T F + 2 lambda I
+// and differs in its right-hand side r = F^T b (a column of W^T V, or a row of
+// V H^T): those come from the same MFMA kernels as the other solvers.  The
+// constrained solve itself is an exact active-set method, block principal pivoting
+// (Kim & Park), which reaches the same KKT point as Lawson-Hanson / FCNNLS (the
+// minimiser is unique for positive definite G):
+//     F = passive set;  x_F = G_FF^-1 r_F, x_G = 0;  y_G = G_GF x_F - r_G, y_F = 0
+//     infeasible = {i in F: x_i < 0} u {i in G: y_i < 0};  exchange them (all at once,
+//     with the usual back-up rule: after 3 non-improving full exchanges only the
+//     largest infeasible index) until none is left.
+// One wavefront owns one right-hand side, so the data-dependent control flow is
+// wave-uniform; variable i lives on lane i (and i+64 for k > 64).  The k x k solve
+// is a Gauss-Jordan elimination over the passive pivots in a per-wave LDS
+// workspace (no pivoting: G_FF is SPD).
+#include "nmfx_internal.h"
+#include "kernels_small.h"
+
+template <int KP>
+__global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
+    const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
+    constexpr int NW = KP <= 64 ? 4 : 2;                // waves (problems) per block
+    constexpr int LDM = KP + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * NW + wave;
+    if (c >= nprob) return;                              // whole wave leaves together
+    float* M = lds + (size_t)wave * (KP * LDM + KP);     // [KP][KP+1] augmented rows
+    float* xs = M + KP * LDM;                            // [KP] broadcast copy of x
+
+    int idx[NV]; bool valid[NV], inF[NV];
+    float r[NV], x[NV], y[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        idx[t] = lane + 64 * t;
+        valid[t] = idx[t] < k;
+        r[t] = valid[t] ? R[(int64_t)idx[t] * sj + c * sc] : 0.f;
+        x[t] = 0.f; y[t] = -r[t]; inF[t] = false;
+    }
+    int best = k + 1, spare = 3;
+    for (int iter = 0; iter < 8 * KP + 64; ++iter) {
+        unsigned long long Im[NV];
+        int n_inf = 0;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const bool bad = valid[t] && (inF[t] ? (x[t] < 0.f) : (y[t] < 0.f));
+            Im[t] = __ballot(bad);
+            n_inf += __popcll(Im[t]);
+        }
+        if (n_inf == 0) break;
+        bool full = true;
+        if (n_inf < best) { best = n_inf; spare = 3; }
+        else if (spare > 0) { --spare; }
+        else full = false;
+        if (!full) {                                     // back-up rule: largest infeasible index only
+#pragma unroll
+            for (int t = NV - 1; t >= 0; --t) {
+                if (Im[t]) {
+                    const int hi = 63 - __clzll((long long)Im[t]);
+                    Im[t] = 1ull << hi;
+#pragma unroll
+                    for (int u = 0; u < t; ++u) Im[u] = 0ull;
+                    break;
+                }
+            }
+        }
+        unsigned long long Fm[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if ((Im[t] >> lane) & 1ull) inF[t] = !inF[t];
+            Fm[t] = __ballot(inF[t]);
+        }
+        // augmented rows of the passive block (other rows are never touched)
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (inF[t]) {
+                const float* grow = G + (int64_t)idx[t] * KP;
+                float* mrow = M + idx[t] * LDM;
+                for (int cc = 0; cc < KP; ++cc) {
+                    const bool in = (Fm[cc >> 6] >> (cc & 63)) & 1ull;
+                    mrow[cc] = in ? (grow[cc] + (cc == idx[t] ? diag_add : 0.f)) : 0.f;
+                }
+                mrow[KP] = r[t];
+            }
+        }
+        // Gauss-Jordan over the passive pivots
+        for (int tp = 0; tp < NV; ++tp) {
+            unsigned long long left = Fm[tp];
+            while (left) {
+                const int b = __ffsll((long long)left) - 1;
+                left &= left - 1;
+                const int p = b + 64 * tp;
+                const float* prow = M + p * LDM;
+                const float inv = 1.f / prow[p];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    if (inF[t] && idx[t] != p) {
+                        float* mrow = M + idx[t] * LDM;
+                        const float f = mrow[p] * inv;
+                        // only passive columns after p still matter, plus the right-hand side
+                        for (int tc = tp; tc < NV; ++tc) {
+                            unsigned long long cols = Fm[tc];
+                            if (tc == tp) cols &= ~((2ull << b) - 1ull);
+                            while (cols) {
+                                const int cb = __ffsll((long long)cols) - 1;
+                                cols &= cols - 1;
+                                const int cc = cb + 64 * tc;
+                                mrow[cc] -= f * prow[cc];
+                            }
+                        }
+                        mrow[KP] -= f * prow[KP];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            x[t] = inF[t] ? M[idx[t] * LDM + KP] / M[idx[t] * LDM + idx[t]] : 0.f;
+            if (idx[t] < KP) xs[idx[t]] = x[t];          // lanes beyond KP own no variable
+        }
+        // dual variables of the active set: y = G x - r
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            float acc = 0.f;
+            if (valid[t] && !inF[t]) {
+                const float* grow = G + (int64_t)idx[t] * KP;
+                for (int tc = 0; tc < NV; ++tc) {
+                    unsigned long long cols = Fm[tc];
+                    while (cols) {
+                        const int cb = __ffsll((long long)cols) - 1;
+                        cols &= cols - 1;
+                        const int cc = cb + 64 * tc;
+                        acc += grow[cc] * xs[cc];
+                    }
+                }
+                acc -= r[t];
+            }
+            y[t] = acc;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NV; ++t)
+        if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.f) ? x[t] : 0.f;
+}
+
+template <int KP>
+static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
+                       int64_t sc, int64_t nprob) {
+    constexpr int NW = KP <= 64 ? 4 : 2;
+    const size_t shm = (size_t)NW * (KP * (KP + 1) + KP) * sizeof(float);
+    auto kern = nnls_bpp_kernel<KP>;
+    static bool big_lds_ok = false;
+    if (shm > 64 * 1024 && !big_lds_ok) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nprob + NW - 1) / NW)), dim3(64 * NW), shm, E->stream, G, diag_add,
+                       R, X, sj, sc, nprob, E->k, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj, int64_t sc,
+                int64_t nprob) {
+    ProfScope ps(E, "nnls");
+    switch (E->kp) {
+        case 16: return launch_nnls<16>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 32: return launch_nnls<32>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 64: return launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob);
+        default: return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
+    }
+}
+
+static int anls_iteration(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2,
+                          int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    // objective of the current pair (filled by the previous pass) and the stop rule
+    if ((rc = nmfx_launch_obj_reduce(E))) return rc;
+    if ((rc = nmfx_finish_b(E, min_iter, tol1, tol2, j))) return rc;
+    // ---- W: rows of W from G = H H^T + 2 lam_w I, r = (V H^T)[i, :]  (anls.py:18-31) ----
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
+    if ((rc = nnls(E, E->HHt, (float)(2.0 * lam_w), E->Asum, W, 1, E->kp, E->m))) return rc;
+    // ---- H: columns of H from G = W^T W + 2 lam_h I, r = (W^T V)[:, c]  (anls.py:34-47) ----
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
+    if ((rc = nmfx_launch_pack(E))) return rc;
+    if ((rc = nnls(E, E->xf32 + (int64_t)E->kp * E->np, (float)(2.0 * lam_h), E->xf32, E->H, E->np, 1, E->n))) return rc;
+    // ---- objective (anls.py:118) ----
+    return nmfx_launch_wphase(E, W, false, true);
+}
+
+extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, int64_t min_iter, double tol1,
+                             double tol2, int64_t first, int64_t count) {
+    if (!E) return NMFX_E_ARG;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (first < 0 || count < 0 || lambda_w < 0 || lambda_h < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if (!E->Asum) {
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
+        NMFX_HIP(hipMemsetAsync(E->Asum, 0, (size_t)E->mp * E->kp * sizeof(float), E->stream));
+    }
+    if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
+    E->wsel = 0;
+    E->w_in_place = true;
+    if (first == 0 && count > 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0]
+    for (int64_t j = first; j < first + count; ++j)
+        if ((rc = anls_iteration(E, lambda_w, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    return NMFX_OK;
+}
