@@ -26,8 +26,17 @@
 // ---- k x k inverse -------------------------------------------------------
 // src: summed Gram matrix (f32, [KP][KP], zero beyond the logical k).
 // record_obj: also publish obj[j] and run the outer convergence test first.
+// The matrix lives in registers: thread (ti, tj) of a (KP/4) x (KP/4) grid owns the 4 x 4
+// patch rows 4ti.., columns 4tj...  Per pivot p the owners publish row p, column p and
+// 1/piv through double-buffered LDS (one barrier per pivot) and every thread applies
+// ONE rank-1 FMA update to its patch.  The in-place Gauss-Jordan step
+//     a[p][p] <- 1/piv,  a[p][c] <- a[p][c]/piv,  a[i][p] <- -a[i][p]/piv,
+//     a[i][c] <- a[i][c] - a[i][p] a[p][c]/piv
+// is exactly  a[i][c] <- a[i][c] - cv[i] * rv[c]  with the published values adjusted to
+//     cv[p] = piv - 1   and   rv[p] = 1 + 1/piv      (rv[c] = a[p][c]/piv otherwise),
+// so there are no special cases in the update (the kernel is f64 issue bound).
 template <int KP>
-__global__ __launch_bounds__(1024) void ao_prepare_kernel(
+__global__ __launch_bounds__((KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4)) void ao_prepare_kernel(
     const float* __restrict__ src, int k, float* __restrict__ Minv, DevState* __restrict__ st,
     int record_obj, const double* __restrict__ xf64, long long j, long long min_iter,
     double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho)
@@ -38,46 +47,78 @@ __global__ __launch_bounds__(1024) void ao_prepare_kernel(
                                                threadIdx.x == 0);
         if (rule) return;
     }
-    extern __shared__ __attribute__((aligned(16))) double S[];     // [KP][KP] + 2*KP
-    double* colp = S + KP * KP;
-    double* rowp = colp + KP;
+    constexpr int T = KP / 4;
+    __shared__ double rowr[2][KP], colp[2][KP], pivinv[2][2], shrho;
     const int tid = threadIdx.x;
-    for (int i = tid; i < KP * KP; i += 1024) S[i] = (double)src[i];
-    __syncthreads();
+    const bool active = tid < T * T;
+    const int ti = active ? tid / T : -1, tj = active ? tid % T : -1;
+    double a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 v = active ? *reinterpret_cast<const float4*>(src + (int64_t)(4 * ti + r) * KP + 4 * tj)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[r][0] = v.x; a[r][1] = v.y; a[r][2] = v.z; a[r][3] = v.w;
+    }
     if (tid == 0) {
         double rho = fixed_rho;
         if (!(fixed_rho >= 0.0)) {                 // AO-ADMM: rho = trace(G) / k  (ao_admm.py:54)
             double tr = 0.0;
-            for (int i = 0; i < k; ++i) tr += S[i * KP + i];
+            for (int i = 0; i < k; ++i) tr += (double)src[(int64_t)i * KP + i];
             rho = tr / (double)k;
         }
-        colp[0] = rho;
+        shrho = rho;
+        st->rho = rho; st->inner_stop = 0; st->inner_count = 0;
     }
     __syncthreads();
-    const double rho = colp[0];
-    __syncthreads();
-    if (tid < KP) S[tid * KP + tid] += rho;
-    if (tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
-    __syncthreads();
+    const double rho = shrho;
+    if (active && ti == tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r][r] += rho;
+    }
     for (int p = 0; p < KP; ++p) {
-        const double piv = S[p * KP + p];
+        const int buf = p & 1, pg = p >> 2, pr = p & 3;
+        if (ti == pg) {                            // owners of row p
+            double rowv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                rowv[c] = pr == 0 ? a[0][c] : pr == 1 ? a[1][c] : pr == 2 ? a[2][c] : a[3][c];
+                rowr[buf][4 * tj + c] = rowv[c];
+            }
+            if (tj == pg) {                        // the pivot owner divides once for everybody
+                const double piv = pr == 0 ? rowv[0] : pr == 1 ? rowv[1] : pr == 2 ? rowv[2] : rowv[3];
+                pivinv[buf][0] = piv;
+                pivinv[buf][1] = 1.0 / piv;
+            }
+        }
+        if (tj == pg) {                            // owners of column p
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                colp[buf][4 * ti + r] = pr == 0 ? a[r][0] : pr == 1 ? a[r][1] : pr == 2 ? a[r][2] : a[r][3];
+        }
+        __syncthreads();
+        const double piv = pivinv[buf][0];
         if (!(piv > 0.0)) {                        // scipy cholesky would raise LinAlgError
             if (tid == 0) { st->notpd = 1; st->flag = 3; }
             return;
         }
-        if (tid < KP) { colp[tid] = S[tid * KP + p]; rowp[tid] = S[p * KP + tid] / piv; }
-        __syncthreads();
-        for (int e = tid; e < KP * KP; e += 1024) {
-            const int i = e / KP, c = e % KP;
-            double v;
-            if (i == p) v = (c == p) ? 1.0 / piv : rowp[c];
-            else if (c == p) v = -colp[i] / piv;
-            else v = S[e] - colp[i] * rowp[c];
-            S[e] = v;
+        const double inv = pivinv[buf][1];
+        double rv[4], cv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rv[c] = (4 * tj + c == p) ? 1.0 + inv : rowr[buf][(4 * tj + c) & (KP - 1)] * inv;
+            cv[c] = (4 * ti + c == p) ? piv - 1.0 : colp[buf][(4 * ti + c) & (KP - 1)];
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[r][c] = fma(-cv[r], rv[c], a[r][c]);
     }
-    for (int i = tid; i < KP * KP; i += 1024) Minv[i] = (float)S[i];
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(Minv + (int64_t)(4 * ti + r) * KP + 4 * tj) =
+                make_float4((float)a[r][0], (float)a[r][1], (float)a[r][2], (float)a[r][3]);
+    }
 }
 
 // ---- inner stop test -------------------------------------------------------
@@ -353,13 +394,9 @@ int nmfx_aoadmm_alloc(nmfx_engine* E) {
 template <int KP>
 static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
                           double tol1, double tol2, double fixed_rho) {
-    const size_t shm = ((size_t)KP * KP + 2 * KP) * sizeof(double);
-    auto kern = ao_prepare_kernel<KP>;
-    if (shm > 64 * 1024)
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), shm, E->stream, src, E->k, E->Minv, E->state, record_obj,
-                       E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
+    constexpr int NT = (KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4);
+    hipLaunchKernelGGL((ao_prepare_kernel<KP>), dim3(1), dim3(NT), 0, E->stream, src, E->k, E->Minv, E->state,
+                       record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
