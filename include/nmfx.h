@@ -63,6 +63,13 @@ int nmfx_device_count(void);
 int nmfx_set_stream(nmfx_handle_t h, void* hip_stream);
 int nmfx_reset_stream(nmfx_handle_t h);
 int nmfx_synchronize(nmfx_handle_t h);
+/* Arithmetic of the two V-sized products of MUR-Euclidean: 0 = f32-input MFMA (exact
+ * f32 FMA chains), 1 = split bf16 (each f32 operand as bf16 hi + bf16 lo, four bf16
+ * MFMA terms, f32 accumulation; available when k pads to 64, otherwise mode 0 is
+ * used).  nmfx_get_precision returns the mode in effect.  Environment override at
+ * create time: NMFX_PRECISION=f32|bf16.                                         */
+int nmfx_set_precision(nmfx_handle_t h, int mode);
+int nmfx_get_precision(nmfx_handle_t h);
 
 /* ---- data --------------------------------------------------------------- */
 /* Copy rows [row0, row0+rows) of the local V from host memory (row stride `ld`

@@ -29,6 +29,8 @@ SIGNATURES = {
     "nmfx_set_stream": (_i32, [_vp, _vp]),
     "nmfx_reset_stream": (_i32, [_vp]),
     "nmfx_synchronize": (_i32, [_vp]),
+    "nmfx_set_precision": (_i32, [_vp, _i32]),
+    "nmfx_get_precision": (_i32, [_vp]),
     "nmfx_upload_v": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64]),
     "nmfx_set_factors": (_i32, [_vp, _vp, _vp]),
     "nmfx_get_factors": (_i32, [_vp, _vp, _vp]),

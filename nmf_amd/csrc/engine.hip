@@ -12,6 +12,9 @@ int nmfx_mur_kl_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_kl_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j);
 
+#ifndef NMFX_DEFAULT_PRECISION
+#define NMFX_DEFAULT_PRECISION 0
+#endif
 static thread_local std::string g_err;
 
 static int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -111,6 +114,9 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     int wocc = 2, hocc = 2, ncu = 256;
     nmfx_phase_occupancy(E->kp, &wocc, &hocc);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    E->ncu = ncu;
+    { const char* pm = getenv("NMFX_PRECISION");
+      E->precision = (pm && (!strcmp(pm, "f32") || !strcmp(pm, "fp32"))) ? 0 : (pm && !strcmp(pm, "bf16")) ? 1 : NMFX_DEFAULT_PRECISION; }
     const char* ev;
     const int64_t wtarget = (ev = getenv("NMFX_WBLOCKS")) ? atoll(ev) : (int64_t)ncu * wocc;
     const int64_t htarget = (ev = getenv("NMFX_HBLOCKS")) ? atoll(ev) : (int64_t)ncu * hocc;
@@ -149,7 +155,8 @@ int nmfx_destroy(nmfx_handle_t E) {
     void* bufs[] = {E->V, E->W[0], E->W[1], E->H, E->HHt, E->HHt_part, E->G_part, E->A_part, E->B_part,
                     E->obj_part, E->own_x ? (void*)E->xf32 : nullptr, E->own_x ? (void*)E->xf64 : nullptr,
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
-                    E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV};
+                    E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Bt_part, E->Whi[0], E->Whi[1],
+                    E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->side_stream) { hipStreamSynchronize(E->side_stream); hipStreamDestroy(E->side_stream); }
     if (E->ev_fork) hipEventDestroy(E->ev_fork);
@@ -173,6 +180,17 @@ int nmfx_reset_stream(nmfx_handle_t E) {
     NMFX_HIP(hipStreamSynchronize(E->stream));
     E->stream = E->own_stream;
     return NMFX_OK;
+}
+
+int nmfx_set_precision(nmfx_handle_t E, int mode) {
+    if (!E || (mode != 0 && mode != 1)) { if (E) E->err = "precision must be 0 (f32) or 1 (split bf16)"; return NMFX_E_ARG; }
+    E->precision = mode;
+    return NMFX_OK;
+}
+
+int nmfx_get_precision(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    return (E->precision == 1 && nmfx_bf16_supported(E)) ? 1 : 0;
 }
 
 int nmfx_synchronize(nmfx_handle_t E) {
@@ -211,7 +229,8 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
         }
         hipFree(stage);
     } else { E->err = "upload_v: dtype must be NMFX_F32 or NMFX_F64"; return NMFX_E_ARG; }
-    if (row0 + rows == E->m || true) E->have_v = true;
+    E->have_v = true;
+    E->bf_ready = false;
     return NMFX_OK;
 }
 
@@ -251,6 +270,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
     E->wsel = 0;
     E->have_f = true;
+    E->bf_ready = false;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;
@@ -356,7 +376,9 @@ static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
 int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;
-    if (distance == NMFX_EU) return nmfx_mur_eu_phase_a(E, lambda_w, j);
+    if (distance == NMFX_EU)
+        return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_eu_phase_a_bf16(E, lambda_w, j)
+                                                             : nmfx_mur_eu_phase_a(E, lambda_w, j);
     if (distance == NMFX_KL) return nmfx_mur_kl_phase_a(E, lambda_w, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;
 }
@@ -367,7 +389,10 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
     int rc = check_ready(E, j, 1); if (rc) return rc;
     E->wsel = (int)((j + 1) & 1);
     E->w_in_place = false;
-    if (distance == NMFX_EU) return nmfx_mur_eu_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
+    if (distance == NMFX_EU)
+        return (E->precision == 1 && nmfx_bf16_supported(E))
+                   ? nmfx_mur_eu_phase_b_bf16(E, lambda_h, min_iter, tol1, tol2, j)
+                   : nmfx_mur_eu_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
     if (distance == NMFX_KL) return nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;
 }

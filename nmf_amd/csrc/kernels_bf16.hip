@@ -1,0 +1,472 @@
+// Split-bf16 ("2 x bf16") form of the two V-sized products of MUR-Euclidean, k = 64.
+//
+// An f32 number x is written x = hi + lo + eps with hi = bf16(x), lo = bf16(x - hi),
+// |eps| <= 2^-17 |x|.  A product of two such numbers is evaluated as the four bf16 MFMA
+// terms hi*hi + hi*lo + lo*hi + lo*lo with f32 accumulation (v_mfma_f32_16x16x32_bf16,
+// 16x the rate of the f32-input MFMA), i.e. every operand carries 16 significant bits
+// and the accumulation is the same f32 chain as before.  On dot products of length
+// 8192 / 16384 the result differs from the exact-f32 kernels by ~1e-7 relative (the
+// parity tests run both).  With this form both products leave the MFMA roofline and
+// become HBM bound (V is read once per phase).
+//
+// One kernel serves both phases because every contraction runs along the contiguous
+// dimension:
+//     W phase:  A   = V   H^T      X = V   [m][n],  Y = H   [64][n]   (+ fused residual)
+//     H phase:  B^T = V^T W        X = V^T [n][m],  Y = W^T [64][m]
+// so the engine keeps a transposed copy of V in HBM (built once after the upload) and
+// the small update kernels emit the bf16 hi/lo images (and their transposes) of the
+// factors they have just produced.
+#include "nmfx_internal.h"
+#include "kernels_small.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union Frag8 { uint4 u; bf16x8 v; };
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void dma16b(const void* gsrc, unsigned lds_dst_wave_base) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pinu(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+// two floats -> packed bf16 hi pair and lo pair (round to nearest even both times)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));
+}
+__device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& hi, Frag8& lo) {
+    split2(p.x, p.y, hi.u.x, lo.u.x); split2(p.z, p.w, hi.u.y, lo.u.y);
+    split2(q.x, q.y, hi.u.z, lo.u.z); split2(q.z, q.w, hi.u.w, lo.u.w);
+}
+
+// ---------------------------------------------------------------------------
+// A_part[sp] = X(rows of the block, columns of split sp) * Y^T, optional residual
+// objective 0.5 * sum (X - Z Y)^2.  Block = 64 rows (4 waves x 16), 64-column groups.
+// LDS per buffer (x2): Yhi, Ylo, YThi, YTlo tiles, each 64 rows x 128 B (bf16), 16-byte
+// chunk c of row r stored at position c ^ ((r >> 1) & 7); V tiles: 4 x [16][64] f32,
+// chunk c of row r at position c ^ r.  All filled by LDS-DMA, all reads conflict free.
+// ---------------------------------------------------------------------------
+template <bool WITH_OBJ>
+__global__ __launch_bounds__(256) void xyt_bf16_kernel(
+    const float* __restrict__ X, int64_t ldx,
+    const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
+    const unsigned short* __restrict__ YThi, const unsigned short* __restrict__ YTlo,
+    const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
+    float* __restrict__ Apart, double* __restrict__ objpart, int64_t R, int ngroups,
+    const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int KP = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x 4 x 8 KiB + 4 x 4 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int S = gridDim.y, sp = blockIdx.y;
+    const int g0 = (int)((int64_t)ngroups * sp / S);
+    const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    unsigned char* vt = smem + 65536 + wave * 4096;
+
+    // ---- DMA plan ----
+    constexpr int NT = WITH_OBJ ? 4 : 2;              // tiles per buffer
+    constexpr int NP = NT * 8 / 4;                    // (tile, 1 KiB piece) pairs per wave
+    const unsigned short* tsrc[NP];
+    int tdst[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pidx = wave * NP + i, tile = pidx >> 3, piece = pidx & 7;
+        const int row = 8 * piece + (lane >> 3), pos = lane & 7, chunk = pos ^ ((row >> 1) & 7);
+        const unsigned short* base = tile == 0 ? Yhi : tile == 1 ? Ylo : tile == 2 ? YThi : YTlo;
+        tsrc[i] = tile < 2 ? base + (int64_t)row * ldy + 8 * chunk           // + c0 per group
+                           : base + (int64_t)row * KP + 8 * chunk;           // + c0 * KP per group
+        tdst[i] = tile * 8192 + piece * 1024;
+    }
+    const float* vsrc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = 4 * t + g;
+        vsrc[t] = X + (r0 + row) * ldx + 4 * (x ^ row);
+    }
+    auto issue = [&](int grp, int buf) {
+        const int64_t c0 = (int64_t)grp * 64;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const bool tr = (wave * NP + i) >= 16;                           // YT tiles advance by c0 rows
+            dma16b(tsrc[i] + (tr ? c0 * KP : c0), lds_off(smem + buf * 32768 + tdst[i]));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma16b(vsrc[t] + c0, lds_off(vt + t * 1024));
+    };
+
+    // Z fragments (rows of W as bf16 hi/lo): lane (r = x, g): Z[r0 + x][32 s + 8 g .. +7]
+    Frag8 zh[2], zl[2];
+    if (WITH_OBJ) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + x) * KP + 32 * s + 8 * g);
+            zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + x) * KP + 32 * s + 8 * g);
+            pinu(zh[s].u); pinu(zl[s].u);
+        }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double osum = 0.0;
+
+    if (g0 < g1) issue(g0, 0);
+    dma_wait();
+    __syncthreads();
+    int cur = 0;
+    for (int grp = g0; grp < g1; ++grp) {
+        // V slice of this wave, two register images: A-operand chunks (8s + 2g, +1) and,
+        // for the residual, chunks (4e + g) -- both of row x
+        float4 va[2][2], vr[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                va[s][h] = *reinterpret_cast<const float4*>(vt + x * 256 + 16 * ((8 * s + 2 * g + h) ^ x));
+        if (WITH_OBJ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                vr[e] = *reinterpret_cast<const float4*>(vt + x * 256 + 16 * ((4 * e + g) ^ x));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pin4(vr[e]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { pin4(va[s][0]); pin4(va[s][1]); }
+        if (grp + 1 < g1) issue(grp + 1, cur ^ 1);
+        const unsigned char* buf = smem + cur * 32768;
+
+        Frag8 vh[2], vl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
+
+        // A-product: acc[jt] += V(16 x 64) . Ytile(rows jt*16.., 64)^T
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int row = jt * 16 + x;
+                const int off = row * 128 + 16 * ((4 * s + g) ^ ((row >> 1) & 7));
+                Frag8 yh, yl;
+                yh.u = *reinterpret_cast<const uint4*>(buf + off);
+                yl.u = *reinterpret_cast<const uint4*>(buf + 8192 + off);
+                acc[jt] = MFMA_BF16(vh[s], yh, acc[jt]);
+                acc[jt] = MFMA_BF16(vl[s], yh, acc[jt]);
+                acc[jt] = MFMA_BF16(vh[s], yl, acc[jt]);
+                acc[jt] = MFMA_BF16(vl[s], yl, acc[jt]);
+            }
+        }
+        if (WITH_OBJ) {
+            // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]   (computed as Y^T-tile x Z^T)
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int row = 16 * e + x;
+                    const int off = row * 128 + 16 * ((4 * s + g) ^ ((row >> 1) & 7));
+                    Frag8 th, tl;
+                    th.u = *reinterpret_cast<const uint4*>(buf + 16384 + off);
+                    tl.u = *reinterpret_cast<const uint4*>(buf + 24576 + off);
+                    d = MFMA_BF16(th, zh[s], d);
+                    d = MFMA_BF16(tl, zh[s], d);
+                    d = MFMA_BF16(th, zl[s], d);
+                    d = MFMA_BF16(tl, zl[s], d);
+                }
+                const float rx = vr[e].x - d[0], ry = vr[e].y - d[1], rz = vr[e].z - d[2], rw = vr[e].w - d[3];
+                part += rx * rx + ry * ry + rz * rz + rw * rw;
+            }
+            osum += (double)part;
+        }
+        dma_wait();
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    {
+        float* out = Apart + ((int64_t)sp * R + r0) * KP;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(int64_t)(4 * g + r) * KP + jt * 16 + x] = acc[jt][r];
+    }
+    if (WITH_OBJ) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) red[wave] = osum;
+        __syncthreads();
+        if (tid == 0)
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// out[c][r] = in[r][c]  (64 x 64 tiles through LDS; both matrices padded to 64)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int64_t ldi,
+                                                            float* __restrict__ out, int64_t ldo)
+{
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = in[(r0 + r) * ldi + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) out[(c0 + c) * ldo + r0 + tx] = tile[tx][c];
+}
+
+// bf16 hi/lo images of M [rows][cols] (row-major, ld) and of its transpose [cols][rows]
+__global__ __launch_bounds__(256) void split_images_kernel(
+    const float* __restrict__ M, int64_t rows, int64_t cols, int64_t ld,
+    unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo)
+{
+    __shared__ unsigned short sh[64][66], sl[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    for (int r = ty; r < 64; r += 4) {
+        const float v = M[(r0 + r) * ld + c0 + tx];
+        unsigned h, l;
+        split2(v, 0.f, h, l);
+        hi[(r0 + r) * ld + c0 + tx] = (unsigned short)h;
+        lo[(r0 + r) * ld + c0 + tx] = (unsigned short)l;
+        sh[r][tx] = (unsigned short)h; sl[r][tx] = (unsigned short)l;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        thi[(c0 + c) * rows + r0 + tx] = sh[tx][c];
+        tlo[(c0 + c) * rows + r0 + tx] = sl[tx][c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// W epilogue (nmf/mur.py:29) + the bf16 images of the new W: row-major (next
+// iteration's residual) and transposed (this iteration's H phase).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
+    const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
+    const float* __restrict__ HHt, float lam, float* __restrict__ Wnew,
+    unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
+    unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int KP = 64;
+    __shared__ float hs[KP * KP];
+    __shared__ float ws[16 * KP];
+    __shared__ unsigned short th[KP][18], tl[KP][18];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    for (int i = tid; i < KP * KP; i += 256) hs[i] = HHt[i];
+    for (int i = tid; i < 16 * KP; i += 256) ws[i] = Wold[r0 * KP + i];
+    __syncthreads();
+    const int row = tid >> 4, jl = tid & 15;
+#pragma unroll
+    for (int jj = 0; jj < KP / 16; ++jj) {
+        const int j = jl + 16 * jj;
+        float d = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < KP; ++l) d = fmaf(ws[row * KP + l], hs[l * KP + j], d);
+        const int64_t idx = (r0 + row) * KP + j;
+        float a = Apart[idx];
+        for (int p = 1; p < wsplit; ++p) a += Apart[(int64_t)p * mp * KP + idx];
+        const float w = ws[row * KP + j];
+        const float wn = w * a / (d + lam * w + 1e-9f);
+        Wnew[idx] = wn;
+        unsigned h, l2;
+        split2(wn, 0.f, h, l2);
+        Whi[idx] = (unsigned short)h; Wlo[idx] = (unsigned short)l2;
+        th[j][row] = (unsigned short)h; tl[j][row] = (unsigned short)l2;
+    }
+    __syncthreads();
+    {   // transposed images: thread (f = tid/4, quarter = tid%4) stores 4 rows = 8 bytes
+        const int f = tid >> 2, qd = tid & 3;
+        const uint2 vh = make_uint2(th[f][4 * qd] | ((unsigned)th[f][4 * qd + 1] << 16),
+                                    th[f][4 * qd + 2] | ((unsigned)th[f][4 * qd + 3] << 16));
+        const uint2 vl = make_uint2(tl[f][4 * qd] | ((unsigned)tl[f][4 * qd + 1] << 16),
+                                    tl[f][4 * qd + 2] | ((unsigned)tl[f][4 * qd + 3] << 16));
+        *reinterpret_cast<uint2*>(WThi + (int64_t)f * mp + r0 + 4 * qd) = vh;
+        *reinterpret_cast<uint2*>(WTlo + (int64_t)f * mp + r0 + 4 * qd) = vl;
+    }
+}
+
+// H epilogue (nmf/mur.py:45) from B^T = V^T W (stored [np][64]) + objective bookkeeping
+// + the bf16 images of the new H (row-major [64][np] and transposed [np][64]).
+__global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
+    const float* __restrict__ xf32, const double* __restrict__ xf64, float* __restrict__ H,
+    int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
+    DevState* __restrict__ st, double* __restrict__ obj_hist,
+    unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
+    unsigned short* __restrict__ HThi, unsigned short* __restrict__ HTlo)
+{
+    if (st->flag) return;
+    const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
+                                           blockIdx.x == 0 && threadIdx.x == 0);
+    if (rule) return;
+    constexpr int KP = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* gs = lds;                 // [KP][KP]
+    float* hs = lds + KP * KP;       // [KP][64]
+    const int tid = threadIdx.x, c = tid & 63, jq = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const float* G = xf32 + (int64_t)KP * np;
+    for (int i = tid; i < KP * KP; i += 256) gs[i] = G[i];
+    for (int i = tid; i < KP * 64; i += 256) hs[i] = H[(int64_t)(i >> 6) * np + c0 + (i & 63)];
+    __syncthreads();
+    constexpr int NJ = KP / 4;
+    float acc[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) acc[t] = 0.f;
+    for (int l = 0; l < KP; ++l) {
+        const float hv = hs[l * 64 + c];
+        const float* grow = gs + l * KP + jq * NJ;
+#pragma unroll
+        for (int t = 0; t < NJ; t += 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(grow + t);
+            acc[t] = fmaf(g4.x, hv, acc[t]);
+            acc[t + 1] = fmaf(g4.y, hv, acc[t + 1]);
+            acc[t + 2] = fmaf(g4.z, hv, acc[t + 2]);
+            acc[t + 3] = fmaf(g4.w, hv, acc[t + 3]);
+        }
+    }
+    const float* brow = xf32 + (c0 + c) * KP + jq * NJ;          // B^T[c][j .. j+15]
+    unsigned ph[NJ / 2], pl[NJ / 2];
+#pragma unroll
+    for (int t = 0; t < NJ; t += 2) {
+        float hn[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int jrow = jq * NJ + t + u;
+            const float h = hs[jrow * 64 + c];
+            hn[u] = h * brow[t + u] / (acc[t + u] + lam * h + 1e-9f);
+            H[(int64_t)jrow * np + c0 + c] = hn[u];
+        }
+        split2(hn[0], hn[1], ph[t / 2], pl[t / 2]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int jrow = jq * NJ + t + u;
+            Hhi[(int64_t)jrow * np + c0 + c] = (unsigned short)(u ? ph[t / 2] >> 16 : ph[t / 2] & 0xffffu);
+            Hlo[(int64_t)jrow * np + c0 + c] = (unsigned short)(u ? pl[t / 2] >> 16 : pl[t / 2] & 0xffffu);
+        }
+    }
+    uint4* th = reinterpret_cast<uint4*>(HThi + (c0 + c) * KP + jq * NJ);
+    uint4* tl = reinterpret_cast<uint4*>(HTlo + (c0 + c) * KP + jq * NJ);
+    th[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); th[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+    tl[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); tl[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
+    if (*p) return NMFX_OK;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T)));
+    NMFX_HIP(hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), E->stream));
+    return NMFX_OK;
+}
+
+bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64; }
+
+static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
+                      const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy,
+                      const unsigned short* YThi, const unsigned short* YTlo, const unsigned short* Zhi,
+                      const unsigned short* Zlo, float* Apart, const char* name) {
+    ProfScope ps(E, name);
+    dim3 grid((unsigned)(R / 64), (unsigned)splits), block(256);
+    const size_t shm = 65536 + 16384;
+    static bool ok0 = false, ok1 = false;
+    if (obj) {
+        if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
+        hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
+                           Zhi, Zlo, Apart, E->obj_part, R, ngroups, &E->state->flag);
+    } else {
+        if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
+        hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
+                           Zhi, Zlo, Apart, E->obj_part, R, ngroups, &E->state->flag);
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// Allocate the bf16 state and build V^T and the images of the initial factors.
+int nmfx_bf16_prepare(nmfx_engine* E) {
+    if (E->bf_ready) return NMFX_OK;
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if ((rc = lazy_alloc(E, &E->Vt, mp * np))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = lazy_alloc(E, &E->Whi[b], mp * kp))) return rc;
+        if ((rc = lazy_alloc(E, &E->Wlo[b], mp * kp))) return rc;
+    }
+    if ((rc = lazy_alloc(E, &E->WThi, mp * kp))) return rc;
+    if ((rc = lazy_alloc(E, &E->WTlo, mp * kp))) return rc;
+    if ((rc = lazy_alloc(E, &E->Hhi, kp * np))) return rc;
+    if ((rc = lazy_alloc(E, &E->Hlo, kp * np))) return rc;
+    if ((rc = lazy_alloc(E, &E->HThi, kp * np))) return rc;
+    if ((rc = lazy_alloc(E, &E->HTlo, kp * np))) return rc;
+    // splits of the H phase: rows of V^T are columns of V
+    const int64_t rbt = np / 64, cbt = mp / 64;
+    int64_t hs2 = std::max<int64_t>(1, ((int64_t)E->ncu * 2 + rbt / 2) / rbt);
+    hs2 = std::min<int64_t>(hs2, std::max<int64_t>(1, cbt / 4));
+    E->bt_split = (int)hs2;
+    int64_t ws2 = std::max<int64_t>(1, ((int64_t)E->ncu * 2 + (mp / 64) / 2) / (mp / 64));
+    ws2 = std::min<int64_t>(ws2, std::max<int64_t>(1, (np / 64) / 4));
+    ws2 = std::min<int64_t>(ws2, E->wsplit);           // A_part was sized for wsplit slabs
+    E->bf_wsplit = (int)ws2;
+    if ((rc = lazy_alloc(E, &E->Bt_part, hs2 * np * kp))) return rc;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
+                       E->V, np, E->Vt, mp);
+    hipLaunchKernelGGL(split_images_kernel, dim3(1, (unsigned)(mp / 64)), dim3(256), 0, E->stream, E->W[0], mp, kp,
+                       kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo);
+    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(np / 64), 1), dim3(256), 0, E->stream, E->H, kp, np, np,
+                       E->Hhi, E->Hlo, E->HThi, E->HTlo);
+    NMFX_HIP(hipGetLastError());
+    E->bf_ready = true;
+    return NMFX_OK;
+}
+
+int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
+    int rc;
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    const int cur = (int)(j & 1), nxt = cur ^ 1;
+    const float* Wold = E->W[cur];
+    float* Wnew = E->W[nxt];
+    { ProfScope ps(E, "sum_hht");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
+    if ((rc = launch_xyt(E, true, E->V, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                         E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, "wphase"))) return rc;
+    { ProfScope ps(E, "w_update");
+      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 16)), dim3(256), 0, E->stream, E->A_part,
+                         E->bf_wsplit, E->mp, Wold, E->HHt, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
+                         E->WThi, E->WTlo, &E->state->flag);
+      NMFX_HIP(hipGetLastError()); }
+    if ((rc = nmfx_launch_gram_tn(E, Wnew, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = launch_xyt(E, false, E->Vt, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
+                         nullptr, nullptr, nullptr, nullptr, E->Bt_part, "hphase"))) return rc;
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->gsplit,
+                                 (int64_t)(E->mp / 64) * E->bf_wsplit);
+}
+
+int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,
+                             int64_t j) {
+    { ProfScope ps(E, "h_update");
+      const size_t shm = (size_t)(64 * 64 + 64 * 64) * sizeof(float);
+      hipLaunchKernelGGL(mur_h_update_bf16_kernel, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32,
+                         E->xf64, E->H, E->np, (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2,
+                         E->state, E->obj_hist, E->Hhi, E->Hlo, E->HThi, E->HTlo);
+      NMFX_HIP(hipGetLastError()); }
+    return nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit);
+}

@@ -213,6 +213,18 @@ int nmfx_launch_pack(nmfx_engine* E, const int* flag2) {
     return NMFX_OK;
 }
 
+int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const float* Gpart, int gsplit,
+                          int64_t nobj) {
+    ProfScope ps(E, "pack");
+    const int nb = 256;
+    const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
+    hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, Bpart, bsplit,
+                       (int64_t)E->kp * E->np, Gpart, gsplit, (int64_t)E->kp * E->kp, E->obj_part, nobj,
+                       E->xf32, E->xf64, nb, &E->state->flag, (const int*)nullptr);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 int nmfx_launch_obj_reduce(nmfx_engine* E) {
     ProfScope ps(E, "small");
     const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;

@@ -63,6 +63,15 @@ struct nmfx_engine {
     float* Pw = nullptr; float* Ph = nullptr;   // [kp][kp] fixed l2n prox operators (ADMM)
     float* Asum = nullptr;         // [mp][kp] summed V H^T (ADMM)
     float* S = nullptr; float* DV = nullptr;    // [mp][np] KL-ADMM: v_aux + dual_v, dual_v
+    // split-bf16 mode (kernels_bf16.hip): V^T and bf16 hi/lo images of the factors
+    int precision = 0;             // 0 = f32 MFMA, 1 = split bf16 (k padded to 64 only)
+    bool bf_ready = false;
+    int ncu = 256, bt_split = 1, bf_wsplit = 1;
+    float* Vt = nullptr;           // [np][mp]
+    float* Bt_part = nullptr;      // [bt_split][np][kp]
+    unsigned short *Whi[2] = {nullptr, nullptr}, *Wlo[2] = {nullptr, nullptr};   // [mp][kp]
+    unsigned short *WThi = nullptr, *WTlo = nullptr;                              // [kp][mp]
+    unsigned short *Hhi = nullptr, *Hlo = nullptr, *HThi = nullptr, *HTlo = nullptr;   // [kp][np], [np][kp]
     double* nrm_part = nullptr;    // [blocks][4]
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
@@ -101,7 +110,12 @@ int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld
 // shared small launchers (kernels_mur.hip / engine.hip)
 int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out);
 int nmfx_launch_pack(nmfx_engine* E, const int* flag2 = nullptr);   // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
+int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const float* Gpart, int gsplit,
+                          int64_t nobj);
 int nmfx_launch_obj_reduce(nmfx_engine* E);    // xf64[0] = sum obj_part
+bool nmfx_bf16_supported(const nmfx_engine* E);
+int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
+int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);

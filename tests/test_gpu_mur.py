@@ -95,3 +95,37 @@ def test_mur_kl_default_distance_is_kl_like_reference():
     np.random.seed(2)
     ref = R.mur(v.copy(), 4, min_iter=3, max_iter=3)
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(512, 384, 40), (640, 1000, 64), (200, 130, 33)])
+def test_mur_eu_k64_both_precisions_vs_oracle(precision, shape, monkeypatch):
+    """k in (32, 64] pads to 64, where the split-bf16 products are available
+    (NMFX_PRECISION=bf16).  Both arithmetic modes must meet the same bars."""
+    from nmf_amd.mur import mur
+    monkeypatch.setenv("NMFX_PRECISION", precision)
+    m, n, k = shape
+    v = R.planted_matrix(m, n, k, seed=m + n, dtype=np.float32)
+    np.random.seed(7)
+    res = mur(v, k, distance_type="eu", min_iter=40, max_iter=40, lambda_w=0.01, lambda_h=0.0)
+    np.random.seed(7)
+    ref = R.mur(v.astype(np.float64), k, distance_type="eu", min_iter=40, max_iter=40, lambda_w=0.01, lambda_h=0.0)
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    assert err < WH_TOL, err
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=OBJ_RTOL)
+
+
+def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
+    from nmf_amd.mur import mur
+    v = R.planted_matrix(300, 260, 36, seed=77, dtype=np.float32)
+    kw = dict(distance_type="eu", min_iter=5, max_iter=600, tol1=1e-9, tol2=5e-3)
+    out = {}
+    for precision in ("f32", "bf16"):
+        monkeypatch.setenv("NMFX_PRECISION", precision)
+        np.random.seed(3)
+        out[precision] = mur(v.copy(), 36, **kw)
+    np.random.seed(3)
+    ref = R.mur(v.astype(np.float64), 36, **kw)
+    assert ref.trace["stop_rule"] == 2 and ref.i < 599
+    assert out["f32"].i == ref.i
+    assert abs(out["bf16"].i - ref.i) <= 1, (out["bf16"].i, ref.i)
