@@ -12,10 +12,14 @@ HBM before the timed region.  For N > 1 the SAME matrix is row-sharded over the
 ranks (strong scaling) with one RCCL all-reduce of [W^T V | W^T W | objective]
 per iteration.  Rank 0 prints one JSON line.
 
-`roofline`: the dominant kernel (wphase: A = V H^T with the fused residual
-objective) priced with its ALGORITHMIC flops 2*m*n*k (the objective's second
-MFMA product is not counted) over its mean launch time, measured
-with HIP events on the engine's stream in a separate profiled pass.
+`roofline`: the dominant kernel (the W phase: A = V H^T with the fused residual
+objective), mean launch time from HIP events on the engine's stream in a
+separate profiled pass.  In the default arithmetic (split bf16: each f32 operand
+as bf16 hi + lo, four bf16 MFMA terms, f32 accumulation) the kernel is HBM
+bound: achieved = algorithmic bytes (V read once: m*n*4, plus the A slabs) over
+time against 8 TB/s.  With NMFX_PRECISION=f32 (exact f32-input MFMA) it is MFMA
+bound: algorithmic flops 2*m*n*k (the objective's second product is executed but
+not counted) against the 157.3 TFLOP/s f32 matrix peak.
 `cpu_baseline`: the numpy oracle (the reference's literal evaluation order:
 six m*n*k GEMMs per iteration, float64 factors) timed on this box's host cores.
 """
@@ -117,6 +121,8 @@ def main():
         def run(first, count):
             eng.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
 
+    precision = eng.precision()
+
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
@@ -158,12 +164,20 @@ def main():
         if "wphase" in prof:
             sec = prof["wphase"]["ms_per_launch"] * 1e-3
             flops = 2.0 * ml * n * k
-            ach = flops / sec / 1e12
-            roof = {"kernel": "wphase_kernel", "bound": "mfma", "achieved": ach,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                    "executed_flops_per_launch": 4.0 * ml * n * k,
-                    "hbm_gbs": (ml * n * 4.0 + 2.0 * ml * k * 4) / sec / 1e9}
+            nbytes = ml * n * 4.0 + 2.0 * ml * k * 4
+            if precision == "bf16":
+                ach = nbytes / sec / 1e9
+                roof = {"kernel": "xyt_bf16_kernel<true> (W phase)", "bound": "hbm", "achieved": ach,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": nbytes,
+                        "algorithmic_tflops": flops / sec / 1e12}
+            else:
+                ach = flops / sec / 1e12
+                roof = {"kernel": "wphase_kernel<64,true,true,false>", "bound": "mfma", "achieved": ach,
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                        "executed_flops_per_launch": 4.0 * ml * n * k,
+                        "hbm_gbs": nbytes / sec / 1e9}
         if "hphase" in prof:
             sec = prof["hphase"]["ms_per_launch"] * 1e-3
             prof["hphase"]["tflops"] = 2.0 * ml * n * k / sec / 1e12
@@ -184,7 +198,9 @@ def main():
             "metric": "NMF outer iterations/sec (MUR-eu, V=16384x8192 f32, k=64)",
             "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 hi+lo split MFMA, f32 accumulate, f64 objective" if precision == "bf16" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
                                    "|randn| init, objective every iteration",
                        "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}"},

@@ -13,7 +13,7 @@ int nmfx_mur_kl_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, doubl
 int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j);
 
 #ifndef NMFX_DEFAULT_PRECISION
-#define NMFX_DEFAULT_PRECISION 0
+#define NMFX_DEFAULT_PRECISION 1   /* split bf16 where available (k padded to 64, MUR-eu); NMFX_PRECISION=f32 for exact f32 */
 #endif
 static thread_local std::string g_err;
 
@@ -98,7 +98,8 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     nmfx_engine* E = new nmfx_engine();
     E->device = device; E->m = m; E->n = n; E->k = k;
     E->kp = k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 128;
-    E->mp = round_up(m, NMFX_TILE); E->np = round_up(n, NMFX_TILE);
+    // 128: the split-bf16 kernel works on 128-row blocks of V and of V^T; the f32 kernels need 64
+    E->mp = round_up(m, 2 * NMFX_TILE); E->np = round_up(n, 2 * NMFX_TILE);
     auto fail = [&](int rc) { g_err = E->err; nmfx_destroy(E); return rc; };
 #define TRY(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { E->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(NMFX_E_HIP); } } while (0)
@@ -130,7 +131,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->W[1], mp * kp));
     TRY(dev_alloc(E, &E->H, kp * np));
     TRY(dev_alloc(E, &E->HHt, kp * kp));
-    TRY(dev_alloc(E, &E->HHt_part, gs * kp * kp));
+    TRY(dev_alloc(E, &E->HHt_part, std::max(gs, ws) * kp * kp));
     TRY(dev_alloc(E, &E->G_part, std::max(gs, hs) * kp * kp));
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));

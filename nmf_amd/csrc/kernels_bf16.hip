@@ -26,14 +26,31 @@ union Frag8 { uint4 u; bf16x8 v; };
 __device__ __forceinline__ unsigned lds_off(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
-__device__ __forceinline__ void dma16b(const void* gsrc, unsigned lds_dst_wave_base) {
+// LDS-DMA runs: N consecutive 1 KiB pieces, 16 bytes per lane each, from (wave-uniform base
+// + per-lane 32-bit byte offset) to LDS (wave-uniform dst + piece * 1 KiB + lane * 16).  One
+// asm statement per run: m0 is saved once, bumped between the loads and restored, the lane
+// offsets are loop invariant and the base advances on the scalar unit, so a run costs no
+// vector instruction (cdna_hip_programming.md 5.7: M0 written in the statement that uses it).
+__device__ __forceinline__ void dma_run4(unsigned long long base, unsigned dst, unsigned o0, unsigned o1,
+                                         unsigned o2, unsigned o3) {
     unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory", "scc");
 }
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma_run2(unsigned long long base, unsigned dst, unsigned o0, unsigned o1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1) : "memory", "scc");
+}
+template <int N> __device__ __forceinline__ void dma_wait_le() {      // at most N DMAs still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
 __device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void pinu(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
@@ -50,63 +67,102 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& 
 
 // ---------------------------------------------------------------------------
 // A_part[sp] = X(rows of the block, columns of split sp) * Y^T, optional residual
-// objective 0.5 * sum (X - Z Y)^2.  Block = 64 rows (4 waves x 16), 64-column groups.
-// LDS per buffer (x2): Yhi, Ylo, YThi, YTlo tiles, each 64 rows x 128 B (bf16), 16-byte
-// chunk c of row r stored at position c ^ ((r >> 1) & 7); V tiles: 4 x [16][64] f32,
-// chunk c of row r at position c ^ r.  All filled by LDS-DMA, all reads conflict free.
+// objective 0.5 * sum (X - Z Y)^2.  Block = 128 rows (8 waves x 16 rows, two waves per
+// SIMD), 64-column groups.  LDS (all of the 160 KiB with the objective):
+//   Y side, double buffered: Yhi, Ylo (and YThi, YTlo) tiles, each 64 rows x 128 B of bf16,
+//     16-byte chunk c of row r at position c ^ ((r >> 1) & 7);  L2-resident source.
+//   V side, a 3-deep ring per wave: [16][64] f32, chunk c of row r at position c ^ r;
+//     this is the HBM stream, requested two groups ahead.
+// Everything is filled by LDS-DMA and retired with a COUNTED s_waitcnt vmcnt.  The DMA work
+// is split by wave (4 "Y loaders", 4 "V loaders" that each fetch the tiles of two waves) so
+// that the deep V prefetch is not drained by the shallow Y prefetch.  One barrier per group
+// publishes Y(grp) / V(grp) and frees the buffers read one group earlier.  All LDS reads are (loop-invariant lane offset)
+// + immediate and conflict free.
 // ---------------------------------------------------------------------------
+#pragma clang fp contract(fast)
 template <bool WITH_OBJ>
-__global__ __launch_bounds__(256) void xyt_bf16_kernel(
+__global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
     const unsigned short* __restrict__ YThi, const unsigned short* __restrict__ YTlo,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
-    float* __restrict__ Apart, double* __restrict__ objpart, int64_t R, int ngroups,
-    const int* __restrict__ flag)
+    float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
+    int ngroups, const int* __restrict__ flag)
 {
     if (*flag) return;
     constexpr int KP = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x 4 x 8 KiB + 4 x 4 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = WITH_OBJ ? 4 : 2;              // bf16 tiles per Y buffer
+    constexpr int YBUF = NT * 8192;                   // bytes
+    constexpr int VOFF = 2 * YBUF;                    // start of the V rings
+    constexpr int VRING = WITH_OBJ ? 3 : 4;           // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a PROVABLY uniform value: everything derived from it (DMA bases, LDS
+    // destinations) then stays in SGPRs, which the "s" operands of the DMA statements need
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = lane & 15, g = lane >> 4;
     const int S = gridDim.y, sp = blockIdx.y;
     const int g0 = (int)((int64_t)ngroups * sp / S);
     const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
-    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
-    unsigned char* vt = smem + 65536 + wave * 4096;
+    const int64_t r0 = (int64_t)blockIdx.x * 128 + wave * 16;
 
-    // ---- DMA plan ----
-    constexpr int NT = WITH_OBJ ? 4 : 2;              // tiles per buffer
-    constexpr int NP = NT * 8 / 4;                    // (tile, 1 KiB piece) pairs per wave
-    const unsigned short* tsrc[NP];
-    int tdst[NP];
+    // ---- DMA plan: roles by wave, so that every wave's vmcnt queue is homogeneous ----
+    // (vmcnt retires in order: a shallow Y request behind deep V requests would force
+    // the V requests to complete too.)
+    //   waves 4..7 ("Y loaders"): all NT*8 pieces of the Y tiles of group grp+1
+    //   waves 0..3 ("V loaders"): the V tiles of TWO waves each (w and w+4), VRING-1 groups ahead
+    const bool yrole = wave >= 4;
+    const int lw = wave & 3;
+    constexpr int YPW = NT * 8 / 4;                   // Y pieces per loader wave per group (8 / 4)
+    const int pidx0 = lw * YPW, ytile = pidx0 >> 3, p0 = pidx0 & 7;
+    const unsigned short* ysrc = ytile == 0 ? Yhi : ytile == 1 ? Ylo : ytile == 2 ? YThi : YTlo;
+    const unsigned long long ystep = ytile < 2 ? 64ull * 2ull : 64ull * KP * 2ull;     // bytes per group
+    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * ystep;
+    unsigned yoffs[YPW];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int pidx = wave * NP + i, tile = pidx >> 3, piece = pidx & 7;
-        const int row = 8 * piece + (lane >> 3), pos = lane & 7, chunk = pos ^ ((row >> 1) & 7);
-        const unsigned short* base = tile == 0 ? Yhi : tile == 1 ? Ylo : tile == 2 ? YThi : YTlo;
-        tsrc[i] = tile < 2 ? base + (int64_t)row * ldy + 8 * chunk           // + c0 per group
-                           : base + (int64_t)row * KP + 8 * chunk;           // + c0 * KP per group
-        tdst[i] = tile * 8192 + piece * 1024;
+    for (int i = 0; i < YPW; ++i) {
+        const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ ((row >> 1) & 7);
+        yoffs[i] = ytile < 2 ? (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2)
+                             : (unsigned)(((int64_t)row * KP + 8 * chunk) * 2);
     }
-    const float* vsrc[4];
+    const unsigned ydst = (unsigned)(ytile * 8192 + p0 * 1024);
+    // V: rows 4t + g of a wave's 16, position x holds chunk x ^ row
+    const int64_t rblk = (int64_t)blockIdx.x * 128;
+    unsigned long long vbaseA = (unsigned long long)(X + (rblk + lw * 16) * ldx) + (unsigned long long)g0 * 256ull;
+    unsigned long long vbaseB = (unsigned long long)(X + (rblk + (lw + 4) * 16) * ldx) + (unsigned long long)g0 * 256ull;
+    unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = 4 * t + g;
-        vsrc[t] = X + (r0 + row) * ldx + 4 * (x ^ row);
+        voffs[t] = (unsigned)(((int64_t)row * ldx + 4 * (x ^ row)) * 4);
     }
-    auto issue = [&](int grp, int buf) {
-        const int64_t c0 = (int64_t)grp * 64;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const bool tr = (wave * NP + i) >= 16;                           // YT tiles advance by c0 rows
-            dma16b(tsrc[i] + (tr ? c0 * KP : c0), lds_off(smem + buf * 32768 + tdst[i]));
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dma16b(vsrc[t] + c0, lds_off(vt + t * 1024));
+    const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
+    const unsigned vdstA = smem0 + VOFF + lw * (VRING * 4096);
+    const unsigned vdstB = smem0 + VOFF + (lw + 4) * (VRING * 4096);
+    int yq = 0, vq = 0;                               // next Y buffer / V ring slot to fill
+    auto issue_y = [&]() {                            // Y loaders only
+        dma_run4(ybase, smem0 + yq * YBUF + ydst, yoffs[0], yoffs[1], yoffs[2], yoffs[3]);
+        if (YPW == 8) dma_run4(ybase, smem0 + yq * YBUF + ydst + 4096, yoffs[YPW - 4], yoffs[YPW - 3], yoffs[YPW - 2], yoffs[YPW - 1]);
+        ybase += ystep; yq ^= 1;
+    };
+    auto issue_v = [&]() {                            // V loaders only
+        dma_run4(vbaseA, vdstA + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
+        dma_run4(vbaseB, vdstB + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
+        vbaseA += 256ull; vbaseB += 256ull; vq = (vq == VRING - 1) ? 0 : vq + 1;
     };
 
-    // Z fragments (rows of W as bf16 hi/lo): lane (r = x, g): Z[r0 + x][32 s + 8 g .. +7]
+    // ---- loop-invariant LDS read offsets ----
+    int ylane[2], vaoff[2][2], vroff[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ ((x >> 1) & 7));     // + 2048 * (row block) + 8192 * tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h) vaoff[s][h] = x * 256 + 16 * ((8 * s + 2 * g + h) ^ x);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vroff[e] = x * 256 + 16 * ((4 * e + g) ^ x);
+    const unsigned char* vring = smem + VOFF + wave * (VRING * 4096);
+
     Frag8 zh[2], zl[2];
     if (WITH_OBJ) {
 #pragma unroll
@@ -119,79 +175,120 @@ __global__ __launch_bounds__(256) void xyt_bf16_kernel(
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Gram by-product: the row blocks with blockIdx.x == 0 also accumulate Y Y^T over their
+    // column range from the Y fragments they fetch anyway (H H^T in the W phase, W^T W in the
+    // H phase).  Wave w owns tile row w>>1 and tile columns 2(w&1), 2(w&1)+1.
+    const bool do_gram = (blockIdx.x == 0);
+    const int git = wave >> 1, gj0 = 2 * (wave & 1);
+    f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
+    // the Z loads above are ordinary vector loads: retire them before DMAs enter the queue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (g0 < g1) issue(g0, 0);
-    dma_wait();
-    __syncthreads();
-    int cur = 0;
+    if (yrole) { if (g0 < g1) issue_y(); }
+    else {
+#pragma unroll
+        for (int a = 0; a < VRING - 1; ++a) if (g0 + a < g1) issue_v();
+    }
+    int ycur = 0, vcur = 0;
     for (int grp = g0; grp < g1; ++grp) {
-        // V slice of this wave, two register images: A-operand chunks (8s + 2g, +1) and,
-        // for the residual, chunks (4e + g) -- both of row x
+        // Y loaders: Y(grp) is their newest request.  V loaders: V(grp+1 .. grp+VRING-2) may
+        // stay in flight (8 DMAs per group), V(grp) must have landed.
+        if (yrole) dma_wait_le<0>();
+        else {
+            const int ahead = min(VRING - 2, g1 - 1 - grp);
+            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        }
+        __syncthreads();
+        if (yrole) { if (grp + 1 < g1) issue_y(); }
+        else if (grp + VRING - 1 < g1) issue_v();
+        const unsigned char* ybuf = smem + ycur * YBUF;
+        const unsigned char* vt = vring + vcur * 4096;
+
         float4 va[2][2], vr[4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                va[s][h] = *reinterpret_cast<const float4*>(vt + x * 256 + 16 * ((8 * s + 2 * g + h) ^ x));
+            for (int h = 0; h < 2; ++h) va[s][h] = *reinterpret_cast<const float4*>(vt + vaoff[s][h]);
         if (WITH_OBJ) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                vr[e] = *reinterpret_cast<const float4*>(vt + x * 256 + 16 * ((4 * e + g) ^ x));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pin4(vr[e]);
+            for (int e = 0; e < 4; ++e) vr[e] = *reinterpret_cast<const float4*>(vt + vroff[e]);
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { pin4(va[s][0]); pin4(va[s][1]); }
-        if (grp + 1 < g1) issue(grp + 1, cur ^ 1);
-        const unsigned char* buf = smem + cur * 32768;
-
         Frag8 vh[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
 
-        // A-product: acc[jt] += V(16 x 64) . Ytile(rows jt*16.., 64)^T
+        // A-product: acc[jt] += V(16 x 64) . Ytile(rows jt*16.., 64)^T ; fragments of one
+        // k-step are fetched together, then 16 MFMAs
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            const unsigned char* ys = ybuf + ylane[s];
+            Frag8 yh[4], yl[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                const int row = jt * 16 + x;
-                const int off = row * 128 + 16 * ((4 * s + g) ^ ((row >> 1) & 7));
-                Frag8 yh, yl;
-                yh.u = *reinterpret_cast<const uint4*>(buf + off);
-                yl.u = *reinterpret_cast<const uint4*>(buf + 8192 + off);
-                acc[jt] = MFMA_BF16(vh[s], yh, acc[jt]);
-                acc[jt] = MFMA_BF16(vl[s], yh, acc[jt]);
-                acc[jt] = MFMA_BF16(vh[s], yl, acc[jt]);
-                acc[jt] = MFMA_BF16(vl[s], yl, acc[jt]);
+                yh[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
+                yl[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[s], yh[jt], acc[jt]);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[s], yh[jt], acc[jt]);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[s], yl[jt], acc[jt]);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[s], yl[jt], acc[jt]);
+            if (do_gram) {
+                // operands straight from the LDS tiles at wave-uniform tile rows (selecting among
+                // the yh[]/yl[] registers by wave would spill): A = rows 16*git.., B = rows 16*(gj0+c)..
+                Frag8 ah, al;
+                ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
+                al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + 8192);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    Frag8 bh, bl;
+                    bh.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048);
+                    bl.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048 + 8192);
+                    gacc[c] = MFMA_BF16(ah, bh, gacc[c]);
+                    gacc[c] = MFMA_BF16(al, bh, gacc[c]);
+                    gacc[c] = MFMA_BF16(ah, bl, gacc[c]);
+                    gacc[c] = MFMA_BF16(al, bl, gacc[c]);
+                }
             }
         }
         if (WITH_OBJ) {
             // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]   (computed as Y^T-tile x Z^T)
+            f32x4 d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char* ts = ybuf + ylane[s] + 16384;
+                Frag8 th[4], tl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    th[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
+                    tl[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(th[e], zh[s], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(tl[e], zh[s], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(th[e], zl[s], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(tl[e], zl[s], d[e]);
+            }
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int row = 16 * e + x;
-                    const int off = row * 128 + 16 * ((4 * s + g) ^ ((row >> 1) & 7));
-                    Frag8 th, tl;
-                    th.u = *reinterpret_cast<const uint4*>(buf + 16384 + off);
-                    tl.u = *reinterpret_cast<const uint4*>(buf + 24576 + off);
-                    d = MFMA_BF16(th, zh[s], d);
-                    d = MFMA_BF16(tl, zh[s], d);
-                    d = MFMA_BF16(th, zl[s], d);
-                    d = MFMA_BF16(tl, zl[s], d);
-                }
-                const float rx = vr[e].x - d[0], ry = vr[e].y - d[1], rz = vr[e].z - d[2], rw = vr[e].w - d[3];
+                const float rx = vr[e].x - d[e][0], ry = vr[e].y - d[e][1];
+                const float rz = vr[e].z - d[e][2], rw = vr[e].w - d[e][3];
                 part += rx * rx + ry * ry + rz * rz + rw * rw;
             }
             osum += (double)part;
         }
-        dma_wait();
-        __syncthreads();
-        cur ^= 1;
+        ycur ^= 1;
+        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
     }
 
     {
@@ -201,16 +298,29 @@ __global__ __launch_bounds__(256) void xyt_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(int64_t)(4 * g + r) * KP + jt * 16 + x] = acc[jt][r];
     }
+    if (do_gram) {
+        float* go = gram_part + (int64_t)sp * KP * KP;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                go[(int64_t)(16 * git + 4 * g + r) * KP + 16 * (gj0 + c) + x] = gacc[c][r];
+    }
     if (WITH_OBJ) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
+        __syncthreads();                                   // everybody is done with the LDS tiles
         double* red = reinterpret_cast<double*>(smem);
         if (lane == 0) red[wave] = osum;
         __syncthreads();
-        if (tid == 0)
-            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 8; ++w) t += red[w];
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * t;
+        }
     }
 }
+#pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------
 // out[c][r] = in[r][c]  (64 x 64 tiles through LDS; both matrices padded to 64)
@@ -256,7 +366,7 @@ __global__ __launch_bounds__(256) void split_images_kernel(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
-    const float* __restrict__ HHt, float lam, float* __restrict__ Wnew,
+    const float* __restrict__ HHtpart, float lam, float* __restrict__ Wnew,
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
@@ -267,7 +377,11 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     __shared__ unsigned short th[KP][18], tl[KP][18];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 16;
-    for (int i = tid; i < KP * KP; i += 256) hs[i] = HHt[i];
+    for (int i = tid; i < KP * KP; i += 256) {         // H H^T = sum of the W phase's by-product slabs
+        float v = HHtpart[i];
+        for (int p = 1; p < wsplit; ++p) v += HHtpart[(int64_t)p * KP * KP + i];
+        hs[i] = v;
+    }
     for (int i = tid; i < 16 * KP; i += 256) ws[i] = Wold[r0 * KP + i];
     __syncthreads();
     const int row = tid >> 4, jl = tid & 15;
@@ -376,26 +490,26 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
     return NMFX_OK;
 }
 
-bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64; }
+bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64 && E->mp % 128 == 0 && E->np % 128 == 0; }
 
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy,
                       const unsigned short* YThi, const unsigned short* YTlo, const unsigned short* Zhi,
-                      const unsigned short* Zlo, float* Apart, const char* name) {
+                      const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
     ProfScope ps(E, name);
-    dim3 grid((unsigned)(R / 64), (unsigned)splits), block(256);
-    const size_t shm = 65536 + 16384;
+    dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+    const size_t shm = (size_t)2 * (obj ? 4 : 2) * 8192 + (size_t)8 * (obj ? 3 : 4) * 4096;
     static bool ok0 = false, ok1 = false;
     if (obj) {
         if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, R, ngroups, &E->state->flag);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag);
     } else {
         if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, R, ngroups, &E->state->flag);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag);
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -418,11 +532,12 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     if ((rc = lazy_alloc(E, &E->HThi, kp * np))) return rc;
     if ((rc = lazy_alloc(E, &E->HTlo, kp * np))) return rc;
     // splits of the H phase: rows of V^T are columns of V
-    const int64_t rbt = np / 64, cbt = mp / 64;
-    int64_t hs2 = std::max<int64_t>(1, ((int64_t)E->ncu * 2 + rbt / 2) / rbt);
+    // one 512-thread block per CU: grid = (rows / 128) x splits ~ number of CUs
+    const int64_t rbt = np / 128, cbt = mp / 64;
+    int64_t hs2 = std::max<int64_t>(1, ((int64_t)E->ncu + rbt / 2) / rbt);
     hs2 = std::min<int64_t>(hs2, std::max<int64_t>(1, cbt / 4));
     E->bt_split = (int)hs2;
-    int64_t ws2 = std::max<int64_t>(1, ((int64_t)E->ncu * 2 + (mp / 64) / 2) / (mp / 64));
+    int64_t ws2 = std::max<int64_t>(1, ((int64_t)E->ncu + (mp / 128) / 2) / (mp / 128));
     ws2 = std::min<int64_t>(ws2, std::max<int64_t>(1, (np / 64) / 4));
     ws2 = std::min<int64_t>(ws2, E->wsplit);           // A_part was sized for wsplit slabs
     E->bf_wsplit = (int)ws2;
@@ -444,29 +559,28 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const int cur = (int)(j & 1), nxt = cur ^ 1;
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
-    { ProfScope ps(E, "sum_hht");
-      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
+    // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
     if ((rc = launch_xyt(E, true, E->V, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                         E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, "wphase"))) return rc;
+                         E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
     { ProfScope ps(E, "w_update");
       hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 16)), dim3(256), 0, E->stream, E->A_part,
-                         E->bf_wsplit, E->mp, Wold, E->HHt, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
+                         E->bf_wsplit, E->mp, Wold, E->HHt_part, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
                          E->WThi, E->WTlo, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
-    if ((rc = nmfx_launch_gram_tn(E, Wnew, E->mp, E->G_part, E->gsplit))) return rc;
+    // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                         nullptr, nullptr, nullptr, nullptr, E->Bt_part, "hphase"))) return rc;
-    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->gsplit,
-                                 (int64_t)(E->mp / 64) * E->bf_wsplit);
+                         nullptr, nullptr, nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->bt_split,
+                                 (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,
                              int64_t j) {
-    { ProfScope ps(E, "h_update");
-      const size_t shm = (size_t)(64 * 64 + 64 * 64) * sizeof(float);
-      hipLaunchKernelGGL(mur_h_update_bf16_kernel, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32,
-                         E->xf64, E->H, E->np, (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2,
-                         E->state, E->obj_hist, E->Hhi, E->Hlo, E->HThi, E->HTlo);
-      NMFX_HIP(hipGetLastError()); }
-    return nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit);
+    ProfScope ps(E, "h_update");
+    const size_t shm = (size_t)(64 * 64 + 64 * 64) * sizeof(float);
+    hipLaunchKernelGGL(mur_h_update_bf16_kernel, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32,
+                       E->xf64, E->H, E->np, (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2,
+                       E->state, E->obj_hist, E->Hhi, E->Hlo, E->HThi, E->HTlo);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }

@@ -15,7 +15,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
-    if not any(s in k for s in ("wphase", "hphase")):
+    if not any(s in k for s in ("wphase", "hphase", "xyt")):
         continue
     print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
 PY
