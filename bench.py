@@ -51,7 +51,48 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def hbm_traffic(kernel_prefix, m, n, k):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
+    passes (--pmc with --kernel-trace only), FETCH_SIZE (KB) doubled because gfx950
+    reports half of the bytes of wide coalesced streaming reads.  Each pass runs this
+    script again as a child (`-- python3 bench.py --pmc-child`).  None when rocprofv3 is
+    unavailable or fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="nmfx_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1",
+                   "--m", str(m), "--n", str(n), "--k", str(k)]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=240, cwd="/tmp")
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                   if row["Counter_Name"] == ctr and kernel_prefix in row["Kernel_Name"]]
+            if not got:
+                return None
+            vals[ctr] = sum(got) / len(got)
+        except Exception:  # noqa: BLE001
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0
 
 
 def cpu_baseline(v, k, iters):
@@ -150,7 +191,7 @@ def main():
     # profiled pass: per-kernel device time from HIP events on the engine's stream
     roof = None
     prof = {}
-    if args.profile_steps > 0:
+    if args.profile_steps > 0 and not args.pmc_child:
         eng.profile_enable(True)
         eng.profile_reset()
         run(done, args.profile_steps)
@@ -182,6 +223,14 @@ def main():
             sec = prof["hphase"]["ms_per_launch"] * 1e-3
             prof["hphase"]["tflops"] = 2.0 * ml * n * k / sec / 1e12
             prof["hphase"]["hbm_gbs"] = ml * n * 4.0 / sec / 1e9
+
+    if args.pmc_child:            # inside a rocprofv3 PMC pass: the timed region above is all that is needed
+        return
+    if rank == 0 and world == 1 and roof is not None and not args.no_traffic:
+        eng.close()               # free the HBM before the child passes allocate their own
+        roof["traffic"] = hbm_traffic("xyt_bf16_kernel<true>" if precision == "bf16" else "wphase_kernel", m, n, k)
+        roof["traffic_note"] = ("HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                "FETCH_SIZE x2 (gfx950 correction)")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
