@@ -16,6 +16,8 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "lib", "libnmfx.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-ffp-contract=off"]
+if os.environ.get("NMFX_BF16_TERMS"):
+    FLAGS.append("-DNMFX_BF16_TERMS=" + os.environ["NMFX_BF16_TERMS"])
 
 
 def _hipcc():

@@ -19,6 +19,9 @@
 #include "nmfx_internal.h"
 #include "kernels_small.h"
 
+#ifndef NMFX_BF16_TERMS
+#define NMFX_BF16_TERMS 4      // 4: hi*hi + hi*lo + lo*hi + lo*lo;  3: without lo*lo (2^-16 relative, random sign)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union Frag8 { uint4 u; bf16x8 v; };
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const unsigned short* __restrict__ YThi, const unsigned short* __restrict__ YTlo,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
-    int ngroups, const int* __restrict__ flag)
+    int ngroups, const int* __restrict__ flag, int dbg)
 {
     if (*flag) return;
     constexpr int KP = 64;
@@ -200,12 +203,18 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
         }
         __syncthreads();
-        if (yrole) { if (grp + 1 < g1) issue_y(); }
-        else if (grp + VRING - 1 < g1) issue_v();
+        if (yrole) { if (grp + 1 < g1 && !(dbg & 1)) issue_y(); }      // dbg: timing experiments only
+        else if (grp + VRING - 1 < g1 && !(dbg & 2)) issue_v();
         const unsigned char* ybuf = smem + ycur * YBUF;
         const unsigned char* vt = vring + vcur * 4096;
 
+        // Explicit software pipeline (hipcc otherwise pairs every ds_read with its own
+        // s_waitcnt right in front of the MFMA that uses it): each stage first ISSUES the
+        // next batch of eight fragment reads, then runs the 16 MFMAs of the batch that has
+        // landed.  sched_barrier(0) pins the stage boundaries.
+#define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
         float4 va[2][2], vr[4];
+        Frag8 fa[4], fb[4], fc[4], fd[4];              // two batches in flight: (fa, fb) and (fc, fd)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -214,32 +223,62 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) vr[e] = *reinterpret_cast<const float4*>(vt + vroff[e]);
         }
+        {   // batch A0: Y tile rows jt*16.., k-step 0 (hi -> fa, lo -> fb)
+            const unsigned char* ys = ybuf + ylane[0];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                fa[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
+                fb[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
+            }
+        }
+        NMFX_FENCE();
         Frag8 vh[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
-
-        // A-product: acc[jt] += V(16 x 64) . Ytile(rows jt*16.., 64)^T ; fragments of one
-        // k-step are fetched together, then 16 MFMAs
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const unsigned char* ys = ybuf + ylane[s];
-            Frag8 yh[4], yl[4];
+        {   // issue batch A1 (-> fc, fd)
+            const unsigned char* ys = ybuf + ylane[1];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                yh[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
-                yl[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
+                fc[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
+                fd[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
             }
+        }
+        NMFX_FENCE();
+        // A-product, k-step 0
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[s], yh[jt], acc[jt]);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[0], fa[jt], acc[jt]);
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[s], yh[jt], acc[jt]);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[0], fa[jt], acc[jt]);
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[s], yl[jt], acc[jt]);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[0], fb[jt], acc[jt]);
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[s], yl[jt], acc[jt]);
-            if (do_gram) {
-                // operands straight from the LDS tiles at wave-uniform tile rows (selecting among
-                // the yh[]/yl[] registers by wave would spill): A = rows 16*git.., B = rows 16*(gj0+c)..
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[0], fb[jt], acc[jt]);
+        NMFX_FENCE();
+        if (WITH_OBJ) {   // issue batch D0: Y^T tile rows 16e.., k-step 0 (-> fa, fb)
+            const unsigned char* ts = ybuf + ylane[0] + 16384;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                fa[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
+                fb[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
+            }
+        }
+        NMFX_FENCE();
+        // A-product, k-step 1
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[1], fc[jt], acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[1], fc[jt], acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[1], fd[jt], acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[1], fd[jt], acc[jt]);
+        NMFX_FENCE();
+        if (do_gram) {
+            // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
+            // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char* ys = ybuf + ylane[s];
                 Frag8 ah, al;
                 ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
                 al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + 8192);
@@ -260,24 +299,32 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             f32x4 d[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned char* ts = ybuf + ylane[s] + 16384;
-                Frag8 th[4], tl[4];
+            {   // issue batch D1 (-> fc, fd)
+                const unsigned char* ts = ybuf + ylane[1] + 16384;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    th[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
-                    tl[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
+                    fc[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
+                    fd[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(th[e], zh[s], d[e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(tl[e], zh[s], d[e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(th[e], zl[s], d[e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(tl[e], zl[s], d[e]);
             }
+            NMFX_FENCE();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fa[e], zh[0], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fb[e], zh[0], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fa[e], zl[0], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fb[e], zl[0], d[e]);
+            NMFX_FENCE();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fc[e], zh[1], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fd[e], zh[1], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fc[e], zl[1], d[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fd[e], zl[1], d[e]);
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -287,6 +334,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             }
             osum += (double)part;
         }
+#undef NMFX_FENCE
         ycur ^= 1;
         vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
     }
@@ -497,6 +545,7 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int
                       const unsigned short* YThi, const unsigned short* YTlo, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
     ProfScope ps(E, name);
+    static const int dbg = getenv("NMFX_DEBUG_SKIP") ? atoi(getenv("NMFX_DEBUG_SKIP")) : 0;   // 1: no Y refills, 2: no V refills
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = (size_t)2 * (obj ? 4 : 2) * 8192 + (size_t)8 * (obj ? 3 : 4) * 4096;
     static bool ok0 = false, ok1 = false;
@@ -504,12 +553,12 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int
         if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, dbg);
     } else {
         if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, dbg);
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

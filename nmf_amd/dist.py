@@ -41,8 +41,19 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.stage = stage_through_host
+        self._coalesce = hasattr(dist, "_coalescing_manager")
 
     def all_reduce(self, *tensors):
+        # RCCL: put the f32 and the f64 reduction into ONE group launch (ncclGroupStart/End)
+        # -- one host call and one kernel instead of two per outer iteration.
+        if len(tensors) > 1 and not self.stage and all(t.is_cuda for t in tensors) and self._coalesce:
+            try:
+                with self.dist._coalescing_manager(group=self.group, device=tensors[0].device, async_ops=False):
+                    for t in tensors:
+                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                return
+            except Exception:      # noqa: BLE001  (private torch API: fall back for good)
+                self._coalesce = False
         for t in tensors:
             if self.stage and t.is_cuda:
                 import torch
