@@ -416,11 +416,13 @@ int nmfx_mur_run(nmfx_handle_t E, int distance, double lambda_w, double lambda_h
                  double tol1, double tol2, int64_t first, int64_t count) {
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, first, count); if (rc) return rc;
-    for (int64_t j = first; j < first + count; ++j) {
-        if ((rc = nmfx_mur_phase_a(E, distance, lambda_w, j))) return rc;
-        if ((rc = nmfx_mur_phase_b(E, distance, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    E->fused_pack = true;            // nothing is exchanged between the phases here
+    for (int64_t j = first; j < first + count && !rc; ++j) {
+        if ((rc = nmfx_mur_phase_a(E, distance, lambda_w, j))) break;
+        rc = nmfx_mur_phase_b(E, distance, lambda_h, min_iter, tol1, tol2, j);
     }
-    return NMFX_OK;
+    E->fused_pack = false;
+    return rc;
 }
 
 int nmfx_mur_finish(nmfx_handle_t E, int distance, int64_t min_iter, double tol1, double tol2,

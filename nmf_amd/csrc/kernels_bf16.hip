@@ -409,9 +409,20 @@ __global__ __launch_bounds__(256) void split_images_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// W epilogue (nmf/mur.py:29) + the bf16 images of the new W: row-major (next
-// iteration's residual) and transposed (this iteration's H phase).
+// W epilogue (nmf/mur.py:29): W_new = W * A / (W (H H^T) + lam W + 1e-9), plus the bf16 images
+// of the new W: row-major (next iteration's residual) and transposed (this iteration's H
+// phase).  Block = 64 rows; the 64 x 64 x 64 product W (H H^T) runs on the f32 MFMA.
 // ---------------------------------------------------------------------------
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ void add4(float* acc, const float* src) {   // acc[0..3] += one 16-byte load
+    const float4 t = *reinterpret_cast<const float4*>(src);
+    acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+}
+__device__ __forceinline__ uint4 pack8(const unsigned short* p) {       // 8 consecutive bf16 from LDS
+    return make_uint4(p[0] | ((unsigned)p[1] << 16), p[2] | ((unsigned)p[3] << 16),
+                      p[4] | ((unsigned)p[5] << 16), p[6] | ((unsigned)p[7] << 16));
+}
+
 __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
     const float* __restrict__ HHtpart, float lam, float* __restrict__ Wnew,
@@ -419,112 +430,211 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
     if (*flag) return;
-    constexpr int KP = 64;
-    __shared__ float hs[KP * KP];
-    __shared__ float ws[16 * KP];
-    __shared__ unsigned short th[KP][18], tl[KP][18];
-    const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * 16;
-    for (int i = tid; i < KP * KP; i += 256) {         // H H^T = sum of the W phase's by-product slabs
-        float v = HHtpart[i];
-        for (int p = 1; p < wsplit; ++p) v += HHtpart[(int64_t)p * KP * KP + i];
-        hs[i] = v;
-    }
-    for (int i = tid; i < 16 * KP; i += 256) ws[i] = Wold[r0 * KP + i];
-    __syncthreads();
-    const int row = tid >> 4, jl = tid & 15;
+    constexpr int KP = 64, RB = 64, LDW = 68, LDH = 80;          // padded LDS rows: conflict-free dword reads
+    __shared__ __attribute__((aligned(16))) float hs[KP * LDH];  // H H^T, later the product tile D [row][LDW]
+    __shared__ __attribute__((aligned(16))) float ws[RB * LDW];
+    __shared__ unsigned short th[KP][RB + 2], tl[KP][RB + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * RB;
+    {   // H H^T = sum of the W phase's by-product slabs; 4 independent 16-byte loads per slab round
+        float v[4][4] = {};
+        for (int p = 0; p < wsplit; ++p) {
+            float4 t[4];
 #pragma unroll
-    for (int jj = 0; jj < KP / 16; ++jj) {
-        const int j = jl + 16 * jj;
-        float d = 0.f;
-#pragma unroll 8
-        for (int l = 0; l < KP; ++l) d = fmaf(ws[row * KP + l], hs[l * KP + j], d);
-        const int64_t idx = (r0 + row) * KP + j;
-        float a = Apart[idx];
-        for (int p = 1; p < wsplit; ++p) a += Apart[(int64_t)p * mp * KP + idx];
-        const float w = ws[row * KP + j];
-        const float wn = w * a / (d + lam * w + 1e-9f);
-        Wnew[idx] = wn;
-        unsigned h, l2;
-        split2(wn, 0.f, h, l2);
-        Whi[idx] = (unsigned short)h; Wlo[idx] = (unsigned short)l2;
-        th[j][row] = (unsigned short)h; tl[j][row] = (unsigned short)l2;
+            for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const float4*>(HHtpart + (int64_t)p * KP * KP)[tid + 256 * u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u][0] += t[u].x; v[u][1] += t[u].y; v[u][2] += t[u].z; v[u][3] += t[u].w; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u;
+            *reinterpret_cast<float4*>(hs + (i >> 4) * LDH + 4 * (i & 15)) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
+    }
+    for (int i = tid; i < RB * KP / 4; i += 256)
+        *reinterpret_cast<float4*>(ws + (i >> 4) * LDW + 4 * (i & 15)) = reinterpret_cast<const float4*>(Wold + r0 * KP)[i];
+    __syncthreads();
+    // D[row][j] = sum_l W[row][l] HHt[l][j]; wave = 16 rows, 4 column tiles
+    f32x4 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int u = 0; u < KP / 4; ++u) {
+        const float a = ws[(16 * wave + x) * LDW + 4 * u + q];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_F32(a, hs[(4 * u + q) * LDH + 16 * jt + x], acc[jt]);
+    }
+    __syncthreads();                                   // everybody is done with H H^T
+    // volatile: hipcc 7.2's DS store merging (ds_write2_b32) mis-encodes offset0 for these
+    // strided stores (17/34/51 dwords instead of 68/136/204); volatile keeps them single.
+    volatile float* dt = hs;                           // D tile [row][LDW]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dt[(16 * wave + 4 * q + r) * LDW + 16 * jt + x] = acc[jt][r];
+    __syncthreads();
+    {   // epilogue, vectorised along the factor index: thread = (row, 16 consecutive j)
+        const int row = tid >> 2, j0 = 16 * (tid & 3);
+        const int64_t idx = (r0 + row) * KP + j0;
+        float a[16] = {}, wn[16];
+        for (int p = 0; p < wsplit; ++p) {
+            float4 t[4];
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) t[v4] = *reinterpret_cast<const float4*>(Apart + (int64_t)p * mp * KP + idx + 4 * v4);
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) { a[4 * v4] += t[v4].x; a[4 * v4 + 1] += t[v4].y; a[4 * v4 + 2] += t[v4].z; a[4 * v4 + 3] += t[v4].w; }
+        }
+        unsigned ph[8], pl[8];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float w = ws[row * LDW + j0 + e];
+            wn[e] = w * a[e] / (dt[row * LDW + j0 + e] + lam * w + 1e-9f);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            split2(wn[2 * e], wn[2 * e + 1], ph[e], pl[e]);
+            th[j0 + 2 * e][row] = (unsigned short)(ph[e] & 0xffffu); th[j0 + 2 * e + 1][row] = (unsigned short)(ph[e] >> 16);
+            tl[j0 + 2 * e][row] = (unsigned short)(pl[e] & 0xffffu); tl[j0 + 2 * e + 1][row] = (unsigned short)(pl[e] >> 16);
+        }
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4)
+            *reinterpret_cast<float4*>(Wnew + idx + 4 * v4) = make_float4(wn[4 * v4], wn[4 * v4 + 1], wn[4 * v4 + 2], wn[4 * v4 + 3]);
+        uint4* oh = reinterpret_cast<uint4*>(Whi + idx);
+        uint4* ol = reinterpret_cast<uint4*>(Wlo + idx);
+        oh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); oh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+        ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
     }
     __syncthreads();
-    {   // transposed images: thread (f = tid/4, quarter = tid%4) stores 4 rows = 8 bytes
+    {   // transposed images: thread (f = tid/4, quarter = tid%4) stores 16 rows = 32 bytes per image
         const int f = tid >> 2, qd = tid & 3;
-        const uint2 vh = make_uint2(th[f][4 * qd] | ((unsigned)th[f][4 * qd + 1] << 16),
-                                    th[f][4 * qd + 2] | ((unsigned)th[f][4 * qd + 3] << 16));
-        const uint2 vl = make_uint2(tl[f][4 * qd] | ((unsigned)tl[f][4 * qd + 1] << 16),
-                                    tl[f][4 * qd + 2] | ((unsigned)tl[f][4 * qd + 3] << 16));
-        *reinterpret_cast<uint2*>(WThi + (int64_t)f * mp + r0 + 4 * qd) = vh;
-        *reinterpret_cast<uint2*>(WTlo + (int64_t)f * mp + r0 + 4 * qd) = vl;
+        uint4* oh = reinterpret_cast<uint4*>(WThi + (int64_t)f * mp + r0 + 16 * qd);
+        uint4* ol = reinterpret_cast<uint4*>(WTlo + (int64_t)f * mp + r0 + 16 * qd);
+        oh[0] = pack8(&th[f][16 * qd]); oh[1] = pack8(&th[f][16 * qd + 8]);
+        ol[0] = pack8(&tl[f][16 * qd]); ol[1] = pack8(&tl[f][16 * qd + 8]);
     }
 }
 
-// H epilogue (nmf/mur.py:45) from B^T = V^T W (stored [np][64]) + objective bookkeeping
-// + the bf16 images of the new H (row-major [64][np] and transposed [np][64]).
+// H epilogue (nmf/mur.py:45): H_new = H * B / (G H + lam H + 1e-9) from B^T = V^T W (stored
+// [np][64]) + objective bookkeeping + the bf16 images of the new H (row-major [64][np] and
+// transposed [np][64]).  Block = 64 columns; the 64 x 64 x 64 product G H runs on the f32
+// MFMA and every global access is a 16-byte vector (tiles are turned through LDS).
+// FROM_SLABS: single-GPU runs read the split slabs of the H phase, the Gram slabs and the
+// objective partials directly (no `pack` launch); sharded runs read the all-reduced
+// exchange buffers.
+template <bool FROM_SLABS>
 __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
-    const float* __restrict__ xf32, const double* __restrict__ xf64, float* __restrict__ H,
+    const float* __restrict__ bsrc, int bsplit, const float* __restrict__ gsrc, int gsplit,
+    const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
     int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
     unsigned short* __restrict__ HThi, unsigned short* __restrict__ HTlo)
 {
     if (st->flag) return;
-    const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
-                                           blockIdx.x == 0 && threadIdx.x == 0);
+    constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDG]
+    float* hs = gs + KP * LDG;                         // H tile [j][LDC]
+    float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
+    unsigned short* th = reinterpret_cast<unsigned short*>(bt + CB * LDG);   // [c][KP + 2] hi
+    unsigned short* tl = th + CB * (KP + 2);                                 // [c][KP + 2] lo
+    __shared__ double shd[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    double obj;
+    if (FROM_SLABS) {                                  // same fixed-order sum in every block
+        double sacc = 0.0;
+        for (int64_t i = tid; i < nobj; i += 256) sacc += osrc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+        if (lane == 0) shd[wave] = sacc;
+        __syncthreads();
+        obj = ((shd[0] + shd[1]) + shd[2]) + shd[3];
+    } else {
+        obj = osrc[0];
+    }
+    const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2,
+                                           blockIdx.x == 0 && tid == 0);
     if (rule) return;
-    constexpr int KP = 64;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* gs = lds;                 // [KP][KP]
-    float* hs = lds + KP * KP;       // [KP][64]
-    const int tid = threadIdx.x, c = tid & 63, jq = tid >> 6;
-    const int64_t c0 = (int64_t)blockIdx.x * 64;
-    const float* G = xf32 + (int64_t)KP * np;
-    for (int i = tid; i < KP * KP; i += 256) gs[i] = G[i];
-    for (int i = tid; i < KP * 64; i += 256) hs[i] = H[(int64_t)(i >> 6) * np + c0 + (i & 63)];
+    const int64_t c0 = (int64_t)blockIdx.x * CB;
+    const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
+    {   // G and the B^T tile: slab sums with 8 independent 16-byte loads per slab round
+        float g[4][4] = {}, b[4][4] = {};
+        const int nslab = FROM_SLABS ? (gsplit > bsplit ? gsplit : bsplit) : 1;
+        for (int p = 0; p < nslab; ++p) {
+            float4 tg[4], tb[4];
+            const bool pg = p < gsplit, pb = p < bsplit;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + 256 * u;
+                tg[u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)p * kk)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                tb[u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)p * bn + (c0 + (i >> 4)) * KP + 4 * (i & 15))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u][0] += tg[u].x; g[u][1] += tg[u].y; g[u][2] += tg[u].z; g[u][3] += tg[u].w;
+                b[u][0] += tb[u].x; b[u][1] += tb[u].y; b[u][2] += tb[u].z; b[u][3] += tb[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u;
+            *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) =
+                *reinterpret_cast<const float4*>(H + (int64_t)(i >> 4) * np + c0 + 4 * (i & 15));
+            *reinterpret_cast<float4*>(gs + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
+            *reinterpret_cast<float4*>(bt + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
+        }
+    }
     __syncthreads();
-    constexpr int NJ = KP / 4;
-    float acc[NJ];
+    // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows, 4 column tiles
+    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) acc[t] = 0.f;
-    for (int l = 0; l < KP; ++l) {
-        const float hv = hs[l * 64 + c];
-        const float* grow = gs + l * KP + jq * NJ;
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int u = 0; u < KP / 4; ++u) {
+        const float a = gs[(16 * wave + x) * LDG + 4 * u + q];
 #pragma unroll
-        for (int t = 0; t < NJ; t += 4) {
-            const float4 g4 = *reinterpret_cast<const float4*>(grow + t);
-            acc[t] = fmaf(g4.x, hv, acc[t]);
-            acc[t + 1] = fmaf(g4.y, hv, acc[t + 1]);
-            acc[t + 2] = fmaf(g4.z, hv, acc[t + 2]);
-            acc[t + 3] = fmaf(g4.w, hv, acc[t + 3]);
-        }
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA_F32(a, hs[(4 * u + q) * LDC + 16 * ct + x], acc[ct]);
     }
-    const float* brow = xf32 + (c0 + c) * KP + jq * NJ;          // B^T[c][j .. j+15]
-    unsigned ph[NJ / 2], pl[NJ / 2];
+    __syncthreads();                                   // everybody is done with G
+    volatile float* dt = gs;                           // see mur_w_update_bf16_kernel
 #pragma unroll
-    for (int t = 0; t < NJ; t += 2) {
-        float hn[2];
+    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int jrow = jq * NJ + t + u;
-            const float h = hs[jrow * 64 + c];
-            hn[u] = h * brow[t + u] / (acc[t + u] + lam * h + 1e-9f);
-            H[(int64_t)jrow * np + c0 + c] = hn[u];
+        for (int r = 0; r < 4; ++r) dt[(16 * wave + 4 * q + r) * LDG + 16 * ct + x] = acc[ct][r];
+    __syncthreads();
+    {   // epilogue, vectorised along the columns: thread = (factor row jr, 16 consecutive c)
+        const int jr = tid >> 2, cq = 16 * (tid & 3);
+        float hn[16];
+        unsigned ph[8], pl[8];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float h = hs[jr * LDC + cq + e];
+            hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDG + cq + e] + lam * h + 1e-9f);
         }
-        split2(hn[0], hn[1], ph[t / 2], pl[t / 2]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int jrow = jq * NJ + t + u;
-            Hhi[(int64_t)jrow * np + c0 + c] = (unsigned short)(u ? ph[t / 2] >> 16 : ph[t / 2] & 0xffffu);
-            Hlo[(int64_t)jrow * np + c0 + c] = (unsigned short)(u ? pl[t / 2] >> 16 : pl[t / 2] & 0xffffu);
+        for (int e = 0; e < 8; ++e) {
+            split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
+            th[(cq + 2 * e) * (KP + 2) + jr] = (unsigned short)(ph[e] & 0xffffu); th[(cq + 2 * e + 1) * (KP + 2) + jr] = (unsigned short)(ph[e] >> 16);
+            tl[(cq + 2 * e) * (KP + 2) + jr] = (unsigned short)(pl[e] & 0xffffu); tl[(cq + 2 * e + 1) * (KP + 2) + jr] = (unsigned short)(pl[e] >> 16);
         }
+        const int64_t idx = (int64_t)jr * np + c0 + cq;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4)
+            *reinterpret_cast<float4*>(H + idx + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
+        uint4* oh = reinterpret_cast<uint4*>(Hhi + idx);
+        uint4* ol = reinterpret_cast<uint4*>(Hlo + idx);
+        oh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); oh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+        ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
     }
-    uint4* th = reinterpret_cast<uint4*>(HThi + (c0 + c) * KP + jq * NJ);
-    uint4* tl = reinterpret_cast<uint4*>(HTlo + (c0 + c) * KP + jq * NJ);
-    th[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); th[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-    tl[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); tl[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+    __syncthreads();
+    {   // transposed images [np][64]: thread (c = tid/4, quarter = tid%4) stores 16 factors = 32 bytes
+        const int c = tid >> 2, qd = tid & 3;
+        uint4* oh = reinterpret_cast<uint4*>(HThi + (c0 + c) * KP + 16 * qd);
+        uint4* ol = reinterpret_cast<uint4*>(HTlo + (c0 + c) * KP + 16 * qd);
+        oh[0] = pack8(th + c * (KP + 2) + 16 * qd); oh[1] = pack8(th + c * (KP + 2) + 16 * qd + 8);
+        ol[0] = pack8(tl + c * (KP + 2) + 16 * qd); ol[1] = pack8(tl + c * (KP + 2) + 16 * qd + 8);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -612,13 +722,14 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     if ((rc = launch_xyt(E, true, E->V, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                          E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
     { ProfScope ps(E, "w_update");
-      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 16)), dim3(256), 0, E->stream, E->A_part,
+      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
                          E->bf_wsplit, E->mp, Wold, E->HHt_part, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
                          E->WThi, E->WTlo, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
                          nullptr, nullptr, nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
+    if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
     return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->bt_split,
                                  (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
@@ -626,10 +737,26 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,
                              int64_t j) {
     ProfScope ps(E, "h_update");
-    const size_t shm = (size_t)(64 * 64 + 64 * 64) * sizeof(float);
-    hipLaunchKernelGGL(mur_h_update_bf16_kernel, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32,
-                       E->xf64, E->H, E->np, (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2,
-                       E->state, E->obj_hist, E->Hhi, E->Hlo, E->HThi, E->HTlo);
+    const dim3 grid((unsigned)(E->np / 64)), block(256);
+    const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float) + (size_t)2 * 64 * 66 * sizeof(unsigned short);
+    static bool ok = false;
+    if (!ok) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        ok = true;
+    }
+    if (E->fused_pack)
+        hipLaunchKernelGGL((mur_h_update_bf16_kernel<true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
+                           E->G_part, E->bt_split, E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
+                           (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
+                           E->Hhi, E->Hlo, E->HThi, E->HTlo);
+    else
+        hipLaunchKernelGGL((mur_h_update_bf16_kernel<false>), grid, block, shm, E->stream, E->xf32, 1,
+                           E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
+                           (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
+                           E->Hhi, E->Hlo, E->HThi, E->HTlo);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

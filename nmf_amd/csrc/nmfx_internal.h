@@ -66,6 +66,7 @@ struct nmfx_engine {
     // split-bf16 mode (kernels_bf16.hip): V^T and bf16 hi/lo images of the factors
     int precision = 0;             // 0 = f32 MFMA, 1 = split bf16 (k padded to 64 only)
     bool bf_ready = false;
+    bool fused_pack = false;       // nmfx_mur_run (single GPU): no pack launch, h_update reads the slabs
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
     float* Vt = nullptr;           // [np][mp]
     float* Bt_part = nullptr;      // [bt_split][np][kp]
