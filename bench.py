@@ -119,6 +119,11 @@ def cpu_baseline(v, k, iters):
 
 def main():
     args = parse()
+    # the contract is ONE JSON line on stdout: RCCL prints a version banner to stdout when the
+    # communicator comes up, so everything but the final line is sent to stderr at the fd level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,7 +139,12 @@ def main():
     if os.environ.get("NMFX_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = 0            # rehearsal: all ranks share GPU 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # NMFX_BENCH_FORCE_SHARDED=1: take the N > 1 code path (phase A -> all-reduce -> phase B driven
+    # from Python) with a world of one, to measure its host-side cost on a single GPU
+    sharded = world > 1 or bool(os.environ.get("NMFX_BENCH_FORCE_SHARDED"))
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # "nccl" (= RCCL over xGMI) is the real thing; NMFX_BENCH_BACKEND=gloo stages the
         # exchange through the host so that the N > 1 code path can be rehearsed with several
@@ -156,11 +166,11 @@ def main():
     h0 = np.abs(rs.randn(k, n))
 
     NEVER = 10 ** 12          # min_iter: the stop rule is evaluated but cannot fire
-    if world > 1:
+    if sharded:
         shard = nd.DeviceShard(v_local, k, w0, h0, local_rank)
 
-        def run(first, count):
-            nd.run_iterations(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
+        run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5,
+                        args.warmup + args.steps + args.profile_steps + 8)
         eng = shard.eng
     else:
         from nmf_amd.engine import Engine
@@ -176,7 +186,7 @@ def main():
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -186,7 +196,7 @@ def main():
     run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         on_gpu = dist.get_backend() == "nccl"
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,7 +215,7 @@ def main():
     if args.profile_steps > 0 and not args.pmc_child:
         eng.profile_enable(True)
         eng.profile_reset()
-        run(done, args.profile_steps)
+        (run.eager if sharded else run)(done, args.profile_steps)   # per-kernel events need eager launches
         fence()
         for name in ("wphase", "hphase", "gram_tn", "gram_nt", "sum_hht", "w_update", "pack", "h_update", "small"):
             ms, cnt = eng.profile_get(name)
@@ -263,7 +273,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
                                    "|randn| init, objective every iteration",
-                       "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}"},
+                       "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}",
+                       "loop": (run.mode if sharded else "library")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "iteration": {"algorithmic_gflop": iter_flops / 1e9,
@@ -271,8 +282,9 @@ def main():
                           "frac_of_f32_mfma_peak": iter_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS / world},
             "kernels": prof,
         }
-        print(json.dumps(line))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -124,6 +124,15 @@ int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol
  * elements.  The caller may supply its own device allocations (e.g. torch
  * tensors, so that torch.distributed can all-reduce them in place).           */
 int nmfx_exchange_sizes(nmfx_handle_t h, int64_t* n_f32, int64_t* n_f64);
+/* Stream-capture support for the caller-driven loop.  The phase calls only queue launches on the
+ * handle's stream, so a caller may capture  phase_a(j=0) . all-reduce . phase_b(j=0) .
+ * phase_a(j=1) . all-reduce . phase_b(j=1) . nmfx_shift_iteration_base(+2)  into ONE hipGraph
+ * and replay it: the device adds the base to the index each launch carries (objective slot,
+ * `i > min_iter` test of nmf/mur.py:131).  Keep the base even (W ping-pong parity), reserve
+ * the objective history first (it must not move during replays) and shift the base back to 0
+ * before nmfx_mur_finish_* / the run entry points, which take absolute indices. */
+int nmfx_reserve_objectives(nmfx_handle_t h, int64_t count);
+int nmfx_shift_iteration_base(nmfx_handle_t h, int64_t delta);
 int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, void* dev_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
 

@@ -44,6 +44,8 @@ SIGNATURES = {
     "nmfx_mur_finish_a": (_i32, [_vp, _i32, _i64]),
     "nmfx_mur_finish_b": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
     "nmfx_exchange_sizes": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_reserve_objectives": (_i32, [_vp, _i64]),
+    "nmfx_shift_iteration_base": (_i32, [_vp, _i64]),
     "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),
     "nmfx_get_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nmfx_aoadmm_run": (_i32, [_vp, _i32, _i32, _dbl, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64, _i64]),

@@ -29,8 +29,10 @@ __global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t n, f
 
 __global__ void init_state_kernel(DevState* st) {
     st->flag = 0; st->stop_i = -1; st->n_obj = 0; st->obj_prev = 0.0;
-    st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0;
+    st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0; st->j_base = 0;
 }
+
+__global__ void shift_iteration_base_kernel(DevState* st, long long delta) { st->j_base += delta; }
 
 template <typename T>
 static int dev_alloc(nmfx_engine* E, T** p, int64_t count) {
@@ -363,6 +365,21 @@ int nmfx_get_exchange_buffers(nmfx_handle_t E, void** f32, void** f64) {
     if (!E) return NMFX_E_ARG;
     if (f32) *f32 = E->xf32;
     if (f64) *f64 = E->xf64;
+    return NMFX_OK;
+}
+
+// ---- iteration base (hipGraph replay support) --------------------------------
+int nmfx_reserve_objectives(nmfx_handle_t E, int64_t count) {
+    if (!E || count < 0) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    return nmfx_ensure_obj_capacity(E, count + 2);
+}
+
+int nmfx_shift_iteration_base(nmfx_handle_t E, int64_t delta) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    hipLaunchKernelGGL(shift_iteration_base_kernel, dim3(1), dim3(1), 0, E->stream, E->state, (long long)delta);
+    NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 

@@ -436,14 +436,24 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     __shared__ unsigned short th[KP][RB + 2], tl[KP][RB + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * RB;
-    {   // H H^T = sum of the W phase's by-product slabs; 4 independent 16-byte loads per slab round
+    {   // H H^T = sum of the W phase's by-product slabs (fixed order); the loads of four slabs
+        // (16 x 16 bytes per thread) are in flight together -- a short row shard has many slabs
         float v[4][4] = {};
-        for (int p = 0; p < wsplit; ++p) {
-            float4 t[4];
+        for (int p0 = 0; p0 < wsplit; p0 += 4) {
+            float4 t[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const float4*>(HHtpart + (int64_t)p * KP * KP)[tid + 256 * u];
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { v[u][0] += t[u].x; v[u][1] += t[u].y; v[u][2] += t[u].z; v[u][3] += t[u].w; }
+                for (int u = 0; u < 4; ++u)
+                    t[pp][u] = (p0 + pp < wsplit)
+                        ? reinterpret_cast<const float4*>(HHtpart + (int64_t)(p0 + pp) * KP * KP)[tid + 256 * u]
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u][0] += t[pp][u].x; v[u][1] += t[pp][u].y; v[u][2] += t[pp][u].z; v[u][3] += t[pp][u].w;
+                }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -477,12 +487,21 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
         const int row = tid >> 2, j0 = 16 * (tid & 3);
         const int64_t idx = (r0 + row) * KP + j0;
         float a[16] = {}, wn[16];
-        for (int p = 0; p < wsplit; ++p) {
-            float4 t[4];
+        for (int p0 = 0; p0 < wsplit; p0 += 4) {
+            float4 t[4][4];
 #pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) t[v4] = *reinterpret_cast<const float4*>(Apart + (int64_t)p * mp * KP + idx + 4 * v4);
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) { a[4 * v4] += t[v4].x; a[4 * v4 + 1] += t[v4].y; a[4 * v4 + 2] += t[v4].z; a[4 * v4 + 3] += t[v4].w; }
+                for (int v4 = 0; v4 < 4; ++v4)
+                    t[pp][v4] = (p0 + pp < wsplit)
+                        ? *reinterpret_cast<const float4*>(Apart + (int64_t)(p0 + pp) * mp * KP + idx + 4 * v4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    a[4 * v4] += t[pp][v4].x; a[4 * v4 + 1] += t[pp][v4].y; a[4 * v4 + 2] += t[pp][v4].z; a[4 * v4 + 3] += t[pp][v4].w;
+                }
         }
         unsigned ph[8], pl[8];
 #pragma unroll

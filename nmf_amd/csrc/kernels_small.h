@@ -14,6 +14,7 @@ __device__ __forceinline__ int nmfx_record_objective(DevState* st, double* obj_h
                                                      double tol2, bool writer)
 {
     int rule = 0;
+    j += st->j_base;
     if (j >= 1 && (j - 1) > min_iter) {
         const double prev = obj_hist[j - 1];
         if (obj < tol1) rule = 1;

@@ -28,6 +28,9 @@ struct DevState {          // lives in device memory, written by kernels
     int notpd;             // Cholesky hit a non-positive pivot
     int pad1;
     double rho;            // trace(G)/k of the current sub-problem
+    // added to the iteration index a launch carries: lets a captured hipGraph of two outer
+    // iterations (indices 0 and 1 baked into its kernel arguments) be replayed for any pair
+    long long j_base;
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };

@@ -120,6 +120,12 @@ class Engine:
         self._ck(self.lib.nmfx_mur_phase_b(self.h, dist, float(lambda_h), int(min_iter), float(tol1),
                                            float(tol2), int(j)))
 
+    def reserve_objectives(self, count):
+        self._ck(self.lib.nmfx_reserve_objectives(self.h, int(count)))
+
+    def shift_iteration_base(self, delta):
+        self._ck(self.lib.nmfx_shift_iteration_base(self.h, int(delta)))
+
     def mur_finish_a(self, dist, j):
         self._ck(self.lib.nmfx_mur_finish_a(self.h, dist, int(j)))
 

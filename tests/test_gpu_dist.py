@@ -72,3 +72,60 @@ def test_sharded_device_path(world, backend, tmp_path):
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-4)
         np.testing.assert_array_equal(p["h"], h)        # replicated H is bit-identical on all ranks
+
+
+def _graph_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from nmf_amd import dist as nd
+    m, n, k, v, w0, h0 = _case()
+    out = {}
+    # a run that the stop rule ends in the middle of a replayed pair, and one that exhausts max_iter
+    for name, kw in (("stop", dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-5, tol2=2e-1)),
+                     ("full", dict(distance_type="eu", min_iter=99, max_iter=37)),
+                     ("kl", dict(distance_type="kl", min_iter=99, max_iter=21, lambda_w=0.01))):
+        for graph in (False, True):
+            shard = nd.DeviceShard(v, k, w0, h0, 0)
+            comm = nd.TorchComm()
+            runner_modes = []
+            orig = nd.Runner.__call__
+
+            def spy(self, first, count, _o=orig, _m=runner_modes):
+                _o(self, first, count)
+                _m.append(self.mode)
+            nd.Runner.__call__ = spy
+            try:
+                res = nd.mur_sharded(shard, comm, batch=7, graph=graph, **kw)
+            finally:
+                nd.Runner.__call__ = orig
+            tag = f"{name}_{'graph' if graph else 'eager'}"
+            out[tag + "_w"], out[tag + "_h"] = res.w, res.h
+            out[tag + "_i"], out[tag + "_obj"] = res.i, np.asarray(res.obj_history)
+            out[tag + "_mode"] = np.array(runner_modes[-1])
+            shard.close()
+    np.savez(os.path.join(outdir, "graph.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_loop_equals_eager_loop(tmp_path):
+    """hipGraph replays of the sharded iteration (RCCL all-reduce captured inside) give the very
+    same iterates, objective history and stop index as the Python-driven loop."""
+    import torch.multiprocessing as mp
+    mp.spawn(_graph_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    z = np.load(tmp_path / "graph.npz")
+    for name in ("stop", "full", "kl"):
+        assert str(z[f"{name}_graph_mode"]) == "hipgraph" and str(z[f"{name}_eager_mode"]) == "eager"
+        assert int(z[f"{name}_graph_i"]) == int(z[f"{name}_eager_i"])
+        np.testing.assert_array_equal(z[f"{name}_graph_obj"], z[f"{name}_eager_obj"])
+        np.testing.assert_array_equal(z[f"{name}_graph_w"], z[f"{name}_eager_w"])
+        np.testing.assert_array_equal(z[f"{name}_graph_h"], z[f"{name}_eager_h"])
+    assert int(z["stop_graph_i"]) < 399 and int(z["full_graph_i"]) == 36
