@@ -192,6 +192,16 @@ def main():
 
     run(0, args.warmup)
     fence()
+    if sharded and run.mode == "hipgraph" and args.warmup >= 4:
+        # the replayed loop must have produced a sane history; if not, start over with the eager loop
+        _, _, n_obj = eng.state()
+        hist = eng.objectives(0, n_obj)
+        if n_obj != args.warmup or not np.all(np.isfinite(hist)) or not hist[-1] < hist[0]:
+            sys.stderr.write(f"rank {rank}: graphed loop gave a bad objective history, falling back to eager\n")
+            run.graph, run.mode, run.want_graph = None, "eager", False
+            eng.set_factors(w0, h0)
+            run(0, args.warmup)
+            fence()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     fence()
@@ -206,8 +216,7 @@ def main():
     # sanity: objective history is finite and decreasing
     _, _, n_obj = eng.state()
     obj = eng.objectives(0, n_obj)
-    if not os.environ.get("NMFX_DEBUG_SKIP"):     # (kernel timing experiments deliberately break the data)
-        assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], "bench run produced a bad objective"
+    assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], "bench run produced a bad objective"
 
     # profiled pass: per-kernel device time from HIP events on the engine's stream
     roof = None

