@@ -120,7 +120,7 @@ int nmfx_mur_finish_a(nmfx_handle_t h, int distance, int64_t j);
 int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
 
 /* Exchange buffers: f32 part = [W^T V (kp x n_pad) | W^T W (kp x kp)] (+ KL:
- * column sums of W), f64 part = [objective partial, 3 spare].  Sizes in
+ * column sums of W), f64 part = [objective partial, 4 inner-loop norm sums (sharded AO-ADMM), 3 spare].  Sizes in
  * elements.  The caller may supply its own device allocations (e.g. torch
  * tensors, so that torch.distributed can all-reduce them in place).           */
 int nmfx_exchange_sizes(nmfx_handle_t h, int64_t* n_f32, int64_t* n_f64);
@@ -146,6 +146,22 @@ int nmfx_aoadmm_run(nmfx_handle_t h, int distance, int prox_w, double lambda_w,
                     int prox_h, double lambda_h, int admm_iter,
                     int64_t min_iter, double tol1, double tol2,
                     int64_t first, int64_t count);
+/* Row-sharded form (Euclidean loss).  Per outer iteration j the caller runs
+ *   phase_h_products . all-reduce(f32, f64) . phase_h_solve . phase_w_products .
+ *   { phase_w_round(r) . all-reduce(f64) } for r = 0 .. admm_iter-1 . phase_w_close
+ * The H sub-problem (ao_admm.py:263) needs sum_p W_p^T V_p and sum_p W_p^T W_p, after which it
+ * is replicated work; the W sub-problem (ao_admm.py:265) is rank-local except that `terminate`
+ * (ao_admm.py:33-43) takes norms over ALL rows of W: each round leaves this rank's four sums of
+ * squares in the f64 exchange buffer [1..4].  After the last iteration: nmfx_objective_partial .
+ * all-reduce(f64) . nmfx_mur_finish_b.                                                      */
+int nmfx_aoadmm_phase_h_products(nmfx_handle_t h, int64_t j);
+int nmfx_aoadmm_phase_h_solve(nmfx_handle_t h, int prox_h, double lambda_h, int admm_iter,
+                              int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_aoadmm_phase_w_products(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_aoadmm_phase_w_round(nmfx_handle_t h, int prox_w, double lambda_w, int round);
+int nmfx_aoadmm_phase_w_close(nmfx_handle_t h, int admm_iter, int64_t j);
+/* f64 exchange buffer [0] = this rank's objective partial of the current factor pair.        */
+int nmfx_objective_partial(nmfx_handle_t h);
 /* Record the objective / convergence test of the last queued iteration.       */
 int nmfx_aoadmm_finish(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t iters_done);
 /* Per outer iteration two int32: (H sub-problem, W sub-problem); low 16 bits =
@@ -167,6 +183,15 @@ int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double 
 int nmfx_anls_run(nmfx_handle_t h, double lambda_w, double lambda_h,
                   int64_t min_iter, double tol1, double tol2,
                   int64_t first, int64_t count);
+/* Row-sharded form.  Per outer iteration j:
+ *   phase_objective . all-reduce(f64) . phase_w . all-reduce(f32) . phase_h
+ * phase_w records obj[j] / evaluates the stop rule, solves the rank's rows of W (anls.py:18-31)
+ * and leaves [W^T V | W^T W] partials in the exchange buffer; phase_h solves all columns of H
+ * (replicated, anls.py:34-47).  After the last iteration: nmfx_objective_partial .
+ * all-reduce(f64) . nmfx_mur_finish_b.                                                      */
+int nmfx_anls_phase_objective(nmfx_handle_t h, int64_t j);
+int nmfx_anls_phase_w(nmfx_handle_t h, double lambda_w, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_anls_phase_h(nmfx_handle_t h, double lambda_h, int64_t j);
 
 /* ---- measurement -------------------------------------------------------- */
 /* Accumulated device time (HIP events on the handle's stream) and launch count

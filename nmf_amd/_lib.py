@@ -44,6 +44,15 @@ SIGNATURES = {
     "nmfx_mur_finish_a": (_i32, [_vp, _i32, _i64]),
     "nmfx_mur_finish_b": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
     "nmfx_exchange_sizes": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_aoadmm_phase_h_products": (_i32, [_vp, _i64]),
+    "nmfx_aoadmm_phase_h_solve": (_i32, [_vp, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64]),
+    "nmfx_aoadmm_phase_w_products": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
+    "nmfx_aoadmm_phase_w_round": (_i32, [_vp, _i32, _dbl, _i32]),
+    "nmfx_aoadmm_phase_w_close": (_i32, [_vp, _i32, _i64]),
+    "nmfx_objective_partial": (_i32, [_vp]),
+    "nmfx_anls_phase_objective": (_i32, [_vp, _i64]),
+    "nmfx_anls_phase_w": (_i32, [_vp, _dbl, _i64, _dbl, _dbl, _i64]),
+    "nmfx_anls_phase_h": (_i32, [_vp, _dbl, _i64]),
     "nmfx_reserve_objectives": (_i32, [_vp, _i64]),
     "nmfx_shift_iteration_base": (_i32, [_vp, _i64]),
     "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),

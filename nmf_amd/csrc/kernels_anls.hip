@@ -180,28 +180,75 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
     }
 }
 
-static int anls_iteration(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2,
-                          int64_t j) {
+// One outer iteration (anls.py:112-126) in the pieces the row-sharded form needs:
+//   objective of the current pair -> [all-reduce] -> stop rule, W rows (rank-local), products
+//   for H -> [all-reduce] -> H columns (replicated) and the objective partials of the new pair.
+static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     float* W = E->W[0];
     const int64_t kk = (int64_t)E->kp * E->kp;
-    // objective of the current pair (filled by the previous pass) and the stop rule
-    if ((rc = nmfx_launch_obj_reduce(E))) return rc;
-    if ((rc = nmfx_finish_b(E, min_iter, tol1, tol2, j))) return rc;
+    if ((rc = nmfx_finish_b(E, min_iter, tol1, tol2, j))) return rc;      // obj[j] + stop rule
     // ---- W: rows of W from G = H H^T + 2 lam_w I, r = (V H^T)[i, :]  (anls.py:18-31) ----
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
     if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
     if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
     if ((rc = nnls(E, E->HHt, (float)(2.0 * lam_w), E->Asum, W, 1, E->kp, E->m))) return rc;
-    // ---- H: columns of H from G = W^T W + 2 lam_h I, r = (W^T V)[:, c]  (anls.py:34-47) ----
+    // ---- products for H: [W^T V | W^T W] ----
     const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
     if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
-    if ((rc = nmfx_launch_pack(E))) return rc;
+    return nmfx_launch_pack(E);
+}
+
+static int anls_h(nmfx_engine* E, double lam_h) {
+    int rc;
+    // ---- H: columns of H from G = W^T W + 2 lam_h I, r = (W^T V)[:, c]  (anls.py:34-47) ----
     if ((rc = nnls(E, E->xf32 + (int64_t)E->kp * E->np, (float)(2.0 * lam_h), E->xf32, E->H, E->np, 1, E->n))) return rc;
     // ---- objective (anls.py:118) ----
-    return nmfx_launch_wphase(E, W, false, true);
+    return nmfx_launch_wphase(E, E->W[0], false, true);
+}
+
+static int anls_iteration(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2,
+                          int64_t j) {
+    int rc;
+    // objective of the current pair (filled by the previous pass) and the stop rule
+    if ((rc = nmfx_launch_obj_reduce(E))) return rc;
+    if ((rc = anls_w_and_products(E, lam_w, min_iter, tol1, tol2, j))) return rc;
+    return anls_h(E, lam_h);
+}
+
+static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
+    if (!E) return NMFX_E_ARG;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (j < 0 || lam < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    if (!E->Asum) {
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
+        NMFX_HIP(hipMemsetAsync(E->Asum, 0, (size_t)E->mp * E->kp * sizeof(float), E->stream));
+    }
+    E->wsel = 0;
+    E->w_in_place = true;
+    return nmfx_ensure_obj_capacity(E, j + 3);
+}
+
+// ---- row-sharded form: objective partial -> [all-reduce f64] -> phase_w -> [all-reduce f32]
+// -> phase_h ----
+extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
+    int rc = anls_ready(E, j, 0.0); if (rc) return rc;
+    if (j == 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0] partials
+    return nmfx_launch_obj_reduce(E);
+}
+
+extern "C" int nmfx_anls_phase_w(nmfx_handle_t E, double lambda_w, int64_t min_iter, double tol1, double tol2,
+                                 int64_t j) {
+    int rc = anls_ready(E, j, lambda_w); if (rc) return rc;
+    return anls_w_and_products(E, lambda_w, min_iter, tol1, tol2, j);
+}
+
+extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
+    int rc = anls_ready(E, j, lambda_h); if (rc) return rc;
+    return anls_h(E, lambda_h);
 }
 
 extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, int64_t min_iter, double tol1,

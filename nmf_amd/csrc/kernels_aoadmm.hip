@@ -279,15 +279,19 @@ template <int KP>
 __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
     const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U,
     const float* __restrict__ Minv, float* __restrict__ AUX, int mode, int prox, float lam, int round,
-    DevState* __restrict__ st, double* __restrict__ nrm)
+    DevState* __restrict__ st, double* __restrict__ nrm, const double* __restrict__ nrm_global)
 {
+    // nrm: [2][nblk][4] partials of this launch's blocks.  The previous round's norms are their
+    // sum, or -- row-sharded runs, where the rows of other ranks count too (ao_admm.py:33-43
+    // takes norms of the whole factor) -- the all-reduced sums in nrm_global[4].
     if (st->flag || st->inner_stop) return;
     constexpr int JT = KP / 16;
     constexpr int LDM = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];    // [KP][LDM] + 16 doubles
     double* sh = reinterpret_cast<double*>(lds + KP * LDM);
     const int nblk = gridDim.x;
-    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+    if (round > 0 && (nrm_global ? inner_round_fired(nrm_global, 1, sh)
+                                 : inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh))) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
         return;
     }
@@ -351,15 +355,33 @@ __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
 // After the last round: record (rounds run | fired << 16) for this sub-problem.
 __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
     DevState* __restrict__ st, const double* __restrict__ nrm, int nblk, int admm_iter,
-    int32_t* __restrict__ slot)
+    int32_t* __restrict__ slot, const double* __restrict__ nrm_global)
 {
     if (st->flag) return;
     __shared__ double sh[16];
     int fired = st->inner_stop;
     const int count = st->inner_count;
     if (!fired && count == admm_iter && admm_iter > 0)
-        fired = inner_round_fired(nrm + (int64_t)((admm_iter - 1) & 1) * nblk * 4, nblk, sh) ? 1 : 0;
+        fired = (nrm_global ? inner_round_fired(nrm_global, 1, sh)
+                            : inner_round_fired(nrm + (int64_t)((admm_iter - 1) & 1) * nblk * 4, nblk, sh)) ? 1 : 0;
     if (threadIdx.x == 0) { *slot = count | (fired << 16); st->inner_stop = 0; }
+}
+
+// Row-sharded runs: this rank's four norm sums of round `round` -> out[0..3] (fixed order), to be
+// all-reduced by the caller before the next round looks at them.
+__global__ __launch_bounds__(256) void ao_norm_gather_kernel(
+    const DevState* __restrict__ st, const double* __restrict__ nrm, int nblk, int round, double* __restrict__ out)
+{
+    if (st->flag) return;
+    const double* part = nrm + (int64_t)(round & 1) * nblk * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    // rounds that did not run (inner stop already set) leave stale partials: contribute their
+    // value anyway, every rank skips the same rounds and nobody reads the sums afterwards
+    for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * 4 + wave];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[wave] = s;
 }
 
 // ---- host sequencing -----------------------------------------------------
@@ -423,14 +445,14 @@ static int launch_inner_cols(nmfx_engine* E, const float* M, float* aux, int mod
 
 template <int KP>
 static int launch_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode,
-                             int prox, float lam, int round) {
+                             int prox, float lam, int round, const double* nrm_global) {
     const size_t shm = (size_t)KP * (KP + 4) * sizeof(float) + 16 * sizeof(double);
     auto kern = ao_inner_rows_kernel<KP>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, Asum, W, E->dualW,
-                       M, aux, mode, prox, lam, round, E->state, E->nrm_part);
+                       M, aux, mode, prox, lam, round, E->state, E->nrm_part, nrm_global);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -445,12 +467,12 @@ int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int pr
 }
 
 int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
-                    float lam, int round) {
+                    float lam, int round, const double* nrm_global) {
     switch (E->kp) {
-        case 16: return launch_inner_rows<16>(E, Asum, W, M, aux, mode, prox, lam, round);
-        case 32: return launch_inner_rows<32>(E, Asum, W, M, aux, mode, prox, lam, round);
-        case 64: return launch_inner_rows<64>(E, Asum, W, M, aux, mode, prox, lam, round);
-        default: return launch_inner_rows<128>(E, Asum, W, M, aux, mode, prox, lam, round);
+        case 16: return launch_inner_rows<16>(E, Asum, W, M, aux, mode, prox, lam, round, nrm_global);
+        case 32: return launch_inner_rows<32>(E, Asum, W, M, aux, mode, prox, lam, round, nrm_global);
+        case 64: return launch_inner_rows<64>(E, Asum, W, M, aux, mode, prox, lam, round, nrm_global);
+        default: return launch_inner_rows<128>(E, Asum, W, M, aux, mode, prox, lam, round, nrm_global);
     }
 }
 
@@ -458,39 +480,58 @@ static int inner_cols(nmfx_engine* E, int prox, float lam, int round) {
     return nmfx_inner_cols(E, E->Minv, nullptr, 0, prox, lam, round);
 }
 
-static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round) {
-    return nmfx_inner_rows(E, E->auxW, W, E->Minv, nullptr, 0, prox, lam, round);
+static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round, const double* nrm_global = nullptr) {
+    return nmfx_inner_rows(E, E->auxW, W, E->Minv, nullptr, 0, prox, lam, round, nrm_global);
 }
 
-int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot) {
+int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global) {
     hipLaunchKernelGGL(ao_inner_finish_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part, nblk,
-                       admm_iter, slot);
+                       admm_iter, slot, nrm_global);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
-// One outer iteration of ao_admm.py:259-292 (Euclidean loss).
+// One outer iteration of ao_admm.py:259-292 (Euclidean loss), in the pieces the row-sharded
+// form needs (nmfx_aoadmm_phase_*): between h_products and h_solve the caller all-reduces
+// [W^T V | W^T W | objective]; between the rounds of the W sub-problem, the four norm sums.
+static int ao_h_products(nmfx_engine* E) {
+    int rc;
+    float* W = E->W[0];
+    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
+    return nmfx_launch_pack(E);                                      // xf32 = [W^T V | W^T W], xf64 = obj[j]
+}
+
+static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, int64_t min_iter, double tol1,
+                      double tol2, int64_t j) {
+    int rc;
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+    ProfScope ps(E, "inner_h");
+    for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
+    return nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2);
+}
+
+static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2) {
+    int rc;
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_wphase(E, E->W[0], true, false))) return rc;
+    { ProfScope ps(E, "sums");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+      if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->auxW))) return rc; }
+    return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);
+}
+
 static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
                                int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     float* W = E->W[0];
-    const int64_t kk = (int64_t)E->kp * E->kp;
     // ---- H sub-problem: admm_ls_update(v, w, h, dual_h) ----
-    const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
-    if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
-    if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
-    if ((rc = nmfx_launch_pack(E))) return rc;                       // xf32 = [W^T V | W^T W], xf64 = obj[j]
-    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
-    { ProfScope ps(E, "inner_h");
-      for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
-      if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc; }
+    if ((rc = ao_h_products(E))) return rc;
+    if ((rc = ao_h_solve(E, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j))) return rc;
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
-    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
-    if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
-    { ProfScope ps(E, "sums");
-      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
-      if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->auxW))) return rc; }
-    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
+    if ((rc = ao_w_products(E, j, min_iter, tol1, tol2))) return rc;
     { ProfScope ps(E, "inner_w");
       for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
       if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
@@ -498,9 +539,6 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     return nmfx_launch_wphase(E, W, false, true);
 }
 
-// One outer iteration of ao_admm.py:272-285 (KL loss, admm_kl_update :71-101).  The
-// m x n state is S = v_aux + dual_v and dual_v; every inner round costs one W^T S (or
-// S H^T) pass plus the fused v_aux / dual_v update.
 static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
                                int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
@@ -563,6 +601,68 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
         if (rc) return rc;
     }
     return NMFX_OK;
+}
+
+// ---- row-sharded form (Euclidean loss) -----------------------------------------
+static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = nmfx_aoadmm_alloc(E))) return rc;
+    if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;
+    if ((rc = nmfx_ensure_obj_capacity(E, j + 3))) return rc;
+    E->wsel = 0;
+    E->w_in_place = true;
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_aoadmm_phase_h_products(nmfx_handle_t E, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    if (j == 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0] partials (ao_admm.py:256)
+    return ao_h_products(E);
+}
+
+extern "C" int nmfx_aoadmm_phase_h_solve(nmfx_handle_t E, int prox_h, double lambda_h, int admm_iter,
+                                         int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    if (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    return ao_h_solve(E, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
+}
+
+extern "C" int nmfx_aoadmm_phase_w_products(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    return ao_w_products(E, j, min_iter, tol1, tol2);
+}
+
+// One inner round of the W sub-problem on this rank's rows; leaves this rank's norm sums of
+// the round in the f64 exchange buffer [1..4] for the caller to all-reduce.
+extern "C" int nmfx_aoadmm_phase_w_round(nmfx_handle_t E, int prox_w, double lambda_w, int round) {
+    int rc = ao_sharded_ready(E, 0); if (rc) return rc;
+    if (prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if ((rc = inner_rows(E, E->W[0], prox_w, (float)lambda_w, round, round > 0 ? E->xf64 + 1 : nullptr))) return rc;
+    hipLaunchKernelGGL(ao_norm_gather_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part,
+                       (int)(E->mp / 64), round, E->xf64 + 1);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// After the last round's all-reduce: inner-iteration bookkeeping and the objective partials of
+// the new pair (summed into the exchange buffer by the next nmfx_aoadmm_phase_h_products or by
+// nmfx_objective_partial).
+extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
+    return nmfx_launch_wphase(E, E->W[0], false, true);
+}
+
+// f64 exchange buffer [0] = this rank's objective partial of the current pair.
+extern "C" int nmfx_objective_partial(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    return nmfx_launch_obj_reduce(E);
 }
 
 // bookkeeping of the last iteration's objective (obj_part is already filled)

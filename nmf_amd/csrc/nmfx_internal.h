@@ -54,7 +54,7 @@ struct nmfx_engine {
     float* B_part = nullptr;       // [hsplit][kp][np]
     double* obj_part = nullptr;    // [max blocks]
     float* xf32 = nullptr;         // exchange: [kp*np | kp*kp | kp]
-    double* xf64 = nullptr;        // exchange: [4]
+    double* xf64 = nullptr;        // exchange: [8] = objective partial, 4 inner-loop norm sums, 3 spare
     bool own_x = true;
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
@@ -131,8 +131,8 @@ int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_
                         double tol1, double tol2, double fixed_rho);
 int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int prox, float lam, int round);
 int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
-                    float lam, int round);
-int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot);
+                    float lam, int round, const double* nrm_global = nullptr);
+int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
 
 // Run a few launches on the side stream, concurrently with what follows on the main one:
 //   SideScope s(E);  ...launches (they see E->stream == side)...  s.back_to_main();

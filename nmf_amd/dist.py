@@ -103,6 +103,34 @@ class DeviceShard:
     def finish_b(self, min_iter, tol1, tol2, j):
         self.eng.mur_finish_b(min_iter, tol1, tol2, j)
 
+    # AO-ADMM / ANLS phases: straight delegation to the engine
+    def ao_h_products(self, j):
+        self.eng.aoadmm_phase_h_products(j)
+
+    def ao_h_solve(self, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j):
+        self.eng.aoadmm_phase_h_solve(prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j)
+
+    def ao_w_products(self, min_iter, tol1, tol2, j):
+        self.eng.aoadmm_phase_w_products(min_iter, tol1, tol2, j)
+
+    def ao_w_round(self, prox_w, lam_w, rnd):
+        self.eng.aoadmm_phase_w_round(prox_w, lam_w, rnd)
+
+    def ao_w_close(self, admm_iter, j):
+        self.eng.aoadmm_phase_w_close(admm_iter, j)
+
+    def objective_partial(self):
+        self.eng.objective_partial()
+
+    def anls_objective(self, j):
+        self.eng.anls_phase_objective(j)
+
+    def anls_w(self, lam_w, min_iter, tol1, tol2, j):
+        self.eng.anls_phase_w(lam_w, min_iter, tol1, tol2, j)
+
+    def anls_h(self, lam_h, j):
+        self.eng.anls_phase_h(lam_h, j)
+
     def state(self):
         return self.eng.state()
 
@@ -264,3 +292,98 @@ def mur_sharded(shard, comm, *, distance_type='eu', min_iter=100, max_iter=10000
         logging.warning('Converged.')
         return Results(w, h, stop_i, history[:stop_i + 2], experiment)
     return Results(w, h, max_iter - 1, history, experiment)
+
+
+def _sharded_loop(shard, comm, queue, finish_run, *, max_iter, tol1, tol2, batch, experiment):
+    """The reference's outer loop shape (obj_history, `[i]: objective` lines, stop bookkeeping)
+    around `queue(first, count)`, which only queues device work and collectives."""
+    if max_iter <= 0:
+        raise UnboundLocalError("local variable 'i' referenced before assignment")
+    digits = utils.tol_digits(tol1, tol2)
+    history, done, rule, stop_i = [], 0, 0, -1
+    while done < max_iter and not rule:
+        count = min(batch, max_iter - done)
+        queue(done, count)
+        done += count
+        if done == max_iter:
+            finish_run(done)
+        rule, stop_i, n_obj = shard.state()
+        for val in shard.objectives(len(history), n_obj - len(history)):
+            history.append(np.float64(val))
+            if len(history) >= 2 and comm.rank == 0:
+                utils.say('[{}]: {:.{}f}'.format(len(history) - 2, val, digits))
+    w, h = shard.get_factors()
+    if rule:
+        if comm.rank == 0:
+            utils.convergence_message(rule)
+        logging.warning('Converged.')
+        return Results(w, h, stop_i, history[:stop_i + 2], experiment)
+    return Results(w, h, max_iter - 1, history, experiment)
+
+
+def _prox_code(kind):
+    from . import _lib as L
+    if kind in ('nn', 'l1n'):
+        return L.PROX[kind]
+    if kind in ('l2n', 'l1inf', 'l1inf_transpose'):
+        raise NotImplementedError(f"prox '{kind}' is not available in the row-sharded AO-ADMM")
+    raise TypeError('Unknown prox_type.')                       # nmf/ao_admm.py:198
+
+
+def aoadmm_sharded(shard, comm, *, reg_w=(0, 'nn'), reg_h=(0, 'nn'), min_iter=10, max_iter=100000,
+                   admm_iter=10, tol1=1e-3, tol2=1e-3, batch=4, experiment=None):
+    """AO-ADMM, Euclidean loss (nmf/ao_admm.py:259-301), over a row-sharded V.
+
+    H sub-problem (ao_admm.py:263): [W^T V | W^T W | objective] is all-reduced once, the Cholesky
+    solve / prox / dual rounds are then replicated work.  W sub-problem (ao_admm.py:265): rank-local
+    rows, except that `terminate` (ao_admm.py:33-43) takes norms over the whole factor: the four
+    sums of squares of every round are all-reduced (32 bytes), so all ranks stop at the same
+    round, as the reference would.  Returns Results with THIS rank's rows of w."""
+    prox_h, prox_w = _prox_code(reg_h[1]), _prox_code(reg_w[1])     # H's regulariser is met first
+    x32, x64 = shard.buffers()
+    norms = x64[1:5]
+
+    def queue(first, count):
+        for j in range(first, first + count):
+            shard.ao_h_products(j)
+            comm.all_reduce(x32, x64)
+            shard.ao_h_solve(prox_h, reg_h[0], admm_iter, min_iter, tol1, tol2, j)
+            shard.ao_w_products(min_iter, tol1, tol2, j)
+            for rnd in range(admm_iter):
+                shard.ao_w_round(prox_w, reg_w[0], rnd)
+                comm.all_reduce(norms)
+            shard.ao_w_close(admm_iter, j)
+
+    def finish_run(done):
+        shard.objective_partial()
+        comm.all_reduce(x64)
+        shard.finish_b(min_iter, tol1, tol2, done)
+
+    return _sharded_loop(shard, comm, queue, finish_run, max_iter=max_iter, tol1=tol1, tol2=tol2,
+                         batch=batch, experiment=experiment)
+
+
+def anls_sharded(shard, comm, *, lambda_w=0, lambda_h=0, min_iter=10, max_iter=1000, tol1=1e-3, tol2=1e-3,
+                 batch=4, experiment=None):
+    """ANLS (nmf/anls.py:112-126) over a row-sharded V: the rows of W are independent NNLS
+    problems (anls.py:18-31, rank-local), the columns of H need sum_p W_p^T W_p and
+    sum_p W_p^T V_p (anls.py:34-47; replicated solve after one all-reduce).  The objective
+    partial is all-reduced separately because the stop rule is evaluated BEFORE the updates of
+    the iteration are queued.  Returns Results with THIS rank's rows of w."""
+    x32, x64 = shard.buffers()
+
+    def queue(first, count):
+        for j in range(first, first + count):
+            shard.anls_objective(j)
+            comm.all_reduce(x64)
+            shard.anls_w(lambda_w, min_iter, tol1, tol2, j)
+            comm.all_reduce(x32)
+            shard.anls_h(lambda_h, j)
+
+    def finish_run(done):
+        shard.objective_partial()
+        comm.all_reduce(x64)
+        shard.finish_b(min_iter, tol1, tol2, done)
+
+    return _sharded_loop(shard, comm, queue, finish_run, max_iter=max_iter, tol1=tol1, tol2=tol2,
+                         batch=batch, experiment=experiment)

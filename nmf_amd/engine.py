@@ -120,6 +120,35 @@ class Engine:
         self._ck(self.lib.nmfx_mur_phase_b(self.h, dist, float(lambda_h), int(min_iter), float(tol1),
                                            float(tol2), int(j)))
 
+    # -- row-sharded AO-ADMM / ANLS phases (include/nmfx.h) --------------------
+    def aoadmm_phase_h_products(self, j):
+        self._ck(self.lib.nmfx_aoadmm_phase_h_products(self.h, int(j)))
+
+    def aoadmm_phase_h_solve(self, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_aoadmm_phase_h_solve(self.h, prox_h, float(lam_h), int(admm_iter), int(min_iter),
+                                                    float(tol1), float(tol2), int(j)))
+
+    def aoadmm_phase_w_products(self, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_aoadmm_phase_w_products(self.h, int(min_iter), float(tol1), float(tol2), int(j)))
+
+    def aoadmm_phase_w_round(self, prox_w, lam_w, rnd):
+        self._ck(self.lib.nmfx_aoadmm_phase_w_round(self.h, prox_w, float(lam_w), int(rnd)))
+
+    def aoadmm_phase_w_close(self, admm_iter, j):
+        self._ck(self.lib.nmfx_aoadmm_phase_w_close(self.h, int(admm_iter), int(j)))
+
+    def objective_partial(self):
+        self._ck(self.lib.nmfx_objective_partial(self.h))
+
+    def anls_phase_objective(self, j):
+        self._ck(self.lib.nmfx_anls_phase_objective(self.h, int(j)))
+
+    def anls_phase_w(self, lam_w, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_anls_phase_w(self.h, float(lam_w), int(min_iter), float(tol1), float(tol2), int(j)))
+
+    def anls_phase_h(self, lam_h, j):
+        self._ck(self.lib.nmfx_anls_phase_h(self.h, float(lam_h), int(j)))
+
     def reserve_objectives(self, count):
         self._ck(self.lib.nmfx_reserve_objectives(self.h, int(count)))
 

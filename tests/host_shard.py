@@ -17,7 +17,7 @@ class HostShard:
         self.k = k
         n = self.v.shape[1]
         self.x32 = torch.zeros(k * n + k * k + k, dtype=torch.float64)   # f64 here: compare tightly
-        self.x64 = torch.zeros(4, dtype=torch.float64)
+        self.x64 = torch.zeros(8, dtype=torch.float64)
         self.obj = []
         self.flag, self.stop_i = 0, -1
         self.w_new = None
@@ -84,6 +84,122 @@ class HostShard:
     def finish_b(self, min_iter, tol1, tol2, j):
         if not self.flag:
             self._record(min_iter, tol1, tol2, j)
+
+    # ---- AO-ADMM, Euclidean loss (nmf/ao_admm.py:46-68, 259-292) in the sharded protocol ----
+    def _ao_init(self):
+        if not hasattr(self, "dual_w"):
+            self.dual_w = np.zeros_like(self.w)
+            self.dual_h = np.zeros_like(self.h)
+            self.inner = {}
+
+    def ao_h_products(self, j):
+        self._ao_init()
+        if self.flag:
+            return
+        k, n = self.k, self.v.shape[1]
+        self.x64.zero_()
+        self.x64[0] = self._local_objective(0)
+        x = self.x32.numpy()
+        x[:] = 0
+        x[:k * n] = (self.w.T @ self.v).ravel()
+        x[k * n:k * n + k * k] = (self.w.T @ self.w).ravel()
+
+    @staticmethod
+    def _prox(kind, aux, dual, rho, lam):
+        d = aux - dual - (lam / rho if kind == 1 else 0.0)
+        return np.where(d < 0, 0, d)
+
+    def ao_h_solve(self, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j):
+        import scipy.linalg as sla
+        if self.flag or self._record(min_iter, tol1, tol2, j):
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        b = x[:k * n].reshape(k, n).copy()
+        g = x[k * n:k * n + k * k].reshape(k, k).copy()
+        rho = np.trace(g) / k
+        chol = sla.cholesky(g + rho * np.eye(k), lower=True)
+        ran = 0
+        for r in range(admm_iter):
+            aux = sla.cho_solve((chol, True), b + rho * (self.h + self.dual_h))
+            prev = self.h
+            self.h = self._prox(prox_h, aux, self.dual_h, rho, lam_h)
+            self.dual_h = self.dual_h + self.h - aux
+            ran = r + 1
+            if R.inner_stop(self.h, prev, aux, self.dual_h):
+                break
+        self.inner[(j, 0)] = ran
+
+    def ao_w_products(self, min_iter, tol1, tol2, j):
+        import scipy.linalg as sla
+        if self.flag:
+            return
+        g = self.h @ self.h.T
+        self._rho_w = np.trace(g) / self.k
+        self._chol_w = sla.cholesky(g + self._rho_w * np.eye(self.k), lower=True)
+        self._b_w = self.h @ self.v.T                       # k x m_local
+        self._w_stop, self._w_ran = False, 0
+
+    def ao_w_round(self, prox_w, lam_w, rnd):
+        import scipy.linalg as sla
+        if self.flag:
+            return
+        if rnd > 0 and not self._w_stop:                    # all-reduced sums of the previous round
+            n0, n1, n2, n3 = (float(t) for t in self.x64[1:5])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = np.sqrt(n0) / np.sqrt(n1)
+                s = np.sqrt(n2) / np.sqrt(n3)
+            self._w_stop = bool(r < 1e-2 and s < 1e-2)
+        if self._w_stop:
+            return
+        wt, dt = self.w.T, self.dual_w.T
+        aux = sla.cho_solve((self._chol_w, True), self._b_w + self._rho_w * (wt + dt))
+        new = self._prox(prox_w, aux, dt, self._rho_w, lam_w)
+        dual = dt + new - aux
+        self.x64[1] = np.sum((new - aux) ** 2)
+        self.x64[2] = np.sum(new ** 2)
+        self.x64[3] = np.sum((new - wt) ** 2)
+        self.x64[4] = np.sum(dual ** 2)
+        self.w, self.dual_w = new.T.copy(), dual.T.copy()
+        self._w_ran = rnd + 1
+
+    def ao_w_close(self, admm_iter, j):
+        if not self.flag:
+            self.inner[(j, 1)] = self._w_ran
+
+    def objective_partial(self):
+        if not self.flag:
+            self.x64[0] = self._local_objective(0)
+
+    # ---- ANLS (nmf/anls.py:18-47, 112-126) in the sharded protocol ----
+    def anls_objective(self, j):
+        if not self.flag:
+            self.x64.zero_()
+            self.x64[0] = self._local_objective(0)
+
+    def anls_w(self, lam_w, min_iter, tol1, tol2, j):
+        if self.flag or self._record(min_iter, tol1, tol2, j):
+            return
+        k, n = self.k, self.v.shape[1]
+        self.w = R.anls_w_step(self.v, self.h, lam_w)
+        x = self.x32.numpy()
+        x[:] = 0
+        x[:k * n] = (self.w.T @ self.v).ravel()
+        x[k * n:k * n + k * k] = (self.w.T @ self.w).ravel()
+
+    def anls_h(self, lam_h, j):
+        if self.flag:
+            return
+        # the stacked problem of anls.py:34-47 from its normal equations (what the device solves):
+        # min ||[W; sqrt(2 lam) I] h - [v; 0]||  <=>  G = W^T W + 2 lam I, r = W^T v
+        import scipy.optimize as so
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        b = x[:k * n].reshape(k, n)
+        g = x[k * n:k * n + k * k].reshape(k, k) + 2 * lam_h * np.eye(k)
+        chol = np.linalg.cholesky(g)                        # g = chol chol^T: NNLS on (chol^T, chol^-1 r)
+        rhs = np.linalg.solve(chol, b)
+        self.h = np.stack([so.nnls(chol.T, rhs[:, c])[0] for c in range(n)], axis=1)
 
     def state(self):
         return self.flag, self.stop_i, len(self.obj)

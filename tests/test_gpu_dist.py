@@ -129,3 +129,63 @@ def test_graphed_loop_equals_eager_loop(tmp_path):
         np.testing.assert_array_equal(z[f"{name}_graph_w"], z[f"{name}_eager_w"])
         np.testing.assert_array_equal(z[f"{name}_graph_h"], z[f"{name}_eager_h"])
     assert int(z["stop_graph_i"]) < 399 and int(z["full_graph_i"]) == 36
+
+
+# ---- AO-ADMM and ANLS over row shards (device engine) ------------------------
+def _solver_case(solver):
+    from oracle import nmf_ref as R
+    if solver == "ao_admm":
+        m, n, k = 520, 300, 12
+        kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=8, max_iter=8, admm_iter=10)
+    else:
+        m, n, k = 200, 150, 6
+        kw = dict(lambda_w=0.1, lambda_h=0.05, min_iter=3, max_iter=12, tol1=1e-3, tol2=1e-3)
+    v = R.planted_matrix(m, n, k, seed=31, dtype=np.float32)
+    w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+    return m, n, k, v, w0, h0, kw
+
+
+def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from nmf_amd import dist as nd
+    m, n, k, v, w0, h0, kw = _solver_case(solver)
+    r0, r1 = nd.row_range(m, rank, world)
+    shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
+    comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
+    res = (nd.aoadmm_sharded if solver == "ao_admm" else nd.anls_sharded)(shard, comm, batch=3, **kw)
+    inner = (shard.eng.inner_counts(0, res.i + 1) & 0xFFFF) if solver == "ao_admm" else np.zeros(0)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
+             inner=inner)
+    shard.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solver", ["ao_admm", "anls"])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import nmf_ref as R
+    mp.spawn(_solver_gpu_worker, args=(world, _free_port(), backend, solver, str(tmp_path)), nprocs=world, join=True)
+    m, n, k, v, w0, h0, kw = _solver_case(solver)
+    ref = (R.ao_admm if solver == "ao_admm" else R.anls)(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    w = np.concatenate([p["w"] for p in parts])
+    h = parts[0]["h"]
+    err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
+    assert err < 1e-4, err
+    for p in parts:
+        assert int(p["i"]) == ref.i
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-4)
+        np.testing.assert_array_equal(p["h"], h)
+        if solver == "ao_admm":
+            assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
