@@ -71,35 +71,50 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& 
 // ---------------------------------------------------------------------------
 // A_part[sp] = X(rows of the block, columns of split sp) * Y^T, optional residual
 // objective 0.5 * sum (X - Z Y)^2.  Block = 128 rows (8 waves x 16 rows, two waves per
-// SIMD), 64-column groups.  LDS (all of the 160 KiB with the objective):
-//   Y side, double buffered: Yhi, Ylo (and YThi, YTlo) tiles, each 64 rows x 128 B of bf16,
-//     16-byte chunk c of row r at position c ^ ((r >> 1) & 7);  L2-resident source.
-//   V side, a 3-deep ring per wave: [16][64] f32, chunk c of row r at position c ^ r;
-//     this is the HBM stream, requested two groups ahead.  X is either row-major (ldx) or
-//     tile-major ([128 rows][64 cols] tiles, one contiguous 32 KiB read per block and group:
-//     the H phase, which is HBM-latency bound, gains 20% from the DRAM page locality).
+// SIMD), 64-column groups.  LDS (all of the 160 KiB):
+//   Y side, double buffered: ONE image of the Y tile per group -- Yhi and Ylo, each 64 rows
+//     (factors) x 128 B of bf16; 16-byte chunk c of row r sits at position c ^ yswz(r).  The
+//     A-product takes its B operand from it by rows (ds_read_b128), the residual product takes
+//     its A operand from the SAME image by columns (ds_read_b64_tr_b16, the gfx950 transposing
+//     read): yswz is conflict free for both (searched exhaustively over XOR-linear maps against
+//     the lane groups of MI355X_MICROARCH.md, LDS table).  A second, transposed copy of the tile
+//     would double the L2 -> LDS traffic, which is what bounds the W phase.
+//   V side, a 4-deep ring per wave: [16][64] f32, chunk c of row r at position c ^ r;
+//     this is the HBM stream, requested three groups ahead (96 KiB in flight per CU: the stream
+//     rate follows the bytes in flight until HBM saturates).  X is either row-major (ldx) or
+//     tile-major ([128 rows][64 cols] tiles, one contiguous 32 KiB read per block and group).
 // Everything is filled by LDS-DMA and retired with a COUNTED s_waitcnt vmcnt.  The DMA work
 // is split by wave (4 "Y loaders", 4 "V loaders" that each fetch the tiles of two waves) so
 // that the deep V prefetch is not drained by the shallow Y prefetch.  One barrier per group
-// publishes Y(grp) / V(grp) and frees the buffers read one group earlier.  All LDS reads are (loop-invariant lane offset)
-// + immediate and conflict free.
+// publishes Y(grp) / V(grp) and frees the buffers read one group earlier.  All LDS reads are
+// (loop-invariant lane offset) + immediate and conflict free.
 // ---------------------------------------------------------------------------
 #pragma clang fp contract(fast)
+__device__ __forceinline__ int yswz(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane 4q+p supplies the address of 4
+// consecutive bf16 of row q; lane i receives element i of the 16-wide rows 0..3.
+__device__ __forceinline__ uint2 lds_read_tr(const unsigned char* p) {
+    union { s16x4 s; uint2 u; } r;
+    r.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(const __attribute__((address_space(3))) void*)p);
+    return r.u;
+}
+
 template <bool WITH_OBJ>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
-    const unsigned short* __restrict__ YThi, const unsigned short* __restrict__ YTlo,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
     int ngroups, const int* __restrict__ flag, int tiled)
 {
     if (*flag) return;
     constexpr int KP = 64;
-    constexpr int NT = WITH_OBJ ? 4 : 2;              // bf16 tiles per Y buffer
-    constexpr int YBUF = NT * 8192;                   // bytes
+    constexpr int YBUF = 2 * 8192;                    // bytes: Yhi tile, Ylo tile
     constexpr int VOFF = 2 * YBUF;                    // start of the V rings
-    constexpr int VRING = WITH_OBJ ? 3 : 4;           // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
+    constexpr int VRING = 4;                          // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a PROVABLY uniform value: everything derived from it (DMA bases, LDS
@@ -114,21 +129,18 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     // ---- DMA plan: roles by wave, so that every wave's vmcnt queue is homogeneous ----
     // (vmcnt retires in order: a shallow Y request behind deep V requests would force
     // the V requests to complete too.)
-    //   waves 4..7 ("Y loaders"): all NT*8 pieces of the Y tiles of group grp+1
+    //   waves 4..7 ("Y loaders"): four of the 16 pieces (8 rows x 128 B) of the Y tiles of group grp+1
     //   waves 0..3 ("V loaders"): the V tiles of TWO waves each (w and w+4), VRING-1 groups ahead
     const bool yrole = wave >= 4;
     const int lw = wave & 3;
-    constexpr int YPW = NT * 8 / 4;                   // Y pieces per loader wave per group (8 / 4)
-    const int pidx0 = lw * YPW, ytile = pidx0 >> 3, p0 = pidx0 & 7;
-    const unsigned short* ysrc = ytile == 0 ? Yhi : ytile == 1 ? Ylo : ytile == 2 ? YThi : YTlo;
-    const unsigned long long ystep = ytile < 2 ? 64ull * 2ull : 64ull * KP * 2ull;     // bytes per group
-    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * ystep;
-    unsigned yoffs[YPW];
+    const int ytile = lw >> 1, p0 = 4 * (lw & 1);
+    const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
+    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * 128ull;
+    unsigned yoffs[4];
 #pragma unroll
-    for (int i = 0; i < YPW; ++i) {
-        const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ ((row >> 1) & 7);
-        yoffs[i] = ytile < 2 ? (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2)
-                             : (unsigned)(((int64_t)row * KP + 8 * chunk) * 2);
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ yswz(row);
+        yoffs[i] = (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2);
     }
     const unsigned ydst = (unsigned)(ytile * 8192 + p0 * 1024);
     // V: rows 4t + g of a wave's 16, position x holds chunk x ^ row
@@ -154,8 +166,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     int yq = 0, vq = 0;                               // next Y buffer / V ring slot to fill
     auto issue_y = [&]() {                            // Y loaders only
         dma_run4(ybase, smem0 + yq * YBUF + ydst, yoffs[0], yoffs[1], yoffs[2], yoffs[3]);
-        if (YPW == 8) dma_run4(ybase, smem0 + yq * YBUF + ydst + 4096, yoffs[YPW - 4], yoffs[YPW - 3], yoffs[YPW - 2], yoffs[YPW - 1]);
-        ybase += ystep; yq ^= 1;
+        ybase += 128ull; yq ^= 1;
     };
     auto issue_v = [&]() {                            // V loaders only
         dma_run4(vbaseA, vdstA + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
@@ -164,15 +175,22 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     };
 
     // ---- loop-invariant LDS read offsets ----
-    int ylane[2], vaoff[2][2], vroff[4];
+    int ylane[2], vaoff[2][2], vroff[4], tro[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ ((x >> 1) & 7));     // + 2048 * (row block) + 8192 * tile
+        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz(x));           // + 2048 * (row block) + 8192 * tile
 #pragma unroll
         for (int h = 0; h < 2; ++h) vaoff[s][h] = x * 256 + 16 * ((8 * s + 2 * g + h) ^ x);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) vroff[e] = x * 256 + 16 * ((4 * e + g) ^ x);
+    {   // transposed reads: lane (q = x >> 2, p = x & 3) of group g addresses row 8g + q (+ 32 s + 4 t),
+        // columns 16 e + 4 p .. + 3; yswz of that row = 2 (q >> 1 & 1) + 4 (g & 1) whatever s and t are
+        const int q = x >> 2, pp = x & 3;
+        const int fz = (((q >> 1) & 1) << 1) | ((g & 1) << 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tro[e] = 128 * (8 * g + q) + 8 * (pp & 1) + 16 * ((2 * e + (pp >> 1)) ^ fz);
+    }
     const unsigned char* vring = smem + VOFF + wave * (VRING * 4096);
 
     Frag8 zh[2], zl[2];
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 
         // Explicit software pipeline (hipcc otherwise pairs every ds_read with its own
         // s_waitcnt right in front of the MFMA that uses it): each stage first ISSUES the
-        // next batch of eight fragment reads, then runs the 16 MFMAs of the batch that has
+        // next batch of fragment reads, then runs the 16 MFMAs of the batch that has
         // landed.  sched_barrier(0) pins the stage boundaries.
 #define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
         float4 va[2][2], vr[4];
@@ -263,12 +281,14 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[0], fb[jt], acc[jt]);
         NMFX_FENCE();
-        if (WITH_OBJ) {   // issue batch D0: Y^T tile rows 16e.., k-step 0 (-> fa, fb)
-            const unsigned char* ts = ybuf + ylane[0] + 16384;
+        if (WITH_OBJ) {   // issue batch D0: columns 16e.. of factors 0..31, transposed (-> fa, fb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                fa[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
-                fb[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
+                const unsigned char* ts = ybuf + tro[e];
+                const uint2 h0 = lds_read_tr(ts), h1 = lds_read_tr(ts + 512);
+                const uint2 l0 = lds_read_tr(ts + 8192), l1 = lds_read_tr(ts + 8192 + 512);
+                fa[e].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                fb[e].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         }
         NMFX_FENCE();
@@ -308,12 +328,14 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             f32x4 d[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            {   // issue batch D1 (-> fc, fd)
-                const unsigned char* ts = ybuf + ylane[1] + 16384;
+            {   // issue batch D1: factors 32..63 (-> fc, fd)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    fc[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048);
-                    fd[e].u = *reinterpret_cast<const uint4*>(ts + e * 2048 + 8192);
+                    const unsigned char* ts = ybuf + tro[e] + 4096;
+                    const uint2 h0 = lds_read_tr(ts), h1 = lds_read_tr(ts + 512);
+                    const uint2 l0 = lds_read_tr(ts + 8192), l1 = lds_read_tr(ts + 8192 + 512);
+                    fc[e].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    fd[e].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 }
             }
             NMFX_FENCE();
@@ -393,6 +415,17 @@ __global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __res
     __syncthreads();
     float* dst = out + ((c0 >> 7) * (rows_in >> 6) + blockIdx.y) * 8192 + (c0 & 64) * 64;
     for (int c = ty; c < 64; c += 4) dst[c * 64 + tx] = tile[tx][c];
+}
+
+// out = in, stored TILE-MAJOR: tile (r / 128, c / 64) of [128][64] floats, the tiles of one
+// 128-row block consecutive (ld / 64 of them).  One block per tile, 16-byte accesses.
+__global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out)
+{
+    const int64_t rb = blockIdx.y, cb = blockIdx.x;
+    const float* src = in + rb * 128 * ld + cb * 64;
+    float4* dst = reinterpret_cast<float4*>(out + (rb * (ld >> 6) + cb) * 8192);
+    for (int i = threadIdx.x; i < 128 * 16; i += 256)
+        dst[i] = *reinterpret_cast<const float4*>(src + (int64_t)(i >> 4) * ld + 4 * (i & 15));
 }
 
 // bf16 hi/lo images of M [rows][cols] (row-major, ld) and of its transpose [cols][rows]
@@ -681,22 +714,21 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64 && E->mp % 128 == 0 && E->np % 128 == 0; }
 
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
-                      const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy,
-                      const unsigned short* YThi, const unsigned short* YTlo, const unsigned short* Zhi,
+                      const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
     ProfScope ps(E, name);
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
-    const size_t shm = (size_t)2 * (obj ? 4 : 2) * 8192 + (size_t)8 * (obj ? 3 : 4) * 4096;
+    const size_t shm = (size_t)2 * 2 * 8192 + (size_t)8 * 4 * 4096;      // 160 KiB: Y double buffer + V rings
     static bool ok0 = false, ok1 = false;
     if (obj) {
         if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
-        hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
+        hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy,
                            Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
     } else {
         if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
-        hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, YThi, YTlo,
+        hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy,
                            Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
     }
     NMFX_HIP(hipGetLastError());
@@ -709,6 +741,7 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     int rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     if ((rc = lazy_alloc(E, &E->Vt, mp * np))) return rc;
+    if ((rc = lazy_alloc(E, &E->Vtile, mp * np))) return rc;
     for (int b = 0; b < 2; ++b) {
         if ((rc = lazy_alloc(E, &E->Whi[b], mp * kp))) return rc;
         if ((rc = lazy_alloc(E, &E->Wlo[b], mp * kp))) return rc;
@@ -732,6 +765,8 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     if ((rc = lazy_alloc(E, &E->Bt_part, hs2 * np * kp))) return rc;
     hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
                        E->V, np, E->Vt, mp);
+    hipLaunchKernelGGL(retile_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 128)), dim3(256), 0, E->stream,
+                       E->V, np, E->Vtile);
     hipLaunchKernelGGL(split_images_kernel, dim3(1, (unsigned)(mp / 64)), dim3(256), 0, E->stream, E->W[0], mp, kp,
                        kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo);
     hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(np / 64), 1), dim3(256), 0, E->stream, E->H, kp, np, np,
@@ -748,8 +783,8 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
-    if ((rc = launch_xyt(E, true, E->V, false, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                         E->HThi, E->HTlo, E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
+    if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
     { ProfScope ps(E, "w_update");
       hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
                          E->bf_wsplit, E->mp, Wold, E->HHt_part, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
@@ -757,7 +792,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
       NMFX_HIP(hipGetLastError()); }
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                         nullptr, nullptr, nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
+                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
     if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
     return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->bt_split,
                                  (int64_t)(E->mp / 128) * E->bf_wsplit);

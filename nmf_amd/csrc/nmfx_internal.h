@@ -71,6 +71,7 @@ struct nmfx_engine {
     bool bf_ready = false;
     bool fused_pack = false;       // nmfx_mur_run (single GPU): no pack launch, h_update reads the slabs
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
+    float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
     float* Vt = nullptr;           // V^T, tile-major: [np/128][mp/64] tiles of [128][64] (bf16-path H phase)
     float* Bt_part = nullptr;      // [bt_split][np][kp]
     unsigned short *Whi[2] = {nullptr, nullptr}, *Wlo[2] = {nullptr, nullptr};   // [mp][kp]
