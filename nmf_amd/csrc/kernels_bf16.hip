@@ -13,9 +13,9 @@
 // dimension:
 //     W phase:  A   = V   H^T      X = V   [m][n],  Y = H   [64][n]   (+ fused residual)
 //     H phase:  B^T = V^T W        X = V^T [n][m],  Y = W^T [64][m]
-// so the engine keeps a transposed copy of V in HBM (built once after the upload) and
-// the small update kernels emit the bf16 hi/lo images (and their transposes) of the
-// factors they have just produced.
+// so the engine keeps tile-major copies of V and V^T in HBM (built once after the upload)
+// and the small update kernels emit the bf16 hi/lo images of the factors they have just
+// produced (W: [m][64] for the residual and [64][m] for the H phase; H: [64][n]).
 #include "nmfx_internal.h"
 #include "kernels_small.h"
 
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void split_images_kernel(
         sh[r][tx] = (unsigned short)h; sl[r][tx] = (unsigned short)l;
     }
     __syncthreads();
+    if (!thi) return;                                  // (block-uniform) no transposed image wanted
     for (int c = ty; c < 64; c += 4) {
         thi[(c0 + c) * rows + r0 + tx] = sh[tx][c];
         tlo[(c0 + c) * rows + r0 + tx] = sl[tx][c];
@@ -578,8 +579,8 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
 }
 
 // H epilogue (nmf/mur.py:45): H_new = H * B / (G H + lam H + 1e-9) from B^T = V^T W (stored
-// [np][64]) + objective bookkeeping + the bf16 images of the new H (row-major [64][np] and
-// transposed [np][64]).  Block = 64 columns; the 64 x 64 x 64 product G H runs on the f32
+// [np][64]) + objective bookkeeping + the bf16 images of the new H ([64][np]; the W phase takes
+// its transposed fragments from the same image).  Block = 64 columns; the product G H runs on the f32
 // MFMA and every global access is a 16-byte vector (tiles are turned through LDS).
 // FROM_SLABS: single-GPU runs read the split slabs of the H phase, the Gram slabs and the
 // objective partials directly (no `pack` launch); sharded runs read the all-reduced
@@ -590,8 +591,7 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
     const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
     int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
     DevState* __restrict__ st, double* __restrict__ obj_hist,
-    unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
-    unsigned short* __restrict__ HThi, unsigned short* __restrict__ HTlo)
+    unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo)
 {
     if (st->flag) return;
     constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80;
@@ -599,8 +599,6 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
     float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDG]
     float* hs = gs + KP * LDG;                         // H tile [j][LDC]
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
-    unsigned short* th = reinterpret_cast<unsigned short*>(bt + CB * LDG);   // [c][KP + 2] hi
-    unsigned short* tl = th + CB * (KP + 2);                                 // [c][KP + 2] lo
     __shared__ double shd[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     double obj;
@@ -676,11 +674,7 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
             hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDG + cq + e] + lam * h + 1e-9f);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
-            th[(cq + 2 * e) * (KP + 2) + jr] = (unsigned short)(ph[e] & 0xffffu); th[(cq + 2 * e + 1) * (KP + 2) + jr] = (unsigned short)(ph[e] >> 16);
-            tl[(cq + 2 * e) * (KP + 2) + jr] = (unsigned short)(pl[e] & 0xffffu); tl[(cq + 2 * e + 1) * (KP + 2) + jr] = (unsigned short)(pl[e] >> 16);
-        }
+        for (int e = 0; e < 8; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
         const int64_t idx = (int64_t)jr * np + c0 + cq;
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4)
@@ -689,14 +683,6 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
         uint4* ol = reinterpret_cast<uint4*>(Hlo + idx);
         oh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); oh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
         ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
-    }
-    __syncthreads();
-    {   // transposed images [np][64]: thread (c = tid/4, quarter = tid%4) stores 16 factors = 32 bytes
-        const int c = tid >> 2, qd = tid & 3;
-        uint4* oh = reinterpret_cast<uint4*>(HThi + (c0 + c) * KP + 16 * qd);
-        uint4* ol = reinterpret_cast<uint4*>(HTlo + (c0 + c) * KP + 16 * qd);
-        oh[0] = pack8(th + c * (KP + 2) + 16 * qd); oh[1] = pack8(th + c * (KP + 2) + 16 * qd + 8);
-        ol[0] = pack8(tl + c * (KP + 2) + 16 * qd); ol[1] = pack8(tl + c * (KP + 2) + 16 * qd + 8);
     }
 }
 
@@ -750,8 +736,6 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     if ((rc = lazy_alloc(E, &E->WTlo, mp * kp))) return rc;
     if ((rc = lazy_alloc(E, &E->Hhi, kp * np))) return rc;
     if ((rc = lazy_alloc(E, &E->Hlo, kp * np))) return rc;
-    if ((rc = lazy_alloc(E, &E->HThi, kp * np))) return rc;
-    if ((rc = lazy_alloc(E, &E->HTlo, kp * np))) return rc;
     // splits of the H phase: rows of V^T are columns of V
     // one 512-thread block per CU: grid = (rows / 128) x splits ~ number of CUs
     const int64_t rbt = np / 128, cbt = mp / 64;
@@ -770,7 +754,7 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     hipLaunchKernelGGL(split_images_kernel, dim3(1, (unsigned)(mp / 64)), dim3(256), 0, E->stream, E->W[0], mp, kp,
                        kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo);
     hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(np / 64), 1), dim3(256), 0, E->stream, E->H, kp, np, np,
-                       E->Hhi, E->Hlo, E->HThi, E->HTlo);
+                       E->Hhi, E->Hlo, nullptr, nullptr);
     NMFX_HIP(hipGetLastError());
     E->bf_ready = true;
     return NMFX_OK;
@@ -802,7 +786,7 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
                              int64_t j) {
     ProfScope ps(E, "h_update");
     const dim3 grid((unsigned)(E->np / 64)), block(256);
-    const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float) + (size_t)2 * 64 * 66 * sizeof(unsigned short);
+    const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float);
     static bool ok = false;
     if (!ok) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<true>),
@@ -815,12 +799,12 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
                            E->G_part, E->bt_split, E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
                            (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
-                           E->Hhi, E->Hlo, E->HThi, E->HTlo);
+                           E->Hhi, E->Hlo);
     else
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<false>), grid, block, shm, E->stream, E->xf32, 1,
                            E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
                            (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
-                           E->Hhi, E->Hlo, E->HThi, E->HTlo);
+                           E->Hhi, E->Hlo);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -76,7 +76,7 @@ struct nmfx_engine {
     float* Bt_part = nullptr;      // [bt_split][np][kp]
     unsigned short *Whi[2] = {nullptr, nullptr}, *Wlo[2] = {nullptr, nullptr};   // [mp][kp]
     unsigned short *WThi = nullptr, *WTlo = nullptr;                              // [kp][mp]
-    unsigned short *Hhi = nullptr, *Hlo = nullptr, *HThi = nullptr, *HTlo = nullptr;   // [kp][np], [np][kp]
+    unsigned short *Hhi = nullptr, *Hlo = nullptr;   // [kp][np]
     double* nrm_part = nullptr;    // [blocks][4]
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
