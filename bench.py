@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--tol-max-iter", type=int, default=20000,
+                    help="time-to-tol leg: iteration cap of the run to the reference's default tolerances (0 = skip)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -256,6 +258,31 @@ def main():
 
     if args.pmc_child:            # inside a rocprofv3 PMC pass: the timed region above is all that is needed
         return
+
+    # time-to-tol (the second half of BASELINE.json's metric): the same problem from the same start,
+    # run until the reference's stop rule fires with ITS default tolerances (nmf/mur.py:52-53:
+    # min_iter=100, tol1=tol2=1e-5), or the cap.  Factors stay on the device; the stop rule is
+    # evaluated on the device every iteration; the host looks at the flag once per 256 iterations.
+    ttt = None
+    if rank == 0 and world == 1 and args.tol_max_iter > 0:
+        ttt = []
+        for tol in (1e-5, 1e-2):          # the reference's default, and a looser absolute tolerance
+            eng.set_factors(w0, h0)
+            eng.synchronize()
+            t1 = time.perf_counter()
+            done_t, rule = 0, 0
+            while done_t < args.tol_max_iter and not rule:
+                cnt = min(256, args.tol_max_iter - done_t)
+                eng.mur_run(0, 0.0, 0.0, 100, tol, tol, done_t, cnt)
+                done_t += cnt
+                rule, stop_i, n_obj_t = eng.state()
+            secs = time.perf_counter() - t1
+            ttt.append({"tol1": tol, "tol2": tol, "min_iter": 100, "max_iter": args.tol_max_iter,
+                        "converged": bool(rule), "stop_rule": int(rule),
+                        "iterations": int(stop_i + 1) if rule else int(done_t), "seconds": secs,
+                        "objective": float(eng.objectives(n_obj_t - 1, 1)[0]),
+                        "note": "host checks the device-side stop flag every 256 queued iterations"})
+
     if rank == 0 and world == 1 and roof is not None and not args.no_traffic:
         eng.close()               # free the HBM before the child passes allocate their own
         roof["traffic"] = hbm_traffic("xyt_bf16_kernel<true>" if precision == "bf16" else "wphase_kernel", m, n, k)
@@ -286,6 +313,7 @@ def main():
                        "loop": (run.mode if sharded else "library")},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "time_to_tol": ttt,
             "iteration": {"algorithmic_gflop": iter_flops / 1e9,
                           "tflops": iter_flops / (dt / args.steps) / 1e12,
                           "frac_of_f32_mfma_peak": iter_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS / world},
