@@ -108,9 +108,6 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRYHIP(hipSetDevice(device));
     TRYHIP(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
     E->stream = E->own_stream;
-    TRYHIP(hipStreamCreateWithFlags(&E->side_stream, hipStreamNonBlocking));
-    TRYHIP(hipEventCreateWithFlags(&E->ev_fork, hipEventDisableTiming));
-    TRYHIP(hipEventCreateWithFlags(&E->ev_join, hipEventDisableTiming));
     // split configuration: enough workgroups to fill 256 CUs twice over
     const int64_t rb = E->mp / 64, cb = E->np / 64;
     // grids = a whole number of resident rounds: 256 CUs x blocks/CU of each kernel
@@ -161,9 +158,6 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo};
     for (void* b : bufs) if (b) hipFree(b);
-    if (E->side_stream) { hipStreamSynchronize(E->side_stream); hipStreamDestroy(E->side_stream); }
-    if (E->ev_fork) hipEventDestroy(E->ev_fork);
-    if (E->ev_join) hipEventDestroy(E->ev_join);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
     return NMFX_OK;

@@ -41,8 +41,6 @@ struct nmfx_engine {
     int k = 0, kp = 0;             // logical / padded rank
     int64_t mp = 0, np = 0;        // padded shape (multiples of 64)
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side_stream = nullptr;      // small latency-bound kernels that can hide under a V-sized one
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // device buffers
     float* V = nullptr;            // [mp][np]
     float* W[2] = {nullptr, nullptr};   // [mp][kp], double buffered
@@ -134,23 +132,6 @@ int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int pr
 int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
                     float lam, int round, const double* nrm_global = nullptr);
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
-
-// Run a few launches on the side stream, concurrently with what follows on the main one:
-//   SideScope s(E);  ...launches (they see E->stream == side)...  s.back_to_main();
-//   ...main-stream launches that overlap...  s.join();   // main waits for the side work
-struct SideScope {
-    nmfx_engine* E; hipStream_t main; bool on_side = true;
-    explicit SideScope(nmfx_engine* e) : E(e), main(e->stream) {
-        (void)hipEventRecord(E->ev_fork, main);
-        (void)hipStreamWaitEvent(E->side_stream, E->ev_fork, 0);
-        E->stream = E->side_stream;
-    }
-    void back_to_main() {
-        if (on_side) { (void)hipEventRecord(E->ev_join, E->side_stream); E->stream = main; on_side = false; }
-    }
-    void join() { back_to_main(); (void)hipStreamWaitEvent(main, E->ev_join, 0); }
-    ~SideScope() { back_to_main(); }
-};
 
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;
