@@ -136,6 +136,17 @@ int nmfx_shift_iteration_base(nmfx_handle_t h, int64_t delta);
 int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, void* dev_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
 
+/* ---- initialisation: leading singular triplets of the uploaded V ------------------------
+ * Replaces `numpy.linalg.svd(x, full_matrices=False)` in nmf/utils.py:50 for what NNDSVD uses of
+ * it (the first `rank` triplets, utils.py:51-82; the construction is invariant under the sign
+ * choice of a triplet).  f64 arithmetic on the device: block subspace iteration with
+ * Rayleigh-Ritz on `block` columns (0 = max(k + 16, 1.5 k)), stopped when
+ * ||V^T u_i - s_i v_i|| <= tol * s_1 for i < k (tol <= 0: 1e-11) or after max_sweeps (<= 0: 4000).
+ * u: m x k, s: k, vt: k x n (row-major, host).  sweeps / resid (may be NULL) report the sweeps
+ * run and the largest relative residual reached, so the caller can tell a cap from convergence. */
+int nmfx_topk_svd(nmfx_handle_t h, int k, int block, double tol, int max_sweeps, uint64_t seed,
+                  double* u, double* s, double* vt, int* sweeps, double* resid);
+
 /* ---- AO-ADMM (replaces nmf/ao_admm.py:259-301) -------------------------- */
 /* One call queues `count` outer iterations: H sub-problem then W sub-problem
  * (admm_ls_update, ao_admm.py:46-68: Gram, rho = trace/k, Cholesky, up to

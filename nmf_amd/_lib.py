@@ -53,6 +53,7 @@ SIGNATURES = {
     "nmfx_anls_phase_objective": (_i32, [_vp, _i64]),
     "nmfx_anls_phase_w": (_i32, [_vp, _dbl, _i64, _dbl, _dbl, _i64]),
     "nmfx_anls_phase_h": (_i32, [_vp, _dbl, _i64]),
+    "nmfx_topk_svd": (_i32, [_vp, _i32, _i32, _dbl, _i32, C.c_uint64, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_dbl)]),
     "nmfx_reserve_objectives": (_i32, [_vp, _i64]),
     "nmfx_shift_iteration_base": (_i32, [_vp, _i64]),
     "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),

@@ -29,9 +29,10 @@ def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, 
     if distance_type == 'kl':
         raise NotImplementedError("anls with distance_type='kl' (KL objective of least-squares "
                                   "iterates) is not built in nmf_amd")
-    w0, h0 = utils.initial_factors(x, k, nndsvd_init, uniform=True)
+    init = utils.initial_factors(x, k, nndsvd_init, uniform=True, defer_device=True)
     with Engine(x.shape[0], x.shape[1], k, device=device) as eng:
         eng.upload_v(x)
+        w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         i, history = drive(
             eng,

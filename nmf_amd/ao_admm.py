@@ -45,13 +45,14 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
     if distance_type not in ('eu', 'kl'):
         raise KeyError('Distance type unknown: use "kl" or "eu"')   # nmf/utils.py:31 via ao_admm.py:256
     dist = L.EU if distance_type == 'eu' else L.KL
-    w0, h0 = utils.initial_factors(v, k, nndsvd_init)
+    init = utils.initial_factors(v, k, nndsvd_init, defer_device=True)
     # the reference meets the H regulariser first (ao_admm.py:261), then W's
     prox_h = _prox_code(reg_h[1])
     prox_w = _prox_code(reg_w[1])
 
     with Engine(v.shape[0], v.shape[1], k, device=device) as eng:
         eng.upload_v(v)
+        w0, h0 = utils.device_initial_factors(eng, v, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         seen = {}
 

@@ -149,6 +149,15 @@ class Engine:
     def anls_phase_h(self, lam_h, j):
         self._ck(self.lib.nmfx_anls_phase_h(self.h, float(lam_h), int(j)))
 
+    def topk_svd(self, k, block=0, tol=0.0, max_sweeps=0, seed=0):
+        """Leading k singular triplets of the uploaded V (f64, on the device).
+        Returns (u m x k, s k, vt k x n, sweeps, relative residual)."""
+        u = np.empty((self.m, k)); s = np.empty(k); vt = np.empty((k, self.n))
+        sweeps, resid = C.c_int(), C.c_double()
+        self._ck(self.lib.nmfx_topk_svd(self.h, int(k), int(block), float(tol), int(max_sweeps), int(seed),
+                                        _ptr(u), _ptr(s), _ptr(vt), C.byref(sweeps), C.byref(resid)))
+        return u, s, vt, sweeps.value, resid.value
+
     def reserve_objectives(self, count):
         self._ck(self.lib.nmfx_reserve_objectives(self.h, int(count)))
 

@@ -36,9 +36,10 @@ def mur(x, k, *, distance_type='kl', min_iter=100, max_iter=100000, tol1=1e-5, t
         x += abs(lowest)
         logging.info('Data elevated by {}.'.format(abs(lowest)))
 
-    w0, h0 = utils.initial_factors(x, k, nndsvd_init)
+    init = utils.initial_factors(x, k, nndsvd_init, defer_device=True)
     with Engine(x.shape[0], x.shape[1], k, device=device) as eng:
         eng.upload_v(x)
+        w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         logging.info('Entering Main Loop.')
         i, history = drive(

@@ -30,12 +30,10 @@ def tol_digits(tol1, tol2):
     return int(format(tol, 'e').split('-')[1]) if tol < 1 else 2
 
 
-def nndsvd(x, rank=None, variant='zero'):
-    """SVD based initialisation (Boutsidis & Gallopoulos), same call signature
-    and RNG consumption as nmf/utils.py:36-93.  Returns float64 (w, h)."""
-    u, s, vt = np.linalg.svd(x, full_matrices=False)
-    if rank is None:
-        rank = x.shape[1]
+def _nndsvd_from_triplets(x, u, s, vt, rank, variant):
+    """Boutsidis & Gallopoulos construction from the leading `rank` singular triplets
+    (nmf/utils.py:51-93; invariant under the sign choice of a triplet: the positive and
+    negative parts swap roles)."""
     w = np.zeros((x.shape[0], rank))
     h = np.zeros((rank, x.shape[1]))
     root = np.sqrt(s[:rank])
@@ -66,11 +64,49 @@ def nndsvd(x, rank=None, variant='zero'):
     return w, h
 
 
-def initial_factors(x, k, nndsvd_init, uniform=False):
+def nndsvd(x, rank=None, variant='zero'):
+    """SVD based initialisation (Boutsidis & Gallopoulos), same call signature
+    and RNG consumption as nmf/utils.py:36-93.  Returns float64 (w, h)."""
+    u, s, vt = np.linalg.svd(x, full_matrices=False)
+    if rank is None:
+        rank = x.shape[1]
+    return _nndsvd_from_triplets(x, u, s, vt, rank, variant)
+
+
+def nndsvd_device(eng, x, rank, variant='zero'):
+    """NNDSVD whose singular triplets come from the device (Engine.topk_svd on the uploaded V,
+    f64 subspace iteration) instead of a full LAPACK SVD on the host: the only part of
+    nmf/utils.py:36-93 whose cost grows like m n min(m, n).  Raises if the iteration hits its
+    sweep cap (clustered singular values around the rank-th one)."""
+    u, s, vt, sweeps, resid = eng.topk_svd(rank)
+    if not resid <= 1e-9:
+        raise RuntimeError(f'device SVD did not converge ({sweeps} sweeps, residual {resid:.2e}); '
+                           'set NMFX_NNDSVD=host to use LAPACK on the host')
+    return _nndsvd_from_triplets(x, u, s, vt, rank, variant)
+
+
+def nndsvd_on_device(x, k):
+    """Where the singular triplets of NNDSVD are computed.  NMFX_NNDSVD = host | device | auto
+    (default): auto takes the device for matrices of 2^22 elements and more, where the host's
+    full LAPACK SVD (what nmf/utils.py:50 does) costs seconds to minutes, and keeps small
+    problems on the host LAPACK path (bit-identical to the reference's own initialisation)."""
+    mode = os.environ.get("NMFX_NNDSVD", "auto")
+    if mode == "host":
+        return False
+    if mode == "device":
+        return True
+    return x.shape[0] * x.shape[1] >= (1 << 22) and k <= 128
+
+
+def initial_factors(x, k, nndsvd_init, uniform=False, defer_device=False):
     """W then H from the GLOBAL numpy RNG in the reference's order
     (nmf/mur.py:105-109, nmf/ao_admm.py:19-23, nmf/admm.py:20-24 use |randn|;
-    nmf/anls.py:101-105 uses rand), so identical seeds give identical starts."""
+    nmf/anls.py:101-105 uses rand), so identical seeds give identical starts.
+    With defer_device=True returns None when the NNDSVD is to be computed from the device
+    SVD once V is uploaded (`device_initial_factors`)."""
     if nndsvd_init[0]:
+        if defer_device and nndsvd_on_device(x, k):
+            return None
         return nndsvd(x, k, variant=nndsvd_init[1])
     if uniform:
         w = np.random.rand(x.shape[0], k)
@@ -79,6 +115,11 @@ def initial_factors(x, k, nndsvd_init, uniform=False):
         w = np.abs(np.random.randn(x.shape[0], k))
         h = np.abs(np.random.randn(k, x.shape[1]))
     return w, h
+
+
+def device_initial_factors(eng, x, k, nndsvd_init, init):
+    """`init` from initial_factors(..., defer_device=True), completed on the device if deferred."""
+    return init if init is not None else nndsvd_device(eng, x, k, variant=nndsvd_init[1])
 
 
 def save_results(save_str, w, h, i, obj_history, experiment):
