@@ -156,7 +156,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->obj_part, E->own_x ? (void*)E->xf32 : nullptr, E->own_x ? (void*)E->xf64 : nullptr,
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
-                    E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo};
+                    E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -268,6 +268,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->wsel = 0;
     E->have_f = true;
     E->bf_ready = false;
+    E->lazy_objective = false;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;

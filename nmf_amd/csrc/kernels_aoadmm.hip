@@ -494,13 +494,52 @@ int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, co
 // One outer iteration of ao_admm.py:259-292 (Euclidean loss), in the pieces the row-sharded
 // form needs (nmfx_aoadmm_phase_*): between h_products and h_solve the caller all-reduces
 // [W^T V | W^T W | objective]; between the rounds of the W sub-problem, the four norm sums.
+// Split-bf16 products (kp = 64 / 128, Euclidean loss): the H-side product also carries the residual
+// objective of the CURRENT pair (X = V^T, Y = W^T images, Z = H^T images), which is exactly the
+// obj[j] the following `prepare` records -- so the separate objective pass over V at the end of
+// every outer iteration (one third of the V traffic) disappears.
+static bool ao_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_bf16_supported(E); }
+
+static int ao_bf16_objective_product(nmfx_engine* E) {   // Bt_part, obj_part (and G_part for kp = 64) of the current pair
+    int rc;
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, true))) return rc;
+    return nmfx_bf16_vtw(E, true, "hphase");
+}
+
 static int ao_h_products(nmfx_engine* E) {
     int rc;
     float* W = E->W[0];
+    if (ao_bf16(E)) {
+        if ((rc = ao_bf16_objective_product(E))) return rc;
+        const int64_t nobj = (int64_t)(E->np / 128) * E->bt_split;
+        if (E->kp == 64) return nmfx_bf16_pack_t(E, E->G_part, E->bt_split, nobj);     // W^T W: by-product slabs
+        if ((rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+        return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj);
+    }
     const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
     if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_hphase(E, W, fuse_g))) return rc;
     return nmfx_launch_pack(E);                                      // xf32 = [W^T V | W^T W], xf64 = obj[j]
+}
+
+// objective partials of the pair the iteration has just produced (f32 path: a pass over V now;
+// bf16 path: nothing, the next H-side product or ao_final_objective computes it)
+static int ao_new_pair_objective(nmfx_engine* E) {
+    E->lazy_objective = ao_bf16(E);
+    if (E->lazy_objective) return NMFX_OK;
+    return nmfx_launch_wphase(E, E->W[0], false, true);
+}
+
+// xf64[0] = objective partial of the current pair (end of a run)
+static int ao_final_objective(nmfx_engine* E) {
+    int rc;
+    if (E->lazy_objective) {
+        if ((rc = ao_bf16_objective_product(E))) return rc;
+        return nmfx_launch_obj_reduce(E, (int64_t)(E->np / 128) * E->bt_split);
+    }
+    return nmfx_launch_obj_reduce(E);
 }
 
 static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, int64_t min_iter, double tol1,
@@ -515,6 +554,16 @@ static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, i
 static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2) {
     int rc;
     const int64_t kk = (int64_t)E->kp * E->kp;
+    if (ao_bf16(E)) {
+        if ((rc = nmfx_bf16_images_h(E, false))) return rc;                    // the H the sub-problem above produced
+        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;      // kp = 64: H H^T slabs as a by-product
+        const bool byprod = E->kp == 64;
+        if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+        { ProfScope ps(E, "sums");
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+          if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->auxW))) return rc; }
+        return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);
+    }
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, E->W[0], true, false))) return rc;
     { ProfScope ps(E, "sums");
@@ -536,7 +585,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
       for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
       if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
     // ---- objective of the new pair (utils.py:29), summed by the next pack / finish ----
-    return nmfx_launch_wphase(E, W, false, true);
+    return ao_new_pair_objective(E);
 }
 
 static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
@@ -591,7 +640,8 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
     E->wsel = 0;
     E->w_in_place = true;
-    if (first == 0 && count > 0) {                                    // obj[0] of the initial factors (ao_admm.py:256)
+    if (distance != NMFX_EU) E->lazy_objective = false;
+    if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
         if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
     }
     for (int64_t j = first; j < first + count; ++j) {
@@ -620,7 +670,7 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
 
 extern "C" int nmfx_aoadmm_phase_h_products(nmfx_handle_t E, int64_t j) {
     int rc = ao_sharded_ready(E, j); if (rc) return rc;
-    if (j == 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0] partials (ao_admm.py:256)
+    if (j == 0 && (rc = ao_new_pair_objective(E))) return rc;                      // obj[0] partials (ao_admm.py:256)
     return ao_h_products(E);
 }
 
@@ -655,14 +705,14 @@ extern "C" int nmfx_aoadmm_phase_w_round(nmfx_handle_t E, int prox_w, double lam
 extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
     int rc = ao_sharded_ready(E, j); if (rc) return rc;
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
-    return nmfx_launch_wphase(E, E->W[0], false, true);
+    return ao_new_pair_objective(E);
 }
 
 // f64 exchange buffer [0] = this rank's objective partial of the current pair.
 extern "C" int nmfx_objective_partial(nmfx_handle_t E) {
     if (!E) return NMFX_E_ARG;
     NMFX_HIP(hipSetDevice(E->device));
-    return nmfx_launch_obj_reduce(E);
+    return ao_final_objective(E);
 }
 
 // bookkeeping of the last iteration's objective (obj_part is already filled)
@@ -670,6 +720,6 @@ extern "C" int nmfx_aoadmm_finish(nmfx_handle_t E, int64_t min_iter, double tol1
     if (!E) return NMFX_E_ARG;
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
-    if ((rc = nmfx_launch_obj_reduce(E))) return rc;
+    if ((rc = ao_final_objective(E))) return rc;
     return nmfx_finish_b(E, min_iter, tol1, tol2, done);
 }

@@ -102,7 +102,9 @@ __device__ __forceinline__ uint2 lds_read_tr(const unsigned char* p) {
     return r.u;
 }
 
-template <bool WITH_OBJ>
+// KP = 64 or 128 factors.  KP = 128: Y image 2 x 16 KiB per group (double buffered: 64 KiB), V ring
+// 3 deep, accumulators for 8 factor tiles, the Gram by-product is left to the Gram kernels.
+template <int KP, bool WITH_OBJ>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -111,10 +113,16 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     int ngroups, const int* __restrict__ flag, int tiled)
 {
     if (*flag) return;
-    constexpr int KP = 64;
-    constexpr int YBUF = 2 * 8192;                    // bytes: Yhi tile, Ylo tile
+    constexpr int NJT = KP / 16;                      // factor tiles of the A-product
+    constexpr int YT = KP * 128;                      // bytes of one Y tile (KP rows x 64 bf16)
+    constexpr int YBUF = 2 * YT;                      // Yhi tile, Ylo tile
     constexpr int VOFF = 2 * YBUF;                    // start of the V rings
-    constexpr int VRING = 4;                          // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
+    constexpr int VRING = (KP == 64) ? 4 : 3;         // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
+    constexpr bool WITH_GRAM = (KP == 64);
+    constexpr int YPW = 2 * (KP / 8) / 4;             // Y pieces (8 rows x 128 B) per loader wave and group
+    constexpr int NA = 2 * (NJT / 4);                 // pipeline stages of the A-product: (k-step, half of the tiles)
+    constexpr int ND = WITH_OBJ ? KP / 32 : 0;        // stages of the residual product: k-steps over the factors
+    constexpr int NS = NA + ND;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a PROVABLY uniform value: everything derived from it (DMA bases, LDS
@@ -129,20 +137,20 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     // ---- DMA plan: roles by wave, so that every wave's vmcnt queue is homogeneous ----
     // (vmcnt retires in order: a shallow Y request behind deep V requests would force
     // the V requests to complete too.)
-    //   waves 4..7 ("Y loaders"): four of the 16 pieces (8 rows x 128 B) of the Y tiles of group grp+1
+    //   waves 4..7 ("Y loaders"): YPW of the pieces (8 rows x 128 B) of the Y tiles of group grp+1
     //   waves 0..3 ("V loaders"): the V tiles of TWO waves each (w and w+4), VRING-1 groups ahead
     const bool yrole = wave >= 4;
     const int lw = wave & 3;
-    const int ytile = lw >> 1, p0 = 4 * (lw & 1);
+    const int ytile = (lw * YPW) / (KP / 8), p0 = (lw * YPW) % (KP / 8);
     const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
     unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * 128ull;
-    unsigned yoffs[4];
+    unsigned yoffs[YPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < YPW; ++i) {
         const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ yswz(row);
         yoffs[i] = (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2);
     }
-    const unsigned ydst = (unsigned)(ytile * 8192 + p0 * 1024);
+    const unsigned ydst = (unsigned)(ytile * YT + p0 * 1024);
     // V: rows 4t + g of a wave's 16, position x holds chunk x ^ row
     const int64_t rblk = (int64_t)blockIdx.x * 128;
     unsigned long long vbaseA = (unsigned long long)(X + (rblk + lw * 16) * ldx) + (unsigned long long)g0 * 256ull;
@@ -165,7 +173,9 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const unsigned vdstB = smem0 + VOFF + (lw + 4) * (VRING * 4096);
     int yq = 0, vq = 0;                               // next Y buffer / V ring slot to fill
     auto issue_y = [&]() {                            // Y loaders only
-        dma_run4(ybase, smem0 + yq * YBUF + ydst, yoffs[0], yoffs[1], yoffs[2], yoffs[3]);
+#pragma unroll
+        for (int i = 0; i < YPW; i += 4)
+            dma_run4(ybase, smem0 + yq * YBUF + ydst + i * 1024, yoffs[i], yoffs[i + 1], yoffs[i + 2], yoffs[i + 3]);
         ybase += 128ull; yq ^= 1;
     };
     auto issue_v = [&]() {                            // V loaders only
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     int ylane[2], vaoff[2][2], vroff[4], tro[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz(x));           // + 2048 * (row block) + 8192 * tile
+        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz(x));           // + 2048 * (factor tile) + YT * (lo image)
 #pragma unroll
         for (int h = 0; h < 2; ++h) vaoff[s][h] = x * 256 + 16 * ((8 * s + 2 * g + h) ^ x);
     }
@@ -193,22 +203,22 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     }
     const unsigned char* vring = smem + VOFF + wave * (VRING * 4096);
 
-    Frag8 zh[2], zl[2];
+    Frag8 zh[WITH_OBJ ? KP / 32 : 1], zl[WITH_OBJ ? KP / 32 : 1];
     if (WITH_OBJ) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KP / 32; ++s) {
             zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + x) * KP + 32 * s + 8 * g);
             zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + x) * KP + 32 * s + 8 * g);
             pinu(zh[s].u); pinu(zl[s].u);
         }
     }
-    f32x4 acc[4];
+    f32x4 acc[NJT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Gram by-product: the row blocks with blockIdx.x == 0 also accumulate Y Y^T over their
-    // column range from the Y fragments they fetch anyway (H H^T in the W phase, W^T W in the
-    // H phase).  Wave w owns tile row w>>1 and tile columns 2(w&1), 2(w&1)+1.
-    const bool do_gram = (blockIdx.x == 0);
+    for (int j = 0; j < NJT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Gram by-product (KP = 64): the row blocks with blockIdx.x == 0 also accumulate Y Y^T over
+    // their column range from the Y fragments they fetch anyway (H H^T in the W phase, W^T W in
+    // the H phase).  Wave w owns tile row w>>1 and tile columns 2(w&1), 2(w&1)+1.
+    const bool do_gram = WITH_GRAM && (blockIdx.x == 0);
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
@@ -236,12 +246,34 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         const unsigned char* vt = vring + vcur * 4096;
 
         // Explicit software pipeline (hipcc otherwise pairs every ds_read with its own
-        // s_waitcnt right in front of the MFMA that uses it): each stage first ISSUES the
-        // next batch of fragment reads, then runs the 16 MFMAs of the batch that has
-        // landed.  sched_barrier(0) pins the stage boundaries.
+        // s_waitcnt right in front of the MFMA that uses it): stage st first ISSUES the fragment
+        // reads of stage st+1 into the other register set, then runs its own 16 MFMAs.
+        // Stages: A-product (k-step, half of the factor tiles) ..., then the residual product's
+        // k-steps over the factors.  sched_barrier(0) pins the stage boundaries.
 #define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
         float4 va[2][2], vr[4];
-        Frag8 fa[4], fb[4], fc[4], fd[4];              // two batches in flight: (fa, fb) and (fc, fd)
+        Frag8 fh[2][4], fl[2][4];                      // [register set][fragment]: hi and lo images
+        auto issue = [&](int st, int set) {
+            if (st < NA) {                             // Y tile rows 16 jt.., k-step st / (NJT / 4)
+                const int ks = st / (NJT / 4), half = st % (NJT / 4);
+                const unsigned char* ys = ybuf + ylane[ks] + half * 4 * 2048;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fh[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048);
+                    fl[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048 + YT);
+                }
+            } else {                                   // columns 16 e.. of factors 32 s.. 32 s + 31, transposed
+                const int s = st - NA;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned char* ts = ybuf + tro[e] + s * 4096;
+                    const uint2 h0 = lds_read_tr(ts), h1 = lds_read_tr(ts + 512);
+                    const uint2 l0 = lds_read_tr(ts + YT), l1 = lds_read_tr(ts + YT + 512);
+                    fh[set][e].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    fl[set][e].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+        };
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -250,112 +282,64 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) vr[e] = *reinterpret_cast<const float4*>(vt + vroff[e]);
         }
-        {   // batch A0: Y tile rows jt*16.., k-step 0 (hi -> fa, lo -> fb)
-            const unsigned char* ys = ybuf + ylane[0];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                fa[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
-                fb[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
-            }
-        }
+        issue(0, 0);
         NMFX_FENCE();
         Frag8 vh[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
-        {   // issue batch A1 (-> fc, fd)
-            const unsigned char* ys = ybuf + ylane[1];
+        f32x4 d[4];                                    // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                fc[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048);
-                fd[jt].u = *reinterpret_cast<const uint4*>(ys + jt * 2048 + 8192);
+        for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int set = st & 1;
+            if (st + 1 < NS) issue(st + 1, set ^ 1);
+            NMFX_FENCE();
+            if (st < NA) {
+                const int ks = st / (NJT / 4), j0 = 4 * (st % (NJT / 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vh[ks], fh[set][j], acc[j0 + j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fh[set][j], acc[j0 + j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vh[ks], fl[set][j], acc[j0 + j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fl[set][j], acc[j0 + j]);
+            } else {
+                const int s = st - NA;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zh[WITH_OBJ ? s : 0], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zh[WITH_OBJ ? s : 0], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zl[WITH_OBJ ? s : 0], d[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_OBJ ? s : 0], d[e]);
             }
-        }
-        NMFX_FENCE();
-        // A-product, k-step 0
+            NMFX_FENCE();
+            if (WITH_GRAM && st == NA - 1 && do_gram) {
+                // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
+                // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[0], fa[jt], acc[jt]);
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned char* ys = ybuf + ylane[s];
+                    Frag8 ah, al;
+                    ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
+                    al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + YT);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[0], fa[jt], acc[jt]);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[0], fb[jt], acc[jt]);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[0], fb[jt], acc[jt]);
-        NMFX_FENCE();
-        if (WITH_OBJ) {   // issue batch D0: columns 16e.. of factors 0..31, transposed (-> fa, fb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned char* ts = ybuf + tro[e];
-                const uint2 h0 = lds_read_tr(ts), h1 = lds_read_tr(ts + 512);
-                const uint2 l0 = lds_read_tr(ts + 8192), l1 = lds_read_tr(ts + 8192 + 512);
-                fa[e].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                fb[e].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
-            }
-        }
-        NMFX_FENCE();
-        // A-product, k-step 1
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[1], fc[jt], acc[jt]);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[1], fc[jt], acc[jt]);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vh[1], fd[jt], acc[jt]);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_BF16(vl[1], fd[jt], acc[jt]);
-        NMFX_FENCE();
-        if (do_gram) {
-            // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
-            // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned char* ys = ybuf + ylane[s];
-                Frag8 ah, al;
-                ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
-                al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + 8192);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    Frag8 bh, bl;
-                    bh.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048);
-                    bl.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048 + 8192);
-                    gacc[c] = MFMA_BF16(ah, bh, gacc[c]);
-                    gacc[c] = MFMA_BF16(al, bh, gacc[c]);
-                    gacc[c] = MFMA_BF16(ah, bl, gacc[c]);
-                    gacc[c] = MFMA_BF16(al, bl, gacc[c]);
+                    for (int c = 0; c < 2; ++c) {
+                        Frag8 bh, bl;
+                        bh.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048);
+                        bl.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048 + YT);
+                        gacc[c] = MFMA_BF16(ah, bh, gacc[c]);
+                        gacc[c] = MFMA_BF16(al, bh, gacc[c]);
+                        gacc[c] = MFMA_BF16(ah, bl, gacc[c]);
+                        gacc[c] = MFMA_BF16(al, bl, gacc[c]);
+                    }
                 }
             }
         }
         if (WITH_OBJ) {
-            // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]   (computed as Y^T-tile x Z^T)
-            f32x4 d[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            {   // issue batch D1: factors 32..63 (-> fc, fd)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned char* ts = ybuf + tro[e] + 4096;
-                    const uint2 h0 = lds_read_tr(ts), h1 = lds_read_tr(ts + 512);
-                    const uint2 l0 = lds_read_tr(ts + 8192), l1 = lds_read_tr(ts + 8192 + 512);
-                    fc[e].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    fd[e].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                }
-            }
-            NMFX_FENCE();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fa[e], zh[0], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fb[e], zh[0], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fa[e], zl[0], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fb[e], zl[0], d[e]);
-            NMFX_FENCE();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fc[e], zh[1], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fd[e], zh[1], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fc[e], zl[1], d[e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fd[e], zl[1], d[e]);
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -373,7 +357,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     {
         float* out = Apart + ((int64_t)sp * R + r0) * KP;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(int64_t)(4 * g + r) * KP + jt * 16 + x] = acc[jt][r];
     }
@@ -697,28 +681,33 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
     return NMFX_OK;
 }
 
-bool nmfx_bf16_supported(const nmfx_engine* E) { return E->kp == 64 && E->mp % 128 == 0 && E->np % 128 == 0; }
+bool nmfx_bf16_supported(const nmfx_engine* E) { return (E->kp == 64 || E->kp == 128) && E->mp % 128 == 0 && E->np % 128 == 0; }
+
+template <int KP, bool OBJ>
+static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
+                        const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
+                        const unsigned short* Zlo, float* Apart, float* gram_part) {
+    dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+    const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
+    static bool attr = false;
+    auto kern = xyt_bf16_kernel<KP, OBJ>;
+    if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
+                       gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
 
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
     ProfScope ps(E, name);
-    dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
-    const size_t shm = (size_t)2 * 2 * 8192 + (size_t)8 * 4 * 4096;      // 160 KiB: Y double buffer + V rings
-    static bool ok0 = false, ok1 = false;
-    if (obj) {
-        if (!ok1) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok1 = true; }
-        hipLaunchKernelGGL((xyt_bf16_kernel<true>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
-    } else {
-        if (!ok0) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xyt_bf16_kernel<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok0 = true; }
-        hipLaunchKernelGGL((xyt_bf16_kernel<false>), grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy,
-                           Zhi, Zlo, Apart, E->obj_part, gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
-    }
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
+    if (E->kp == 64)
+        return obj ? launch_xyt_t<64, true>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
+                   : launch_xyt_t<64, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part);
+    return obj ? launch_xyt_t<128, true>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
+               : launch_xyt_t<128, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part);
 }
 
 // Allocate the bf16 state and build V^T and the images of the initial factors.
@@ -751,18 +740,128 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
                        E->V, np, E->Vt, mp);
     hipLaunchKernelGGL(retile_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 128)), dim3(256), 0, E->stream,
                        E->V, np, E->Vtile);
-    hipLaunchKernelGGL(split_images_kernel, dim3(1, (unsigned)(mp / 64)), dim3(256), 0, E->stream, E->W[0], mp, kp,
-                       kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo);
-    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(np / 64), 1), dim3(256), 0, E->stream, E->H, kp, np, np,
-                       E->Hhi, E->Hlo, nullptr, nullptr);
-    NMFX_HIP(hipGetLastError());
     E->bf_ready = true;
+    if ((rc = nmfx_bf16_images_w(E, E->W[E->wsel], E->wsel))) return rc;
+    return nmfx_bf16_images_h(E, false);
+}
+
+// ---- building blocks shared by the solvers (kp = 64 or 128); results land where the exact-f32
+// kernels put theirs, so everything downstream (epilogues, inner rounds) is unchanged ----
+int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf) {      // Whi/Wlo[buf] ([mp][kp]) and WThi/WTlo ([kp][mp])
+    ProfScope ps(E, "images");
+    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(E->kp / 64), (unsigned)(E->mp / 64)), dim3(256), 0, E->stream,
+                       W, E->mp, (int64_t)E->kp, (int64_t)E->kp, E->Whi[buf], E->Wlo[buf], E->WThi, E->WTlo);
+    NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+
+int nmfx_bf16_images_h(nmfx_engine* E, bool transposed) {              // Hhi/Hlo ([kp][np]) (+ HThi/HTlo ([np][kp]))
+    ProfScope ps(E, "images");
+    int rc;
+    if (transposed) {
+        if ((rc = lazy_alloc(E, &E->HThi, (int64_t)E->kp * E->np))) return rc;
+        if ((rc = lazy_alloc(E, &E->HTlo, (int64_t)E->kp * E->np))) return rc;
+    }
+    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(E->np / 64), (unsigned)(E->kp / 64)), dim3(256), 0, E->stream,
+                       E->H, (int64_t)E->kp, E->np, E->np, E->Hhi, E->Hlo, transposed ? E->HThi : nullptr,
+                       transposed ? E->HTlo : nullptr);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// A_part[bf_wsplit][mp][kp] = V H^T (+ obj_part[(mp/128) * bf_wsplit] = residual objective of (W images `zbuf`, H))
+int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name) {
+    return launch_xyt(E, obj, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                      obj ? E->Whi[zbuf] : nullptr, obj ? E->Wlo[zbuf] : nullptr, E->A_part,
+                      E->kp == 64 ? E->HHt_part : nullptr, name);
+}
+
+// Bt_part[bt_split][np][kp] = V^T W (+ obj_part[(np/128) * bt_split] = residual objective, Z = H^T images)
+int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name) {
+    return launch_xyt(E, obj, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
+                      obj ? E->HThi : nullptr, obj ? E->HTlo : nullptr, E->Bt_part,
+                      E->kp == 64 ? E->G_part : nullptr, name);
+}
+
+// xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
+template <int KP>
+__global__ __launch_bounds__(256) void pack_t_kernel(
+    const float* __restrict__ Btpart, int bsplit, int64_t np, const float* __restrict__ Gpart, int gsplit,
+    const double* __restrict__ objpart, int64_t nobj, float* __restrict__ xf32, double* __restrict__ xf64,
+    const int* __restrict__ flag)
+{
+    if (*flag) return;
+    __shared__ float tile[64][KP + 1];
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, nbb = (int)(np / 64), b = blockIdx.x;
+    const int64_t bcount = (int64_t)KP * np;
+    if (b < nbb) {
+        const int64_t c0 = (int64_t)b * 64;
+        for (int e = tid; e < 64 * (KP / 4); e += 256) {
+            const int c = e / (KP / 4), j4 = e % (KP / 4);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < bsplit; ++p) add4(v, Btpart + (int64_t)p * bcount + (c0 + c) * KP + 4 * j4);
+            tile[c][4 * j4] = v[0]; tile[c][4 * j4 + 1] = v[1]; tile[c][4 * j4 + 2] = v[2]; tile[c][4 * j4 + 3] = v[3];
+        }
+        __syncthreads();
+        for (int e = tid; e < KP * 64; e += 256) xf32[(int64_t)(e >> 6) * np + c0 + (e & 63)] = tile[e & 63][e >> 6];
+    } else if (b < nbb + KP * KP / 256) {
+        const int64_t i = (int64_t)(b - nbb) * 256 + tid;
+        float s2 = 0.f;
+        for (int p = 0; p < gsplit; ++p) s2 += Gpart[(int64_t)p * KP * KP + i];
+        xf32[bcount + i] = s2;
+    } else {
+        double t = 0.0;
+        for (int64_t i = tid; i < nobj; i += 256) t += objpart[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((tid & 63) == 0) sh[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) xf64[0] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    }
+}
+
+int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nobj) {
+    ProfScope ps(E, "pack");
+    const unsigned grid = (unsigned)(E->np / 64 + E->kp * E->kp / 256 + 1);
+    if (E->kp == 64)
+        hipLaunchKernelGGL((pack_t_kernel<64>), dim3(grid), dim3(256), 0, E->stream, E->Bt_part, E->bt_split, E->np, Gpart,
+                           gsplit, E->obj_part, nobj, E->xf32, E->xf64, &E->state->flag);
+    else
+        hipLaunchKernelGGL((pack_t_kernel<128>), dim3(grid), dim3(256), 0, E->stream, E->Bt_part, E->bt_split, E->np, Gpart,
+                           gsplit, E->obj_part, nobj, E->xf32, E->xf64, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// MUR-Euclidean, k = 128: split-bf16 products, the exact-f32 path's epilogues and Gram kernels
+// between them, and one image pass per factor update.
+static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) {
+    int rc;
+    const int cur = (int)(j & 1), nxt = cur ^ 1;
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    { ProfScope ps(E, "sum_hht");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc; }
+    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase"))) return rc;
+    if ((rc = nmfx_launch_w_update(E, E->W[cur], E->W[nxt], (float)lambda_w, E->bf_wsplit))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[nxt], nxt))) return rc;
+    if ((rc = nmfx_launch_gram_tn(E, E->W[nxt], E->mp, E->G_part, E->gsplit))) return rc;
+    if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
+    return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, (int64_t)(E->mp / 128) * E->bf_wsplit);
+}
+
+static int mur_eu_phase_b_bf16_k128(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    if ((rc = nmfx_launch_h_update(E, (float)lambda_h, j, min_iter, tol1, tol2))) return rc;
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    return nmfx_bf16_images_h(E, false);
 }
 
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     int rc;
+    if (!E->bf_ready) E->wsel = (int)(j & 1);   // the images of the current W are built from W[j & 1]
     if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if (E->kp != 64) return mur_eu_phase_a_bf16_k128(E, lambda_w, j);
     const int cur = (int)(j & 1), nxt = cur ^ 1;
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
@@ -784,6 +883,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
 
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,
                              int64_t j) {
+    if (E->kp != 64) return mur_eu_phase_b_bf16_k128(E, lambda_h, min_iter, tol1, tol2, j);
     ProfScope ps(E, "h_update");
     const dim3 grid((unsigned)(E->np / 64)), block(256);
     const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float);

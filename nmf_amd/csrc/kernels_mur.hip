@@ -179,9 +179,9 @@ int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int6
 }
 
 template <int KP>
-static int launch_w_update(nmfx_engine* E, const float* Wold, float* Wnew, float lam) {
+static int launch_w_update(nmfx_engine* E, const float* Wold, float* Wnew, float lam, int splits = 0) {
     hipLaunchKernelGGL((mur_w_update_kernel<KP>), dim3((unsigned)(E->mp / 16)), dim3(256), 0, E->stream,
-                       E->A_part, E->wsplit, E->mp, Wold, E->HHt, lam, Wnew, &E->state->flag);
+                       E->A_part, splits > 0 ? splits : E->wsplit, E->mp, Wold, E->HHt, lam, Wnew, &E->state->flag);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -225,13 +225,34 @@ int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const 
     return NMFX_OK;
 }
 
-int nmfx_launch_obj_reduce(nmfx_engine* E) {
+int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj) {
     ProfScope ps(E, "small");
-    const int64_t nobj = (int64_t)(E->mp / 64) * E->wsplit;
+    if (nobj <= 0) nobj = (int64_t)(E->mp / 64) * E->wsplit;     // what the exact-f32 W phase writes
     hipLaunchKernelGGL(obj_reduce_kernel, dim3(1), dim3(256), 0, E->stream, E->obj_part, nobj, E->xf64,
                        &E->state->flag);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+
+// W / H epilogues of the exact-f32 path, callable from the split-bf16 path for k = 128
+int nmfx_launch_w_update(nmfx_engine* E, const float* Wold, float* Wnew, float lam, int splits) {
+    ProfScope ps(E, "w_update");
+    switch (E->kp) {
+        case 16: return launch_w_update<16>(E, Wold, Wnew, lam, splits);
+        case 32: return launch_w_update<32>(E, Wold, Wnew, lam, splits);
+        case 64: return launch_w_update<64>(E, Wold, Wnew, lam, splits);
+        default: return launch_w_update<128>(E, Wold, Wnew, lam, splits);
+    }
+}
+
+int nmfx_launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2) {
+    ProfScope ps(E, "h_update");
+    switch (E->kp) {
+        case 16: return launch_h_update<16>(E, lam, j, min_iter, tol1, tol2);
+        case 32: return launch_h_update<32>(E, lam, j, min_iter, tol1, tol2);
+        case 64: return launch_h_update<64>(E, lam, j, min_iter, tol1, tol2);
+        default: return launch_h_update<128>(E, lam, j, min_iter, tol1, tol2);
+    }
 }
 
 int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {

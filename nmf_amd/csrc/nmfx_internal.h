@@ -69,12 +69,14 @@ struct nmfx_engine {
     bool bf_ready = false;
     bool fused_pack = false;       // nmfx_mur_run (single GPU): no pack launch, h_update reads the slabs
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
+    bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
     float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
     float* Vt = nullptr;           // V^T, tile-major: [np/128][mp/64] tiles of [128][64] (bf16-path H phase)
     float* Bt_part = nullptr;      // [bt_split][np][kp]
     unsigned short *Whi[2] = {nullptr, nullptr}, *Wlo[2] = {nullptr, nullptr};   // [mp][kp]
     unsigned short *WThi = nullptr, *WTlo = nullptr;                              // [kp][mp]
     unsigned short *Hhi = nullptr, *Hlo = nullptr;   // [kp][np]
+    unsigned short *HThi = nullptr, *HTlo = nullptr; // [np][kp], only where H^T is the Z operand (AO-ADMM's fused objective)
     double* nrm_part = nullptr;    // [blocks][4]
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
@@ -112,11 +114,19 @@ int nmfx_launch_gram_nt(nmfx_engine* E, const float* X, int64_t cols, int64_t ld
 
 // shared small launchers (kernels_mur.hip / engine.hip)
 int nmfx_launch_sum_partials(nmfx_engine* E, const float* part, int splits, int64_t count, float* out);
+int nmfx_launch_w_update(nmfx_engine* E, const float* Wold, float* Wnew, float lam, int splits);
+int nmfx_launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2);
 int nmfx_launch_pack(nmfx_engine* E, const int* flag2 = nullptr);   // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
 int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const float* Gpart, int gsplit,
                           int64_t nobj);
-int nmfx_launch_obj_reduce(nmfx_engine* E);    // xf64[0] = sum obj_part
+int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj = 0);    // xf64[0] = sum obj_part (nobj 0: the f32 W phase's count)
 bool nmfx_bf16_supported(const nmfx_engine* E);
+int nmfx_bf16_prepare(nmfx_engine* E);
+int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
+int nmfx_bf16_images_h(nmfx_engine* E, bool transposed);
+int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name);
+int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name);
+int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nobj);
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);

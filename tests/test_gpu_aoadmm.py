@@ -43,7 +43,7 @@ def test_aoadmm_error_behaviour():
     with pytest.raises(np.linalg.LinAlgError):   # W = 0 -> Gram + rho I = 0 -> not PD (ao_admm.py:55)
         import nmf_amd.utils as U
         orig = U.initial_factors
-        U.initial_factors = lambda x, k, init, uniform=False: (np.zeros((40, 3)), np.abs(np.random.randn(3, 30)))
+        U.initial_factors = lambda x, k, init, **kw: (np.zeros((40, 3)), np.abs(np.random.randn(3, 30)))
         try:
             ao_admm(v, 3, max_iter=3, reg_h=(0, "nn"), nndsvd_init=(False, "zero"))
         finally:
@@ -59,3 +59,41 @@ def test_aoadmm_kl_matches_reference():
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
     np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-3)
     assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(520, 300, 40), (384, 640, 100)])
+def test_aoadmm_eu_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
+    """k in (32, 128]: the split-bf16 products (with the objective riding on the H-side product)
+    and the exact-f32 products must meet the same bars: WH error, objective history, stop index
+    and inner-iteration counts of the oracle."""
+    from oracle import nmf_ref as R
+    from nmf_amd.ao_admm import ao_admm
+    monkeypatch.setenv("NMFX_PRECISION", precision)
+    m, n, k = shape
+    v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+    kw = dict(distance_type="eu", reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=7, max_iter=7, admm_iter=10,
+              nndsvd_init=(True, "zero"))
+    ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    res = ao_admm(v.copy(), k, **kw)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
+
+
+def test_aoadmm_bf16_convergence_stop_matches_oracle(monkeypatch):
+    """The stop rule fires inside a batch: the lagged objective of the bf16 path must give the
+    reference's stop index and leave the pair the reference returns."""
+    from oracle import nmf_ref as R
+    from nmf_amd.ao_admm import ao_admm
+    monkeypatch.setenv("NMFX_PRECISION", "bf16")
+    m, n, k = 400, 260, 36
+    v = R.planted_matrix(m, n, k, seed=3, dtype=np.float32)
+    kw = dict(distance_type="eu", reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=3, max_iter=200, admm_iter=10,
+              tol1=1e-3, tol2=5e-2, nndsvd_init=(True, "zero"))
+    ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    res = ao_admm(v.copy(), k, **kw)
+    assert ref.trace["stop_rule"] and ref.i < 199
+    assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL

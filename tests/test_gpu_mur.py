@@ -98,9 +98,9 @@ def test_mur_kl_default_distance_is_kl_like_reference():
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(512, 384, 40), (640, 1000, 64), (200, 130, 33)])
+@pytest.mark.parametrize("shape", [(512, 384, 40), (640, 1000, 64), (200, 130, 33), (520, 700, 100), (384, 256, 128)])
 def test_mur_eu_k64_both_precisions_vs_oracle(precision, shape, monkeypatch):
-    """k in (32, 64] pads to 64, where the split-bf16 products are available
+    """k in (32, 128] pads to 64 or 128, where the split-bf16 products are available
     (NMFX_PRECISION=bf16).  Both arithmetic modes must meet the same bars."""
     from nmf_amd.mur import mur
     monkeypatch.setenv("NMFX_PRECISION", precision)
