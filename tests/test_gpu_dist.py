@@ -22,9 +22,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _case():
+def _case(k=12):
     from oracle import nmf_ref as R
-    m, n, k = 700, 330, 12
+    m, n = 700, 330
     v = R.planted_matrix(m, n, k, seed=21, dtype=np.float32)
     rs = np.random.RandomState(22)
     return m, n, k, v, np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
@@ -33,7 +33,7 @@ def _case():
 KW = dict(distance_type="eu", min_iter=14, max_iter=14, lambda_w=0.01, lambda_h=0.02)
 
 
-def _worker(rank, world, port, backend, outdir):
+def _worker(rank, world, port, backend, outdir, k=12):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
@@ -45,7 +45,7 @@ def _worker(rank, world, port, backend, outdir):
     torch.cuda.set_device(0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     from nmf_amd import dist as nd
-    m, n, k, v, w0, h0 = _case()
+    m, n, k, v, w0, h0 = _case(k)
     r0, r1 = nd.row_range(m, rank, world)
     shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
     comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
@@ -56,12 +56,13 @@ def _worker(rank, world, port, backend, outdir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("k", [12, 40, 100])     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
-def test_sharded_device_path(world, backend, tmp_path):
+def test_sharded_device_path(world, backend, k, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
-    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path)), nprocs=world, join=True)
-    m, n, k, v, w0, h0 = _case()
+    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), k), nprocs=world, join=True)
+    m, n, k, v, w0, h0 = _case(k)
     ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     w = np.concatenate([p["w"] for p in parts])
