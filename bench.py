@@ -193,6 +193,8 @@ def main():
             torch.cuda.synchronize()
 
     run(0, args.warmup)
+    if sharded:
+        run.ensure_graph(args.warmup)      # a capture still pending must not land in the timed region
     fence()
     if sharded and run.mode == "hipgraph" and args.warmup >= 4:
         # the replayed loop must have produced a sane history; if not, start over with the eager loop

@@ -234,6 +234,12 @@ class Runner:
             logging.warning("hipGraph capture of the sharded iteration failed (%s); running eagerly", exc)
             self.graph = None
 
+    def ensure_graph(self, done):
+        """Capture now (outside any timed region) if a capture is still pending and at least one
+        eager iteration has created the lazy state (allocations, RCCL communicator)."""
+        if self.want_graph and done >= 1:
+            self._capture()
+
     def __call__(self, first, count):
         if self.want_graph and first < 2:
             head = min(count, 2 - first)
