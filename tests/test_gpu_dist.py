@@ -135,8 +135,8 @@ def test_graphed_loop_equals_eager_loop(tmp_path):
 # ---- AO-ADMM and ANLS over row shards (device engine) ------------------------
 def _solver_case(solver):
     from oracle import nmf_ref as R
-    if solver == "ao_admm":
-        m, n, k = 520, 300, 12
+    if solver.startswith("ao_admm"):
+        m, n, k = 520, 300, (40 if solver.endswith("bf16") else 12)    # k = 40: split-bf16 products, lazy objective
         kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=8, max_iter=8, admm_iter=10)
     else:
         m, n, k = 200, 150, 6
@@ -162,8 +162,8 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
     r0, r1 = nd.row_range(m, rank, world)
     shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
     comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
-    res = (nd.aoadmm_sharded if solver == "ao_admm" else nd.anls_sharded)(shard, comm, batch=3, **kw)
-    inner = (shard.eng.inner_counts(0, res.i + 1) & 0xFFFF) if solver == "ao_admm" else np.zeros(0)
+    res = (nd.aoadmm_sharded if solver.startswith("ao_admm") else nd.anls_sharded)(shard, comm, batch=3, **kw)
+    inner = (shard.eng.inner_counts(0, res.i + 1) & 0xFFFF) if solver.startswith("ao_admm") else np.zeros(0)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
              inner=inner)
     shard.close()
@@ -171,14 +171,14 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["ao_admm", "anls"])
+@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "anls"])
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
     mp.spawn(_solver_gpu_worker, args=(world, _free_port(), backend, solver, str(tmp_path)), nprocs=world, join=True)
     m, n, k, v, w0, h0, kw = _solver_case(solver)
-    ref = (R.ao_admm if solver == "ao_admm" else R.anls)(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
+    ref = (R.ao_admm if solver.startswith("ao_admm") else R.anls)(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     w = np.concatenate([p["w"] for p in parts])
     h = parts[0]["h"]
@@ -188,5 +188,5 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-4)
         np.testing.assert_array_equal(p["h"], h)
-        if solver == "ao_admm":
+        if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
