@@ -268,6 +268,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->wsel = 0;
     E->have_f = true;
     E->bf_ready = false;
+    E->ht_ready = false;
     E->lazy_objective = false;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
@@ -392,7 +393,9 @@ int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) 
     if (distance == NMFX_EU)
         return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_eu_phase_a_bf16(E, lambda_w, j)
                                                              : nmfx_mur_eu_phase_a(E, lambda_w, j);
-    if (distance == NMFX_KL) return nmfx_mur_kl_phase_a(E, lambda_w, j);
+    if (distance == NMFX_KL)
+        return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_kl_phase_a_bf16(E, lambda_w, j)
+                                                             : nmfx_mur_kl_phase_a(E, lambda_w, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;
 }
 
@@ -406,7 +409,10 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
         return (E->precision == 1 && nmfx_bf16_supported(E))
                    ? nmfx_mur_eu_phase_b_bf16(E, lambda_h, min_iter, tol1, tol2, j)
                    : nmfx_mur_eu_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
-    if (distance == NMFX_KL) return nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
+    if (distance == NMFX_KL)
+        return (E->precision == 1 && nmfx_bf16_supported(E))
+                   ? nmfx_mur_kl_phase_b_bf16(E, lambda_h, min_iter, tol1, tol2, j)
+                   : nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;
 }
 

@@ -104,7 +104,15 @@ __device__ __forceinline__ uint2 lds_read_tr(const unsigned char* p) {
 
 // KP = 64 or 128 factors.  KP = 128: Y image 2 x 16 KiB per group (double buffered: 64 KiB), V ring
 // 3 deep, accumulators for 8 factor tiles, the Gram by-product is left to the Gram kernels.
-template <int KP, bool WITH_OBJ>
+//
+// KL = true (MUR with the KL divergence, nmf/mur.py:24-27, 40-43): A_part = (X / (Z Y + 1e-9)) Y^T.
+// The product Z Y comes FIRST (same transposed reads), the quotient is formed in registers in the
+// D layout (lane = row x, columns 16 e + 4 g + r) and is used as the A operand as it stands: the
+// contraction index of the A-product is PERMUTED (k-step s runs over the columns of e = 2s and
+// 2s + 1), and the B operand follows with two 8-byte reads of the same Y image instead of one
+// 16-byte read.  With WITH_OBJ the objective term x log(x / zy) - x + zy (nmf/utils.py:23-26) is
+// accumulated from the same registers.
+template <int KP, bool WITH_OBJ, bool KL>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -118,11 +126,12 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     constexpr int YBUF = 2 * YT;                      // Yhi tile, Ylo tile
     constexpr int VOFF = 2 * YBUF;                    // start of the V rings
     constexpr int VRING = (KP == 64) ? 4 : 3;         // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
-    constexpr bool WITH_GRAM = (KP == 64);
+    constexpr bool WITH_GRAM = (KP == 64) && !KL;
+    constexpr bool WITH_D = WITH_OBJ || KL;           // the product Z Y is formed
     constexpr int YPW = 2 * (KP / 8) / 4;             // Y pieces (8 rows x 128 B) per loader wave and group
     constexpr int NA = 2 * (NJT / 4);                 // pipeline stages of the A-product: (k-step, half of the tiles)
-    constexpr int ND = WITH_OBJ ? KP / 32 : 0;        // stages of the residual product: k-steps over the factors
-    constexpr int NS = NA + ND;
+    constexpr int ND = WITH_D ? KP / 32 : 0;          // stages of the product Z Y: k-steps over the factors
+    constexpr int NS = NA + ND;                       // order: A.. then D.. (Euclidean), D.. then A.. (KL)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a PROVABLY uniform value: everything derived from it (DMA bases, LDS
@@ -185,10 +194,13 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     };
 
     // ---- loop-invariant LDS read offsets ----
-    int ylane[2], vaoff[2][2], vroff[4], tro[4];
+    int ylane[2], ykl[2][2], vaoff[2][2], vroff[4], tro[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz(x));           // + 2048 * (factor tile) + YT * (lo image)
+        // KL: columns 32 s + 4 g .. + 3 and 32 s + 16 + 4 g .. + 3 of row x (8 bytes each)
+        ykl[s][0] = x * 128 + 16 * ((4 * s + (g >> 1)) ^ yswz(x)) + 8 * (g & 1);
+        ykl[s][1] = x * 128 + 16 * ((4 * s + 2 + (g >> 1)) ^ yswz(x)) + 8 * (g & 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) vaoff[s][h] = x * 256 + 16 * ((8 * s + 2 * g + h) ^ x);
     }
@@ -203,8 +215,8 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     }
     const unsigned char* vring = smem + VOFF + wave * (VRING * 4096);
 
-    Frag8 zh[WITH_OBJ ? KP / 32 : 1], zl[WITH_OBJ ? KP / 32 : 1];
-    if (WITH_OBJ) {
+    Frag8 zh[WITH_D ? KP / 32 : 1], zl[WITH_D ? KP / 32 : 1];
+    if (WITH_D) {
 #pragma unroll
         for (int s = 0; s < KP / 32; ++s) {
             zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + x) * KP + 32 * s + 8 * g);
@@ -254,16 +266,32 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         float4 va[2][2], vr[4];
         Frag8 fh[2][4], fl[2][4];                      // [register set][fragment]: hi and lo images
         auto issue = [&](int st, int set) {
-            if (st < NA) {                             // Y tile rows 16 jt.., k-step st / (NJT / 4)
-                const int ks = st / (NJT / 4), half = st % (NJT / 4);
-                const unsigned char* ys = ybuf + ylane[ks] + half * 4 * 2048;
+            const bool a_stage = KL ? st >= ND : st < NA;
+            if (a_stage) {                             // Y tile rows 16 jt.., k-step ast / (NJT / 4)
+                const int ast = KL ? st - ND : st;
+                const int ks = ast / (NJT / 4), half = ast % (NJT / 4);
+                if (KL) {
+                    const unsigned char* y0 = ybuf + ykl[ks][0] + half * 4 * 2048;
+                    const unsigned char* y1 = ybuf + ykl[ks][1] + half * 4 * 2048;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    fh[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048);
-                    fl[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048 + YT);
+                    for (int j = 0; j < 4; ++j) {
+                        const uint2 a0 = *reinterpret_cast<const uint2*>(y0 + j * 2048);
+                        const uint2 a1 = *reinterpret_cast<const uint2*>(y1 + j * 2048);
+                        const uint2 b0 = *reinterpret_cast<const uint2*>(y0 + j * 2048 + YT);
+                        const uint2 b1 = *reinterpret_cast<const uint2*>(y1 + j * 2048 + YT);
+                        fh[set][j].u = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        fl[set][j].u = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    }
+                } else {
+                    const unsigned char* ys = ybuf + ylane[ks] + half * 4 * 2048;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        fh[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048);
+                        fl[set][j].u = *reinterpret_cast<const uint4*>(ys + j * 2048 + YT);
+                    }
                 }
             } else {                                   // columns 16 e.. of factors 32 s.. 32 s + 31, transposed
-                const int s = st - NA;
+                const int s = KL ? st : st - NA;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned char* ts = ybuf + tro[e] + s * 4096;
@@ -274,19 +302,24 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 }
             }
         };
+        if (!KL) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) va[s][h] = *reinterpret_cast<const float4*>(vt + vaoff[s][h]);
-        if (WITH_OBJ) {
+                for (int h = 0; h < 2; ++h) va[s][h] = *reinterpret_cast<const float4*>(vt + vaoff[s][h]);
+        }
+        if (WITH_D) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) vr[e] = *reinterpret_cast<const float4*>(vt + vroff[e]);
         }
         issue(0, 0);
         NMFX_FENCE();
         Frag8 vh[2], vl[2];
+        if (!KL) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
+            for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
+        }
+        float klpart = 0.f;
         f32x4 d[4];                                    // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -295,8 +328,10 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             const int set = st & 1;
             if (st + 1 < NS) issue(st + 1, set ^ 1);
             NMFX_FENCE();
-            if (st < NA) {
-                const int ks = st / (NJT / 4), j0 = 4 * (st % (NJT / 4));
+            const bool a_stage = KL ? st >= ND : st < NA;
+            if (a_stage) {
+                const int ast = KL ? st - ND : st;
+                const int ks = ast / (NJT / 4), j0 = 4 * (ast % (NJT / 4));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vh[ks], fh[set][j], acc[j0 + j]);
 #pragma unroll
@@ -306,17 +341,47 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fl[set][j], acc[j0 + j]);
             } else {
-                const int s = st - NA;
+                const int s = KL ? st : st - NA;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zh[WITH_OBJ ? s : 0], d[e]);
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zh[WITH_D ? s : 0], d[e]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zh[WITH_OBJ ? s : 0], d[e]);
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zh[WITH_D ? s : 0], d[e]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zl[WITH_OBJ ? s : 0], d[e]);
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zl[WITH_D ? s : 0], d[e]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_OBJ ? s : 0], d[e]);
+                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_D ? s : 0], d[e]);
             }
             NMFX_FENCE();
+            if (KL && st == ND - 1) {
+                // quotient x / (zy + 1e-9) in the D layout = the A operand of the permuted k-steps;
+                // objective term x log(x / zy) [inf, nan -> 0] - x + zy
+                float qv[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float vv[4] = {vr[e].x, vr[e].y, vr[e].z, vr[e].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // v_rcp_f32 / v_log_f32 (1 ulp each) instead of IEEE division and logf: this
+                        // phase is VALU bound, and 0 * log(0 / p), x * log(x / 0) and 0 / 0 still come
+                        // out as nan / inf / nan and are zeroed exactly like utils.py:24 does
+                        const float pv = d[e][r];
+                        if (WITH_OBJ) {
+                            float t = vv[r] * (__builtin_amdgcn_logf(vv[r] * __builtin_amdgcn_rcpf(pv)) * 0.69314718055994531f);
+                            t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                            klpart += (t - vv[r]) + pv;
+                        }
+                        qv[e][r] = vv[r] * __builtin_amdgcn_rcpf(pv + 1e-9f);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    split2(qv[2 * ks][0], qv[2 * ks][1], vh[ks].u.x, vl[ks].u.x);
+                    split2(qv[2 * ks][2], qv[2 * ks][3], vh[ks].u.y, vl[ks].u.y);
+                    split2(qv[2 * ks + 1][0], qv[2 * ks + 1][1], vh[ks].u.z, vl[ks].u.z);
+                    split2(qv[2 * ks + 1][2], qv[2 * ks + 1][3], vh[ks].u.w, vl[ks].u.w);
+                }
+                NMFX_FENCE();
+            }
             if (WITH_GRAM && st == NA - 1 && do_gram) {
                 // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
                 // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
@@ -339,7 +404,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 }
             }
         }
-        if (WITH_OBJ) {
+        if (WITH_OBJ && !KL) {
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -349,6 +414,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             }
             osum += (double)part;
         }
+        if (WITH_OBJ && KL) osum += (double)klpart;
 #undef NMFX_FENCE
         ycur ^= 1;
         vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
@@ -379,7 +445,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < 8; ++w) t += red[w];
-            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * t;
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (KL ? 1.0 : 0.5) * t;
         }
     }
 }
@@ -683,14 +749,14 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 
 bool nmfx_bf16_supported(const nmfx_engine* E) { return (E->kp == 64 || E->kp == 128) && E->mp % 128 == 0 && E->np % 128 == 0; }
 
-template <int KP, bool OBJ>
+template <int KP, bool OBJ, bool KL>
 static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                         const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                         const unsigned short* Zlo, float* Apart, float* gram_part) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
     static bool attr = false;
-    auto kern = xyt_bf16_kernel<KP, OBJ>;
+    auto kern = xyt_bf16_kernel<KP, OBJ, KL>;
     if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
@@ -701,13 +767,17 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
 
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
-                      const unsigned short* Zlo, float* Apart, float* gram_part, const char* name) {
+                      const unsigned short* Zlo, float* Apart, float* gram_part, const char* name, bool kl = false) {
     ProfScope ps(E, name);
-    if (E->kp == 64)
-        return obj ? launch_xyt_t<64, true>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
-                   : launch_xyt_t<64, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part);
-    return obj ? launch_xyt_t<128, true>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
-               : launch_xyt_t<128, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part);
+#define NMFX_XYT(KP_, OBJ_, KL_) \
+    launch_xyt_t<KP_, OBJ_, KL_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
+    if (E->kp == 64) {
+        if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
+        return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
+    }
+    if (kl) return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
+    return obj ? NMFX_XYT(128, true, false) : NMFX_XYT(128, false, false);
+#undef NMFX_XYT
 }
 
 // Allocate the bf16 state and build V^T and the images of the initial factors.
@@ -770,17 +840,21 @@ int nmfx_bf16_images_h(nmfx_engine* E, bool transposed) {              // Hhi/Hl
 }
 
 // A_part[bf_wsplit][mp][kp] = V H^T (+ obj_part[(mp/128) * bf_wsplit] = residual objective of (W images `zbuf`, H))
-int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name) {
+// kl: A_part = (V / (W H + 1e-9)) H^T and the KL objective (the W images `zbuf` are then always read)
+int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl) {
+    const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                      obj ? E->Whi[zbuf] : nullptr, obj ? E->Wlo[zbuf] : nullptr, E->A_part,
-                      E->kp == 64 ? E->HHt_part : nullptr, name);
+                      z ? E->Whi[zbuf] : nullptr, z ? E->Wlo[zbuf] : nullptr, E->A_part,
+                      E->kp == 64 ? E->HHt_part : nullptr, name, kl);
 }
 
 // Bt_part[bt_split][np][kp] = V^T W (+ obj_part[(np/128) * bt_split] = residual objective, Z = H^T images)
-int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name) {
+// kl: Bt_part = (V / (W H + 1e-9))^T W
+int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl) {
+    const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                      obj ? E->HThi : nullptr, obj ? E->HTlo : nullptr, E->Bt_part,
-                      E->kp == 64 ? E->G_part : nullptr, name);
+                      z ? E->HThi : nullptr, z ? E->HTlo : nullptr, E->Bt_part,
+                      E->kp == 64 ? E->G_part : nullptr, name, kl);
 }
 
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part

@@ -294,6 +294,75 @@ int nmfx_mur_kl_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, doubl
     return NMFX_OK;
 }
 
+// ---- split-bf16 products (kp = 64 / 128): the two quotient products of an iteration on the bf16
+// MFMA (xyt_bf16_kernel<.., KL = true>), everything else as above ----
+// part[blk][j] = sum over the block's 128 rows of W[r][j]   (coalesced along j)
+__global__ __launch_bounds__(256) void col_sums_part_kernel(const float* __restrict__ W, int kp, float* __restrict__ part,
+                                                            const int* __restrict__ flag)
+{
+    if (*flag) return;
+    __shared__ float sh[256];
+    const int j = threadIdx.x % kp, rl = threadIdx.x / kp, nrl = 256 / kp;
+    const float* p = W + (int64_t)blockIdx.x * 128 * kp;
+    float s = 0.f;
+    for (int r = rl; r < 128; r += nrl) s += p[(int64_t)r * kp + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int t = 1; t < nrl; ++t) s += sh[t * kp + j];
+        part[(int64_t)blockIdx.x * kp + j] = s;
+    }
+}
+
+__global__ __launch_bounds__(128) void col_sums_final_kernel(const float* __restrict__ part, int nblk, int kp,
+                                                             float* __restrict__ out, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int j = threadIdx.x;
+    if (j >= kp) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * kp + j];
+    out[j] = s;
+}
+
+int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
+    int rc;
+    if (!E->bf_ready) E->wsel = (int)(j & 1);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    const int cur = (int)(j & 1), nxt = cur ^ 1;
+    const float* Wold = E->W[cur];
+    float* Wnew = E->W[nxt];
+    if (!E->ht_ready) { if ((rc = nmfx_bf16_images_h(E, true))) return rc; E->ht_ready = true; }
+    { ProfScope ps(E, "row_sums");        // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
+      hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)E->kp), dim3(256), 0, E->stream, E->H, E->np, E->np,
+                         E->HHt, &E->state->flag);
+      NMFX_HIP(hipGetLastError()); }
+    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", true))) return rc;
+    { ProfScope ps(E, "w_update");
+      const int64_t count = E->mp * E->kp;
+      hipLaunchKernelGGL(kl_w_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, E->stream,
+                         E->A_part, E->bf_wsplit, count, E->kp, E->k, Wold, E->HHt, (float)lambda_w, Wnew,
+                         &E->state->flag);
+      NMFX_HIP(hipGetLastError()); }
+    if ((rc = nmfx_bf16_images_w(E, Wnew, nxt))) return rc;
+    if ((rc = nmfx_bf16_vtw(E, false, "hphase", true))) return rc;
+    { ProfScope ps(E, "row_sums");        // d = W^T 1 into the first kp floats of G_part, slabs behind it
+      const int nblk = (int)(E->mp / 128);
+      float* part = E->B_part;                                   // scratch: the exact-f32 H phase's slabs are unused here
+      hipLaunchKernelGGL(col_sums_part_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, Wnew, E->kp, part,
+                         &E->state->flag);
+      hipLaunchKernelGGL(col_sums_final_kernel, dim3(1), dim3(128), 0, E->stream, part, nblk, E->kp, E->G_part,
+                         &E->state->flag);
+      NMFX_HIP(hipGetLastError()); }
+    return nmfx_bf16_pack_t(E, E->G_part, 1, (int64_t)(E->mp / 128) * E->bf_wsplit);
+}
+
+int nmfx_mur_kl_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    if ((rc = nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    return nmfx_bf16_images_h(E, true);                          // Hhi/Hlo (next W phase) and H^T images (next H phase)
+}
+
 int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j) {
     int rc;
     if ((rc = nmfx_launch_wphase(E, E->W[j & 1], false, true, true))) return rc;

@@ -115,6 +115,26 @@ def test_mur_eu_k64_both_precisions_vs_oracle(precision, shape, monkeypatch):
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=OBJ_RTOL)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(512, 384, 40), (300, 520, 100), (200, 130, 33)])
+def test_mur_kl_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
+    """KL divergence with k in (32, 128]: the quotient products on the split-bf16 kernels (KL mode:
+    product first, quotient in registers, permuted contraction) against the exact-f32 kernels and
+    the oracle."""
+    from nmf_amd.mur import mur
+    monkeypatch.setenv("NMFX_PRECISION", precision)
+    m, n, k = shape
+    v = R.planted_matrix(m, n, k, seed=m + n, dtype=np.float32)
+    kw = dict(distance_type="kl", min_iter=25, max_iter=25, lambda_w=0.02, lambda_h=0.01)
+    np.random.seed(11)
+    res = mur(v.copy(), k, **kw)
+    np.random.seed(11)
+    ref = R.mur(v.astype(np.float64), k, **kw)
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    assert err < WH_TOL, err
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-3)
+
+
 def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
     from nmf_amd.mur import mur
     v = R.planted_matrix(300, 260, 36, seed=77, dtype=np.float32)
