@@ -367,6 +367,237 @@ __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
     if (threadIdx.x == 0) { *slot = count | (fired << 16); st->inner_stop = 0; }
 }
 
+// ---- all rounds of a sub-problem in ONE launch ------------------------------
+// A round only couples the blocks through `terminate` (four global norms, ao_admm.py:33-43).
+// The fused kernels therefore run ALL admm_iter rounds speculatively with X, U (and the
+// right-hand side) resident in registers / LDS, leave the per-round norm partials in
+// nrm_rounds[round][block][4] and a copy of the initial X, U in the backup buffers.
+// ao_fused_decide_kernel then finds the round at which the reference would have stopped; if that
+// is before the last round, the same kernel is launched again in REPAIR mode: it restarts from
+// the backup and runs exactly that many rounds (the common case -- no early stop -- costs one
+// no-op launch).  Same arithmetic, same norm partials, same inner counts as the round-by-round
+// kernels above, 3 launches instead of admm_iter + 1.
+//
+// H side: block = 64 columns, wave w owns the factor tiles w, w + 4, ...; M^-1 staged in LDS once.
+template <int KP>
+__global__ __launch_bounds__(256) void ao_fused_cols_kernel(
+    const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
+    float* __restrict__ Ub, const float* __restrict__ Minv, int64_t np, int prox, float lam, int admm_iter,
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair)
+{
+    if (st->flag) return;
+    int rounds = admm_iter;
+    if (repair) {
+        rounds = st->inner_count;
+        if (rounds >= admm_iter) return;               // nothing to repair: the speculative result stands
+    }
+    constexpr int JT = KP / 16;
+    constexpr int ITW = (JT + 3) / 4;
+    constexpr int LDM = KP + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [KP][64] | M^-1 [KP][LDM] | 16 doubles
+    float* ms = lds + KP * 64;
+    double* sh = reinterpret_cast<double*>(ms + KP * LDM);
+    const int nblk = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    for (int i = tid; i < KP * (KP / 4); i += 256) {
+        const int r = i / (KP / 4), c4 = i % (KP / 4);
+        *reinterpret_cast<float4*>(ms + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
+    }
+    // this wave's part of X, U, B in the accumulator layout: [r][g] = rows 16 it + 4 q + g, columns 4 x .. 4 x + 3
+    float4 hx[ITW][4], ux[ITW][4], bx[ITW][4];
+    const float* srcX = repair ? Xb : X;
+    const float* srcU = repair ? Ub : U;
+#pragma unroll
+    for (int r = 0; r < ITW; ++r) {
+        const int it = wave + 4 * r;
+        if (it < JT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
+                hx[r][g] = *reinterpret_cast<const float4*>(srcX + idx);
+                ux[r][g] = *reinterpret_cast<const float4*>(srcU + idx);
+                bx[r][g] = *reinterpret_cast<const float4*>(Bsum + idx);
+                if (!repair) {
+                    *reinterpret_cast<float4*>(Xb + idx) = hx[r][g];
+                    *reinterpret_cast<float4*>(Ub + idx) = ux[r][g];
+                }
+            }
+        }
+    }
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+        // RHS = B + rho (X + U), every wave its own factor rows
+#pragma unroll
+        for (int r = 0; r < ITW; ++r) {
+            const int it = wave + 4 * r;
+            if (it < JT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 t;
+                    t.x = bx[r][g].x + rho * (hx[r][g].x + ux[r][g].x); t.y = bx[r][g].y + rho * (hx[r][g].y + ux[r][g].y);
+                    t.z = bx[r][g].z + rho * (hx[r][g].z + ux[r][g].z); t.w = bx[r][g].w + rho * (hx[r][g].w + ux[r][g].w);
+                    *reinterpret_cast<float4*>(lds + (16 * it + 4 * q + g) * 64 + 4 * x) = t;
+                }
+            }
+        }
+        __syncthreads();
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < ITW; ++r) {
+            const int it = wave + 4 * r;
+            if (it < JT) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < JT; ++u) {
+                    const float4 mf = *reinterpret_cast<const float4*>(ms + (16 * it + x) * LDM + 16 * u + 4 * q);
+                    const float ma[4] = {mf.x, mf.y, mf.z, mf.w};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const float4 rb = *reinterpret_cast<const float4*>(lds + (16 * u + 4 * q + s2) * 64 + 4 * x);
+                        acc[0] = MFMA(ma[s2], rb.x, acc[0]);
+                        acc[1] = MFMA(ma[s2], rb.y, acc[1]);
+                        acc[2] = MFMA(ma[s2], rb.z, acc[2]);
+                        acc[3] = MFMA(ma[s2], rb.w, acc[3]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float ax[4] = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+                    const float ho[4] = {hx[r][g].x, hx[r][g].y, hx[r][g].z, hx[r][g].w};
+                    const float uo[4] = {ux[r][g].x, ux[r][g].y, ux[r][g].z, ux[r][g].w};
+                    float hn[4], un[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hn[e] = prox_apply(ax[e], uo[e], shift);
+                        un[e] = uo[e] + hn[e] - ax[e];
+                        const float d0 = hn[e] - ax[e], d2 = hn[e] - ho[e];
+                        n0 += d0 * d0; n1 += hn[e] * hn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
+                    }
+                    hx[r][g] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                    ux[r][g] = make_float4(un[0], un[1], un[2], un[3]);
+                }
+            }
+        }
+        if (!repair) block_store_norms<4>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
+        __syncthreads();                               // the RHS tile is rewritten next round
+    }
+#pragma unroll
+    for (int r = 0; r < ITW; ++r) {
+        const int it = wave + 4 * r;
+        if (it < JT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
+                *reinterpret_cast<float4*>(X + idx) = hx[r][g];
+                *reinterpret_cast<float4*>(U + idx) = ux[r][g];
+            }
+        }
+    }
+}
+
+// W side: block = 64 rows (4 waves x 16), M^-1 in LDS; the right-hand side of a wave's 16 rows is
+// turned from the accumulator layout to the A-operand layout through a wave-private LDS tile.
+template <int KP>
+__global__ __launch_bounds__(256) void ao_fused_rows_kernel(
+    const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
+    float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair)
+{
+    if (st->flag) return;
+    int rounds = admm_iter;
+    if (repair) {
+        rounds = st->inner_count;
+        if (rounds >= admm_iter) return;
+    }
+    constexpr int JT = KP / 16;
+    constexpr int LDM = KP + 4;
+    constexpr int LDR = KP + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS 4 x [16][LDR] | 16 doubles
+    float* rs = lds + KP * LDM;
+    double* sh = reinterpret_cast<double*>(rs + 64 * LDR);
+    const int nblk = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    for (int i = tid; i < KP * (KP / 4); i += 256) {
+        const int r = i / (KP / 4), c4 = i % (KP / 4);
+        *reinterpret_cast<float4*>(lds + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    float* myrs = rs + wave * 16 * LDR;
+    // accumulator layout: [it][g] = row 4 q + g, column 16 it + x
+    float wx[JT][4], dx[JT][4], ax0[JT][4];
+    const float* srcX = repair ? Xb : X;
+    const float* srcU = repair ? Ub : U;
+#pragma unroll
+    for (int it = 0; it < JT; ++it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
+            wx[it][g] = srcX[idx]; dx[it][g] = srcU[idx]; ax0[it][g] = Asum[idx];
+            if (!repair) { Xb[idx] = wx[it][g]; Ub[idx] = dx[it][g]; }
+        }
+    __syncthreads();                                   // M^-1 is in place
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+#pragma unroll
+        for (int it = 0; it < JT; ++it)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) myrs[(4 * q + g) * LDR + 16 * it + x] = ax0[it][g] + rho * (wx[it][g] + dx[it][g]);
+        __syncthreads();
+        float4 xf[JT];
+#pragma unroll
+        for (int u = 0; u < JT; ++u) xf[u] = *reinterpret_cast<const float4*>(myrs + x * LDR + 16 * u + 4 * q);
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+        for (int it = 0; it < JT; ++it) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < JT; ++u) {
+                const float4 mb = *reinterpret_cast<const float4*>(lds + (16 * it + x) * LDM + 16 * u + 4 * q);
+                acc = MFMA(xf[u].x, mb.x, acc);
+                acc = MFMA(xf[u].y, mb.y, acc);
+                acc = MFMA(xf[u].z, mb.z, acc);
+                acc = MFMA(xf[u].w, mb.w, acc);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float w = wx[it][g], d = dx[it][g], ax = acc[g];
+                const float wn = prox_apply(ax, d, shift);
+                const float dn = d + wn - ax;
+                const float d0 = wn - ax, d2 = wn - w;
+                n0 += d0 * d0; n1 += wn * wn; n2 += d2 * d2; n3 += dn * dn;
+                wx[it][g] = wn; dx[it][g] = dn;
+            }
+        }
+        if (!repair) block_store_norms<4>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < JT; ++it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
+            X[idx] = wx[it][g]; U[idx] = dx[it][g];
+        }
+}
+
+// The round at which `terminate` first fires decides how many rounds count: inner_count (what the
+// repair launch restarts for) and the (rounds | fired << 16) word of this sub-problem.
+__global__ __launch_bounds__(256) void ao_fused_decide_kernel(
+    DevState* __restrict__ st, const double* __restrict__ nrm_rounds, int nblk, int admm_iter, int32_t* __restrict__ slot)
+{
+    if (st->flag) return;
+    __shared__ double sh[16];
+    int count = admm_iter, fired = 0;
+    for (int r = 0; r < admm_iter; ++r)
+        if (inner_round_fired(nrm_rounds + (int64_t)r * nblk * 4, nblk, sh)) { count = r + 1; fired = 1; break; }
+    if (threadIdx.x == 0) { st->inner_count = count; st->inner_stop = 0; *slot = count | (fired << 16); }
+}
+
 // Row-sharded runs: this rank's four norm sums of round `round` -> out[0..3] (fixed order), to be
 // all-reduced by the caller before the next round looks at them.
 __global__ __launch_bounds__(256) void ao_norm_gather_kernel(
@@ -542,11 +773,89 @@ static int ao_final_objective(nmfx_engine* E) {
     return nmfx_launch_obj_reduce(E);
 }
 
+// All rounds of a sub-problem in three launches (see ao_fused_cols_kernel).  NMFX_AO_FUSED=0 keeps
+// the round-by-round kernels (they remain the path of the row-sharded W sub-problem, whose norms
+// cross ranks every round).
+static bool ao_fused_enabled(const nmfx_engine* E, int admm_iter) {
+    static const bool on = !(getenv("NMFX_AO_FUSED") && atoi(getenv("NMFX_AO_FUSED")) == 0);
+    return on && admm_iter >= 2 && E->kp >= 16;
+}
+
+static int ao_fused_alloc(nmfx_engine* E, int admm_iter) {
+    int rc;
+    const int64_t big = std::max(E->mp, E->np) * E->kp;
+    if ((rc = lazy_alloc(E, &E->bkX, big))) return rc;
+    if ((rc = lazy_alloc(E, &E->bkU, big))) return rc;
+    const int64_t need = (int64_t)admm_iter * (std::max(E->mp, E->np) / 64) * 4 + 64;
+    if (need > E->nrm_rounds_cap) {
+        if (E->nrm_rounds) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->nrm_rounds); E->nrm_rounds = nullptr; }
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->nrm_rounds), (size_t)need * sizeof(double)));
+        NMFX_HIP(hipMemsetAsync(E->nrm_rounds, 0, (size_t)need * sizeof(double), E->stream));
+        E->nrm_rounds_cap = need;
+    }
+    return NMFX_OK;
+}
+
+template <int KP>
+static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter, int repair) {
+    const size_t shm = (size_t)(KP * 64 + KP * (KP + 4)) * sizeof(float) + 16 * sizeof(double);
+    auto kern = ao_fused_cols_kernel<KP>;
+    if (shm > 64 * 1024)
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
+                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, repair);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+template <int KP>
+static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair) {
+    const size_t shm = (size_t)(KP * (KP + 4) + 64 * (KP + 4)) * sizeof(float) + 16 * sizeof(double);
+    auto kern = ao_fused_rows_kernel<KP>;
+    if (shm > 64 * 1024)
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, E->auxW, W, E->dualW, E->bkX, E->bkU,
+                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, float lam, int admm_iter, int32_t* slot) {
+    int rc;
+    if ((rc = ao_fused_alloc(E, admm_iter))) return rc;
+    for (int repair = 0; repair < 2; ++repair) {
+        if (cols) {
+            switch (E->kp) {
+                case 16: rc = launch_fused_cols<16>(E, prox, lam, admm_iter, repair); break;
+                case 32: rc = launch_fused_cols<32>(E, prox, lam, admm_iter, repair); break;
+                case 64: rc = launch_fused_cols<64>(E, prox, lam, admm_iter, repair); break;
+                default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, repair); break;
+            }
+        } else {
+            switch (E->kp) {
+                case 16: rc = launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair); break;
+                case 32: rc = launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair); break;
+                case 64: rc = launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair); break;
+                default: rc = launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair); break;
+            }
+        }
+        if (rc) return rc;
+        if (repair == 0) {
+            hipLaunchKernelGGL(ao_fused_decide_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_rounds,
+                               (int)((cols ? E->np : E->mp) / 64), admm_iter, slot);
+            NMFX_HIP(hipGetLastError());
+        }
+    }
+    return NMFX_OK;
+}
+
 static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, int64_t min_iter, double tol1,
                       double tol2, int64_t j) {
     int rc;
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
     ProfScope ps(E, "inner_h");
+    if (ao_fused_enabled(E, admm_iter))
+        return ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2);
     for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
     return nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2);
 }
@@ -582,8 +891,12 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
     if ((rc = ao_w_products(E, j, min_iter, tol1, tol2))) return rc;
     { ProfScope ps(E, "inner_w");
-      for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
-      if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc; }
+      if (ao_fused_enabled(E, admm_iter)) {
+          if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+      } else {
+          for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
+          if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+      } }
     // ---- objective of the new pair (utils.py:29), summed by the next pack / finish ----
     return ao_new_pair_objective(E);
 }

@@ -79,6 +79,9 @@ struct nmfx_engine {
     unsigned short *Hhi = nullptr, *Hlo = nullptr;   // [kp][np]
     unsigned short *HThi = nullptr, *HTlo = nullptr; // [np][kp], only where H^T is the Z operand (AO-ADMM's fused objective)
     double* nrm_part = nullptr;    // [blocks][4]
+    double* nrm_rounds = nullptr;  // [admm_iter][blocks][4]: norm partials of the fused inner rounds
+    int64_t nrm_rounds_cap = 0;
+    float *bkX = nullptr, *bkU = nullptr;   // initial X, U of a fused sub-problem (restart point of the repair launch)
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
     // split configuration
     int wsplit = 1, hsplit = 1, gsplit = 1;
