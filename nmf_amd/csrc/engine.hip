@@ -122,7 +122,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     const int64_t htarget = (ev = getenv("NMFX_HBLOCKS")) ? atoll(ev) : (int64_t)ncu * hocc;
     int64_t ws = std::max<int64_t>(1, (wtarget + rb / 2) / rb); ws = std::min<int64_t>(ws, std::max<int64_t>(1, cb / 4));
     int64_t hs = std::max<int64_t>(1, (htarget + cb / 2) / cb); hs = std::min<int64_t>(hs, rb);
-    int64_t gs = std::min<int64_t>(8, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));
+    int64_t gs = std::min<int64_t>(32, std::max<int64_t>(1, std::min(E->mp, E->np) / 256));   // Gram kernels: gs x kp/16 blocks
     E->wsplit = (int)ws; E->hsplit = (int)hs; E->gsplit = (int)gs;
     const int64_t kp = E->kp, mp = E->mp, np = E->np;
     TRY(dev_alloc(E, &E->V, mp * np));
