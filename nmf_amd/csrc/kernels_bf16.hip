@@ -524,13 +524,35 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
-    if (*flag) return;
     constexpr int KP = 64, RB = 64, LDW = 68, LDH = 80;          // padded LDS rows: conflict-free dword reads
     __shared__ __attribute__((aligned(16))) float hs[KP * LDH];  // H H^T, later the product tile D [row][LDW]
     __shared__ __attribute__((aligned(16))) float ws[RB * LDW];
     __shared__ unsigned short th[KP][RB + 2], tl[KP][RB + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * RB;
+    // The kernel is a chain of dependent memory round trips, so everything that can be requested up
+    // front is: the stop flag, and the A slabs of this thread's 16 outputs (epilogue layout: row
+    // tid / 4, factors 16 (tid % 4) ..), whose latency then hides under the H H^T sum and the MFMAs.
+    const int stop = *flag;
+    const int64_t eidx = (r0 + (tid >> 2)) * KP + 16 * (tid & 3);
+    float a[16] = {};
+    for (int p0 = 0; p0 < wsplit; p0 += 4) {
+        float4 t[4][4];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4)
+                t[pp][v4] = (p0 + pp < wsplit)
+                    ? *reinterpret_cast<const float4*>(Apart + (int64_t)(p0 + pp) * mp * KP + eidx + 4 * v4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                a[4 * v4] += t[pp][v4].x; a[4 * v4 + 1] += t[pp][v4].y; a[4 * v4 + 2] += t[pp][v4].z; a[4 * v4 + 3] += t[pp][v4].w;
+            }
+    }
+    if (stop) return;
     {   // H H^T = sum of the W phase's by-product slabs (fixed order); the loads of four slabs
         // (16 x 16 bytes per thread) are in flight together -- a short row shard has many slabs
         float v[4][4] = {};
@@ -581,23 +603,7 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     {   // epilogue, vectorised along the factor index: thread = (row, 16 consecutive j)
         const int row = tid >> 2, j0 = 16 * (tid & 3);
         const int64_t idx = (r0 + row) * KP + j0;
-        float a[16] = {}, wn[16];
-        for (int p0 = 0; p0 < wsplit; p0 += 4) {
-            float4 t[4][4];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4)
-                    t[pp][v4] = (p0 + pp < wsplit)
-                        ? *reinterpret_cast<const float4*>(Apart + (int64_t)(p0 + pp) * mp * KP + idx + 4 * v4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) {
-                    a[4 * v4] += t[pp][v4].x; a[4 * v4 + 1] += t[pp][v4].y; a[4 * v4 + 2] += t[pp][v4].z; a[4 * v4 + 3] += t[pp][v4].w;
-                }
-        }
+        float wn[16];
         unsigned ph[8], pl[8];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -643,7 +649,6 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo)
 {
-    if (st->flag) return;
     constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDG]
@@ -651,50 +656,66 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
     __shared__ double shd[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * CB;
+    const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
+    // A chain of dependent memory round trips: request everything that does not depend on a decision
+    // first -- the stop flag, the objective partials, the H tile, and the G / B^T slabs two at a time
+    // (16 x 16 bytes per thread in flight) -- and decide afterwards.
+    const int stop = st->flag;
+    double sacc = 0.0;
+    if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += 256) sacc += osrc[i]; }
+    else sacc = osrc[0];
+    float4 ht[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u;
+        ht[u] = *reinterpret_cast<const float4*>(H + (int64_t)(i >> 4) * np + c0 + 4 * (i & 15));
+    }
+    float g[4][4] = {}, b[4][4] = {};
+    {   // G and the B^T tile: slab sums (fixed order)
+        const int nslab = FROM_SLABS ? (gsplit > bsplit ? gsplit : bsplit) : 1;
+        for (int p0 = 0; p0 < nslab; p0 += 2) {
+            float4 tg[2][4], tb[2][4];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const bool pg = p0 + pp < (FROM_SLABS ? gsplit : 1), pb = p0 + pp < (FROM_SLABS ? bsplit : 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + 256 * u;
+                    tg[pp][u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)(p0 + pp) * kk)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    tb[pp][u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)(p0 + pp) * bn + (c0 + (i >> 4)) * KP + 4 * (i & 15))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    g[u][0] += tg[pp][u].x; g[u][1] += tg[pp][u].y; g[u][2] += tg[pp][u].z; g[u][3] += tg[pp][u].w;
+                    b[u][0] += tb[pp][u].x; b[u][1] += tb[pp][u].y; b[u][2] += tb[pp][u].z; b[u][3] += tb[pp][u].w;
+                }
+        }
+    }
+    if (stop) return;
     double obj;
     if (FROM_SLABS) {                                  // same fixed-order sum in every block
-        double sacc = 0.0;
-        for (int64_t i = tid; i < nobj; i += 256) sacc += osrc[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
         if (lane == 0) shd[wave] = sacc;
         __syncthreads();
         obj = ((shd[0] + shd[1]) + shd[2]) + shd[3];
     } else {
-        obj = osrc[0];
+        obj = sacc;
     }
     const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2,
                                            blockIdx.x == 0 && tid == 0);
     if (rule) return;
-    const int64_t c0 = (int64_t)blockIdx.x * CB;
-    const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
-    {   // G and the B^T tile: slab sums with 8 independent 16-byte loads per slab round
-        float g[4][4] = {}, b[4][4] = {};
-        const int nslab = FROM_SLABS ? (gsplit > bsplit ? gsplit : bsplit) : 1;
-        for (int p = 0; p < nslab; ++p) {
-            float4 tg[4], tb[4];
-            const bool pg = p < gsplit, pb = p < bsplit;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = tid + 256 * u;
-                tg[u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)p * kk)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                tb[u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)p * bn + (c0 + (i >> 4)) * KP + 4 * (i & 15))
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g[u][0] += tg[u].x; g[u][1] += tg[u].y; g[u][2] += tg[u].z; g[u][3] += tg[u].w;
-                b[u][0] += tb[u].x; b[u][1] += tb[u].y; b[u][2] += tb[u].z; b[u][3] += tb[u].w;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u;
-            *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) =
-                *reinterpret_cast<const float4*>(H + (int64_t)(i >> 4) * np + c0 + 4 * (i & 15));
-            *reinterpret_cast<float4*>(gs + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
-            *reinterpret_cast<float4*>(bt + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
-        }
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u;
+        *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) = ht[u];
+        *reinterpret_cast<float4*>(gs + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
+        *reinterpret_cast<float4*>(bt + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
     }
     __syncthreads();
     // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows, 4 column tiles
