@@ -30,16 +30,42 @@ static int admm_alloc(nmfx_engine* E) {
     return NMFX_OK;
 }
 
+static bool admm_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_bf16_supported(E); }
+
+// objective partials of (W, H) (admm.py:324); split-bf16: one pass of the product kernel with
+// Y = H, Z = W (its A output is not used)
+static int admm_objective(nmfx_engine* E) {
+    int rc;
+    if (!admm_bf16(E)) return nmfx_launch_wphase(E, E->W[0], false, true);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+    return nmfx_bf16_vht(E, true, 1, "objective");
+}
+
 static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
                              int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     float* W = E->W[0];
     const int64_t kk = (int64_t)E->kp * E->kp;
+    const bool bf = admm_bf16(E);
     // ---- h_aux and the H half ----
+    if (bf) {       // w_aux^T V and w_aux^T w_aux on the split-bf16 kernel (kp = 64: the Gram is its by-product)
+        const int64_t nobj = E->obj_count;             // the objective pass that ended the previous iteration
+        if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;
+        if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
+        if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, E->bt_split, nobj);
+        else {
+            if ((rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
+            rc = nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj);
+        }
+        if (rc) return rc;
+    } else {
     const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
     if (!fuse_g && (rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_hphase(E, E->auxW, fuse_g))) return rc;
     if ((rc = nmfx_launch_pack(E))) return rc;
+    }
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
     { ProfScope ps(E, "inner_h");
       if (prox_h == NMFX_PROX_L2N) {
@@ -47,11 +73,21 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
           if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
       } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc; }
     // ---- w_aux (from the NEW h_aux) and the W half ----
+    if (bf) {
+        const bool byprod = E->kp == 64;               // h_aux h_aux^T as a by-product
+        if ((rc = nmfx_bf16_images_h(E, false, E->auxH))) return rc;
+        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
+        if (!byprod && (rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+        { ProfScope ps(E, "sums");
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+          if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc; }
+    } else {
     if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->auxH))) return rc;
     { ProfScope ps(E, "sums");
       if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
       if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc; }
+    }
     if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, rho))) return rc;
     { ProfScope ps(E, "inner_w");
       if (prox_w == NMFX_PROX_L2N) {
@@ -59,7 +95,7 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
           if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
       } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc; }
     // ---- objective of (w, h) (admm.py:324) ----
-    return nmfx_launch_wphase(E, W, false, true);
+    return admm_objective(E);
 }
 
 // KL loss (admm.py:303-315): the Gram right-hand sides multiply S = v_aux + dual_v, and
@@ -127,8 +163,11 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
         // w_aux = w, h_aux = h (admm.py:27-28); obj[0] (admm.py:289)
         NMFX_HIP(hipMemcpyAsync(E->auxW, E->W[0], (size_t)E->mp * E->kp * 4, hipMemcpyDeviceToDevice, E->stream));
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
-        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
+        if (distance == NMFX_EU) rc = admm_objective(E);
+        else rc = nmfx_launch_wphase(E, E->W[0], false, true, true);
+        if (rc) return rc;
     }
+    if (distance == NMFX_EU && admm_bf16(E) && (rc = nmfx_bf16_prepare(E))) return rc;
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)

@@ -790,6 +790,7 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name, bool kl = false) {
     ProfScope ps(E, name);
+    if (obj) E->obj_count = (R / 128) * splits;
 #define NMFX_XYT(KP_, OBJ_, KL_) \
     launch_xyt_t<KP_, OBJ_, KL_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
     if (E->kp == 64) {
@@ -846,7 +847,7 @@ int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf) {      // Whi/Wl
     return NMFX_OK;
 }
 
-int nmfx_bf16_images_h(nmfx_engine* E, bool transposed) {              // Hhi/Hlo ([kp][np]) (+ HThi/HTlo ([np][kp]))
+int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src) {   // Hhi/Hlo ([kp][np]) (+ HThi/HTlo ([np][kp])) of src (default H)
     ProfScope ps(E, "images");
     int rc;
     if (transposed) {
@@ -854,7 +855,7 @@ int nmfx_bf16_images_h(nmfx_engine* E, bool transposed) {              // Hhi/Hl
         if ((rc = lazy_alloc(E, &E->HTlo, (int64_t)E->kp * E->np))) return rc;
     }
     hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(E->np / 64), (unsigned)(E->kp / 64)), dim3(256), 0, E->stream,
-                       E->H, (int64_t)E->kp, E->np, E->np, E->Hhi, E->Hlo, transposed ? E->HThi : nullptr,
+                       src ? src : E->H, (int64_t)E->kp, E->np, E->np, E->Hhi, E->Hlo, transposed ? E->HThi : nullptr,
                        transposed ? E->HTlo : nullptr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

@@ -623,6 +623,7 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(    // X X^T, X [KP][ld]
 template <int KP>
 static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc,
                            const float* Vsrc, const int* flag2) {
+    if (with_obj) E->obj_count = (int64_t)(E->mp / 64) * E->wsplit;
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)(2 * KP * 64 + 4 * 16 * 64) * sizeof(float);
     const int ng = (int)(E->np / 64);

@@ -69,6 +69,7 @@ struct nmfx_engine {
     bool bf_ready = false;
     bool fused_pack = false;       // nmfx_mur_run (single GPU): no pack launch, h_update reads the slabs
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
+    int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     bool ht_ready = false;         // H^T images are current (KL split-bf16 path)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
     float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
@@ -127,7 +128,7 @@ int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj = 0);    // xf64[0] = su
 bool nmfx_bf16_supported(const nmfx_engine* E);
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
-int nmfx_bf16_images_h(nmfx_engine* E, bool transposed);
+int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
 int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl = false);
 int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl = false);
 int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);

@@ -29,3 +29,22 @@ def test_admm_default_l2n_runs_like_reference():
     res = admm(v, 4, min_iter=6, max_iter=6)
     ref = R.admm(v.copy(), 4, min_iter=6, max_iter=6)
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,reg_h", [((520, 300, 40), (0.05, "l1n")), ((384, 640, 100), (0.1, "l2n"))])
+def test_admm_eu_k64_k128_both_precisions_vs_oracle(precision, shape, reg_h, monkeypatch):
+    """k in (32, 128]: ADMM with the products on the split-bf16 kernels (objective by one more pass
+    of the same kernel) against the exact-f32 products and the oracle."""
+    from oracle import nmf_ref as R
+    from nmf_amd.admm import admm
+    monkeypatch.setenv("NMFX_PRECISION", precision)
+    m, n, k = shape
+    v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+    kw = dict(rho=1.0, distance_type="eu", reg_w=(0.02, "l1n"), reg_h=reg_h, min_iter=12, max_iter=12,
+              nndsvd_init=(True, "zero"))
+    ref = R.admm(v.astype(np.float64), k, **kw)
+    res = admm(v.copy(), k, **kw)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
