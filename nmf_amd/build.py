@@ -16,6 +16,8 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "lib", "libnmfx.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-ffp-contract=off"]
+if os.environ.get("NMFX_EXTRA_DEFS"):          # e.g. "-DNMFX_NNLS_STATS" for tools/anls_perf.py --stats
+    FLAGS.extend(os.environ["NMFX_EXTRA_DEFS"].split())
 if os.environ.get("NMFX_BF16_TERMS"):
     FLAGS.append("-DNMFX_BF16_TERMS=" + os.environ["NMFX_BF16_TERMS"])
 

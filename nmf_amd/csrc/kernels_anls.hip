@@ -20,6 +20,18 @@
 #include "nmfx_internal.h"
 #include "kernels_small.h"
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Infeasibility is tested against a rounding-level threshold (1e-6 of the largest |x| / |r| of the
+// problem): a variable whose exact x_i (or dual y_i) is zero otherwise flips sign with the f32
+// rounding of every solve and the exchange rule cycles until the iteration cap (seen on 0.03 % of
+// the right-hand sides at 16384 x 8192 -- they set the run time of the whole launch).
+#define NMFX_NNLS_TOL 1e-6f
+
 template <int KP>
 __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
@@ -38,20 +50,37 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
 
     int idx[NV]; bool valid[NV], inF[NV];
     float r[NV], x[NV], y[NV];
+    // WARM START: the passive set starts as the support of the previous solution (X on entry: the
+    // factor of the last outer iteration, or the initial factor).  Block principal pivoting reaches the
+    // unique KKT point from any start; once the supports settle a half-step needs one or two solves
+    // per right-hand side instead of a cold start's five to ten.
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         idx[t] = lane + 64 * t;
         valid[t] = idx[t] < k;
         r[t] = valid[t] ? R[(int64_t)idx[t] * sj + c * sc] : 0.f;
-        x[t] = 0.f; y[t] = -r[t]; inF[t] = false;
+        x[t] = 0.f; y[t] = -r[t];
+        inF[t] = valid[t] && X[(int64_t)idx[t] * sj + c * sc] > 0.f;
+    }
+    float toly;
+    {
+        float ar = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) ar = fmaxf(ar, fabsf(r[t]));
+        toly = NMFX_NNLS_TOL * wave_max(ar);
     }
     int best = k + 1, spare = 3;
     for (int iter = 0; iter < 8 * KP + 64; ++iter) {
         unsigned long long Im[NV];
+        if (iter > 0) {                                  // (iteration 0 solves for the warm-start set first)
+        float ax = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) ax = fmaxf(ax, fabsf(x[t]));
+        const float tolx = NMFX_NNLS_TOL * wave_max(ax);
         int n_inf = 0;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            const bool bad = valid[t] && (inF[t] ? (x[t] < 0.f) : (y[t] < 0.f));
+            const bool bad = valid[t] && (inF[t] ? (x[t] < -tolx) : (y[t] < -toly));
             Im[t] = __ballot(bad);
             n_inf += __popcll(Im[t]);
         }
@@ -71,6 +100,10 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
                     break;
                 }
             }
+        }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NV; ++t) Im[t] = 0ull;
         }
         unsigned long long Fm[NV];
 #pragma unroll
@@ -151,6 +184,109 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.f) ? x[t] : 0.f;
 }
 
+__device__ unsigned long long nnls_dbg[4];     // [sum of iterations, max, problems, exchanges in back-up mode]
+
+// Register-resident variant for k <= 64 (one variable per lane, one right-hand side per wave):
+// lane i keeps row i of G in registers, the elimination works on a register copy with the pivot
+// row BROADCAST through the LDS crossbar (ds_bpermute), pivots in static order.
+// No LDS storage, no data-dependent addressing: the LDS version above spends its time in serial
+// read-modify-write chains (34 ms per half-step at 16384 x 8192, k = 64).
+// The elimination runs over the passive pivots only but over ALL columns: the non-passive columns
+// multiply x = 0, so the passive rows still end with x_i = rhs_i (pivot rows are normalised).
+template <int KP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void nnls_bpp_reg_kernel(
+    const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= nprob) return;                              // whole wave leaves together
+    const bool owner = lane < KP, valid = lane < k;
+    float g[KP];
+#pragma unroll
+    for (int cc = 0; cc < KP; ++cc) g[cc] = owner ? G[(int64_t)lane * KP + cc] + (cc == lane ? diag_add : 0.f) : 0.f;
+    const float r = valid ? R[(int64_t)lane * sj + c * sc] : 0.f;
+    bool inF = valid && X[(int64_t)(owner ? lane : 0) * sj + c * sc] > 0.f;      // warm start: previous support
+    float x = 0.f, y = -r;
+    const float toly = NMFX_NNLS_TOL * wave_max(fabsf(r));
+    int best = k + 1, spare = 3;
+    int iter = 0, nbackup = 0;
+    for (; iter < 8 * KP + 64; ++iter) {
+        if (iter > 0) {
+            const float tolx = NMFX_NNLS_TOL * wave_max(fabsf(x));
+            const bool bad = valid && (inF ? (x < -tolx) : (y < -toly));
+            unsigned long long Im = __ballot(bad);
+            const int n_inf = __popcll(Im);
+            if (n_inf == 0) break;
+            bool full = true;
+            if (n_inf < best) { best = n_inf; spare = 3; }
+            else if (spare > 0) { --spare; }
+            else full = false;
+            if (!full) { Im = 1ull << (63 - __clzll((long long)Im)); ++nbackup; }   // back-up rule: largest infeasible index only
+            if ((Im >> lane) & 1ull) inF = !inF;
+        }
+        const unsigned long long Fm = __ballot(inF);
+        float m[KP], rhs = r;
+#pragma unroll
+        for (int cc = 0; cc < KP; ++cc) m[cc] = g[cc];
+        // Pivots = the passive indices, in a RUNTIME loop: unrolling the 64 pivot bodies statically made
+        // ~80 KiB of code and the kernel instruction-fetch bound (230 cycles per instruction measured).
+        // The row's own entry in the pivot column, m[p] with a wave-uniform runtime p, is picked by a
+        // compare-select sweep; the pivot row comes through the LDS crossbar (ds_bpermute).
+        unsigned long long left = Fm;
+        while (left) {
+            const int p = __ffsll((long long)left) - 1;
+            left &= left - 1;
+            float f = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < KP; ++cc) f = (cc == p) ? m[cc] : f;
+            const float inv = 1.f / __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(f)));
+            const bool me = lane == p;
+#pragma unroll
+            for (int c0 = 0; c0 < KP; c0 += 16) {
+                float pr[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc)
+                    pr[cc] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(m[c0 + cc])));
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const float prs = pr[cc] * inv;
+                    m[c0 + cc] = me ? prs : fmaf(-f, prs, m[c0 + cc]);
+                }
+            }
+            const float prr = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(rhs))) * inv;
+            rhs = me ? prr : fmaf(-f, prr, rhs);
+        }
+        x = inF ? rhs : 0.f;
+        float acc = -r;
+#pragma unroll
+        for (int cc = 0; cc < KP; ++cc)
+            acc = fmaf(g[cc], __int_as_float(__builtin_amdgcn_ds_bpermute(4 * cc, __float_as_int(x))), acc);
+        y = (valid && !inF) ? acc : 0.f;
+    }
+    if (owner) X[(int64_t)lane * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
+#ifdef NMFX_NNLS_STATS
+    if (lane == 0) {
+        atomicAdd(&nnls_dbg[0], (unsigned long long)iter); atomicMax(&nnls_dbg[1], (unsigned long long)iter);
+        atomicAdd(&nnls_dbg[2], 1ull); atomicAdd(&nnls_dbg[3], (unsigned long long)nbackup);
+    }
+#endif
+}
+
+extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build with -DNMFX_NNLS_STATS
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnls_dbg), sizeof(nnls_dbg)) == hipSuccess ? 0 : -1;
+}
+
+template <int KP>
+static int launch_nnls_reg(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
+                           int64_t sc, int64_t nprob) {
+    hipLaunchKernelGGL((nnls_bpp_reg_kernel<KP>), dim3((unsigned)((nprob + 3) / 4)), dim3(256), 0, E->stream, G, diag_add,
+                       R, X, sj, sc, nprob, E->k, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 template <int KP>
 static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
                        int64_t sc, int64_t nprob) {
@@ -172,10 +308,14 @@ static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const flo
 static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj, int64_t sc,
                 int64_t nprob) {
     ProfScope ps(E, "nnls");
+    static const bool lds_only = getenv("NMFX_NNLS_LDS") && atoi(getenv("NMFX_NNLS_LDS")) != 0;
     switch (E->kp) {
-        case 16: return launch_nnls<16>(E, G, diag_add, R, X, sj, sc, nprob);
-        case 32: return launch_nnls<32>(E, G, diag_add, R, X, sj, sc, nprob);
-        case 64: return launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 16: return lds_only ? launch_nnls<16>(E, G, diag_add, R, X, sj, sc, nprob)
+                                 : launch_nnls_reg<16>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 32: return lds_only ? launch_nnls<32>(E, G, diag_add, R, X, sj, sc, nprob)
+                                 : launch_nnls_reg<32>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 64: return lds_only ? launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob)
+                                 : launch_nnls_reg<64>(E, G, diag_add, R, X, sj, sc, nprob);
         default: return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
     }
 }
