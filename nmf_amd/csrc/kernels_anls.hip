@@ -323,11 +323,38 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
 // One outer iteration (anls.py:112-126) in the pieces the row-sharded form needs:
 //   objective of the current pair -> [all-reduce] -> stop rule, W rows (rank-local), products
 //   for H -> [all-reduce] -> H columns (replicated) and the objective partials of the new pair.
+static bool anls_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_bf16_supported(E); }
+
+// objective partials of (W, H) (anls.py:118)
+static int anls_objective(nmfx_engine* E) {
+    int rc;
+    if (!anls_bf16(E)) return nmfx_launch_wphase(E, E->W[0], false, true);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+    return nmfx_bf16_vht(E, true, 1, "objective");
+}
+
 static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     float* W = E->W[0];
     const int64_t kk = (int64_t)E->kp * E->kp;
     if ((rc = nmfx_finish_b(E, min_iter, tol1, tol2, j))) return rc;      // obj[j] + stop rule
+    if (anls_bf16(E)) {     // the same steps with the products on the split-bf16 kernels (kp = 64 / 128)
+        const bool byprod = E->kp == 64;                                   // Gram matrices as by-products
+        if ((rc = nmfx_bf16_prepare(E))) return rc;
+        if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
+        if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+        if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+        if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
+        if ((rc = nnls(E, E->HHt, (float)(2.0 * lam_w), E->Asum, W, 1, E->kp, E->m))) return rc;
+        if ((rc = nmfx_bf16_images_w(E, W, 0))) return rc;
+        if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
+        if (byprod) return nmfx_bf16_pack_t(E, E->G_part, E->bt_split, E->obj_count);
+        if ((rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+        return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, E->obj_count);
+    }
     // ---- W: rows of W from G = H H^T + 2 lam_w I, r = (V H^T)[i, :]  (anls.py:18-31) ----
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, W, true, false))) return rc;
@@ -346,7 +373,7 @@ static int anls_h(nmfx_engine* E, double lam_h) {
     // ---- H: columns of H from G = W^T W + 2 lam_h I, r = (W^T V)[:, c]  (anls.py:34-47) ----
     if ((rc = nnls(E, E->xf32 + (int64_t)E->kp * E->np, (float)(2.0 * lam_h), E->xf32, E->H, E->np, 1, E->n))) return rc;
     // ---- objective (anls.py:118) ----
-    return nmfx_launch_wphase(E, E->W[0], false, true);
+    return anls_objective(E);
 }
 
 static int anls_iteration(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2,
@@ -376,7 +403,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
 // -> phase_h ----
 extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
     int rc = anls_ready(E, j, 0.0); if (rc) return rc;
-    if (j == 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0] partials
+    if (j == 0 && (rc = anls_objective(E))) return rc;   // obj[0] partials
     return nmfx_launch_obj_reduce(E);
 }
 
@@ -405,7 +432,7 @@ extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, 
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
     E->wsel = 0;
     E->w_in_place = true;
-    if (first == 0 && count > 0 && (rc = nmfx_launch_wphase(E, E->W[0], false, true))) return rc;   // obj[0]
+    if (first == 0 && count > 0 && (rc = anls_objective(E))) return rc;   // obj[0]
     for (int64_t j = first; j < first + count; ++j)
         if ((rc = anls_iteration(E, lambda_w, lambda_h, min_iter, tol1, tol2, j))) return rc;
     return NMFX_OK;

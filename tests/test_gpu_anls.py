@@ -38,3 +38,22 @@ def test_anls_larger_rank_properties():
     assert y[res.h == 0].min() > -2e-4 * scale      # dual feasibility on the active set
     assert np.abs(y[res.h > 0]).max() < 2e-4 * scale   # stationarity on the passive set
     # (with lambda_h > 0 the plain objective need not decrease; the KKT system above is the exact test)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(300, 220, 40), (260, 400, 100)])
+def test_anls_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
+    """k in (32, 128]: register-resident NNLS (k <= 64) / LDS NNLS (k = 128), products on the
+    split-bf16 kernels or on the exact-f32 kernels, against the oracle (scipy NNLS)."""
+    from oracle import nmf_ref as R
+    from nmf_amd.anls import anls
+    monkeypatch.setenv("NMFX_PRECISION", precision)
+    m, n, k = shape
+    v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+    kw = dict(lambda_w=0.05, lambda_h=0.02, min_iter=4, max_iter=4, nndsvd_init=(True, "zero"))
+    ref = R.anls(v.astype(np.float64), k, **kw)
+    res = anls(v.copy(), k, **kw)
+    err = np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
+    assert err < 1e-4, err
+    assert res.i == ref.i
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
