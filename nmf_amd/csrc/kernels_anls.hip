@@ -111,20 +111,21 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
             if ((Im[t] >> lane) & 1ull) inF[t] = !inF[t];
             Fm[t] = __ballot(inF[t]);
         }
-        // augmented rows of the passive block (other rows are never touched)
+        // augmented rows of the passive variables (other rows are never touched).  ALL columns are
+        // copied and eliminated: the non-passive ones multiply x = 0 and never serve as pivots, and
+        // plain full-width loops keep the LDS operations independent and pipelined (the earlier
+        // bit-scan over the passive columns made every read-modify-write wait for the previous one).
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             if (inF[t]) {
                 const float* grow = G + (int64_t)idx[t] * KP;
                 float* mrow = M + idx[t] * LDM;
-                for (int cc = 0; cc < KP; ++cc) {
-                    const bool in = (Fm[cc >> 6] >> (cc & 63)) & 1ull;
-                    mrow[cc] = in ? (grow[cc] + (cc == idx[t] ? diag_add : 0.f)) : 0.f;
-                }
+#pragma unroll 8
+                for (int cc = 0; cc < KP; ++cc) mrow[cc] = grow[cc] + (cc == idx[t] ? diag_add : 0.f);
                 mrow[KP] = r[t];
             }
         }
-        // Gauss-Jordan over the passive pivots
+        // Gauss-Jordan over the passive pivots (no normalisation: x_i = rhs_i / diag_i at the end)
         for (int tp = 0; tp < NV; ++tp) {
             unsigned long long left = Fm[tp];
             while (left) {
@@ -133,23 +134,21 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
                 const int p = b + 64 * tp;
                 const float* prow = M + p * LDM;
                 const float inv = 1.f / prow[p];
+                const int c0 = (p + 1) & ~3;                 // columns <= p of the pivot row are already zero
 #pragma unroll
                 for (int t = 0; t < NV; ++t) {
                     if (inF[t] && idx[t] != p) {
                         float* mrow = M + idx[t] * LDM;
                         const float f = mrow[p] * inv;
-                        // only passive columns after p still matter, plus the right-hand side
-                        for (int tc = tp; tc < NV; ++tc) {
-                            unsigned long long cols = Fm[tc];
-                            if (tc == tp) cols &= ~((2ull << b) - 1ull);
-                            while (cols) {
-                                const int cb = __ffsll((long long)cols) - 1;
-                                cols &= cols - 1;
-                                const int cc = cb + 64 * tc;
-                                mrow[cc] -= f * prow[cc];
-                            }
+                        for (int cc = p + 1; cc < c0; ++cc) mrow[cc] = fmaf(-f, prow[cc], mrow[cc]);
+#pragma unroll 4
+                        for (int cc = c0; cc < KP; cc += 4) {
+                            const float p0 = prow[cc], p1 = prow[cc + 1], p2 = prow[cc + 2], p3 = prow[cc + 3];
+                            const float m0 = mrow[cc], m1 = mrow[cc + 1], m2 = mrow[cc + 2], m3 = mrow[cc + 3];
+                            mrow[cc] = fmaf(-f, p0, m0); mrow[cc + 1] = fmaf(-f, p1, m1);
+                            mrow[cc + 2] = fmaf(-f, p2, m2); mrow[cc + 3] = fmaf(-f, p3, m3);
                         }
-                        mrow[KP] -= f * prow[KP];
+                        mrow[KP] = fmaf(-f, prow[KP], mrow[KP]);
                     }
                 }
             }
@@ -159,21 +158,14 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
             x[t] = inF[t] ? M[idx[t] * LDM + KP] / M[idx[t] * LDM + idx[t]] : 0.f;
             if (idx[t] < KP) xs[idx[t]] = x[t];          // lanes beyond KP own no variable
         }
-        // dual variables of the active set: y = G x - r
+        // dual variables of the active set: y = G x - r   (x = 0 outside the passive set)
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             float acc = 0.f;
             if (valid[t] && !inF[t]) {
                 const float* grow = G + (int64_t)idx[t] * KP;
-                for (int tc = 0; tc < NV; ++tc) {
-                    unsigned long long cols = Fm[tc];
-                    while (cols) {
-                        const int cb = __ffsll((long long)cols) - 1;
-                        cols &= cols - 1;
-                        const int cc = cb + 64 * tc;
-                        acc += grow[cc] * xs[cc];
-                    }
-                }
+#pragma unroll 8
+                for (int cc = 0; cc < KP; ++cc) acc = fmaf(grow[cc], xs[cc], acc);
                 acc -= r[t];
             }
             y[t] = acc;
