@@ -270,6 +270,121 @@ extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build wit
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnls_dbg), sizeof(nnls_dbg)) == hipSuccess ? 0 : -1;
 }
 
+// k = 128: two waves per right-hand side (thread = variable), rows in registers, the pivot row
+// handed over through a double-buffered LDS row (one barrier per pivot), the masks of the two
+// waves exchanged through LDS.  Same algorithm as nnls_bpp_reg_kernel.
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) void nnls_bpp_reg128_kernel(
+    const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int KP = 128;
+    __shared__ __attribute__((aligned(16))) float prow_s[2][KP + 4];   // pivot row, [KP] = its right-hand side
+    __shared__ __attribute__((aligned(16))) float xs[KP];
+    __shared__ unsigned long long mask_s[2][2];
+    __shared__ float red_s[2][2];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t c = blockIdx.x;
+    const bool valid = tid < k;
+    const float* grow = G + (int64_t)tid * KP;
+    const float r = valid ? R[(int64_t)tid * sj + c * sc] : 0.f;
+    bool inF = valid && X[(int64_t)tid * sj + c * sc] > 0.f;        // warm start: previous support
+    float x = 0.f, y = -r;
+    int ph = 0;                                                      // parity of the small exchange buffers
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        if ((tid & 63) == 0) red_s[ph][wave] = v;
+        __syncthreads();
+        const float o = fmaxf(red_s[ph][0], red_s[ph][1]);
+        ph ^= 1;
+        return o;
+    };
+    auto block_masks = [&](bool bit, unsigned long long out[2]) {
+        const unsigned long long b = __ballot(bit);
+        if ((tid & 63) == 0) mask_s[ph][wave] = b;
+        __syncthreads();
+        out[0] = mask_s[ph][0]; out[1] = mask_s[ph][1];
+        ph ^= 1;
+    };
+    const float toly = NMFX_NNLS_TOL * block_max(fabsf(r));
+    int best = k + 1, spare = 3, pbuf = 0;
+    for (int iter = 0; iter < 8 * KP + 64; ++iter) {
+        if (iter > 0) {
+            const float tolx = NMFX_NNLS_TOL * block_max(fabsf(x));
+            unsigned long long Im[2];
+            block_masks(valid && (inF ? (x < -tolx) : (y < -toly)), Im);
+            const int n_inf = __popcll(Im[0]) + __popcll(Im[1]);
+            if (n_inf == 0) break;
+            bool full = true;
+            if (n_inf < best) { best = n_inf; spare = 3; }
+            else if (spare > 0) { --spare; }
+            else full = false;
+            if (!full) {                                 // back-up rule: largest infeasible index only
+                if (Im[1]) { Im[1] = 1ull << (63 - __clzll((long long)Im[1])); Im[0] = 0ull; }
+                else Im[0] = 1ull << (63 - __clzll((long long)Im[0]));
+            }
+            if ((Im[wave] >> (tid & 63)) & 1ull) inF = !inF;
+        }
+        unsigned long long Fm[2];
+        block_masks(inF, Fm);
+        float m[KP], rhs = r;
+#pragma unroll
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+            const float4 gv = *reinterpret_cast<const float4*>(grow + 4 * c4);
+            m[4 * c4] = gv.x + (4 * c4 == tid ? diag_add : 0.f); m[4 * c4 + 1] = gv.y + (4 * c4 + 1 == tid ? diag_add : 0.f);
+            m[4 * c4 + 2] = gv.z + (4 * c4 + 2 == tid ? diag_add : 0.f); m[4 * c4 + 3] = gv.w + (4 * c4 + 3 == tid ? diag_add : 0.f);
+        }
+        for (int tp = 0; tp < 2; ++tp) {
+            unsigned long long left = Fm[tp];
+            while (left) {
+                const int p = __ffsll((long long)left) - 1 + 64 * tp;
+                left &= left - 1;
+                float* pw = prow_s[pbuf];
+                if (tid == p) {
+#pragma unroll
+                    for (int c4 = 0; c4 < KP / 4; ++c4)
+                        *reinterpret_cast<float4*>(pw + 4 * c4) = make_float4(m[4 * c4], m[4 * c4 + 1], m[4 * c4 + 2], m[4 * c4 + 3]);
+                    pw[KP] = rhs;
+                }
+                __syncthreads();
+                float f = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < KP; ++cc) f = (cc == p) ? m[cc] : f;
+                const float inv = 1.f / pw[p];
+                const bool me = tid == p;
+#pragma unroll
+                for (int c8 = 0; c8 < KP / 32; ++c8) {           // 8 x 16 bytes of the pivot row in flight at a time
+#pragma unroll
+                    for (int c4 = 8 * c8; c4 < 8 * c8 + 8; ++c4) {
+                        const float4 pv = *reinterpret_cast<const float4*>(pw + 4 * c4);
+                        const float ps[4] = {pv.x * inv, pv.y * inv, pv.z * inv, pv.w * inv};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m[4 * c4 + e] = me ? ps[e] : fmaf(-f, ps[e], m[4 * c4 + e]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // keeps the row's live range short (register budget)
+                }
+                const float prr = pw[KP] * inv;
+                rhs = me ? prr : fmaf(-f, prr, rhs);
+                pbuf ^= 1;
+            }
+        }
+        x = inF ? rhs : 0.f;
+        __syncthreads();                                 // the previous iteration's readers of xs are done
+        xs[tid] = x;
+        __syncthreads();
+        float acc = -r;
+#pragma unroll 8
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+            const float4 gv = *reinterpret_cast<const float4*>(grow + 4 * c4);
+            const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * c4);
+            acc = fmaf(gv.x, xv.x, acc); acc = fmaf(gv.y, xv.y, acc); acc = fmaf(gv.z, xv.z, acc); acc = fmaf(gv.w, xv.w, acc);
+        }
+        acc = fmaf(diag_add, x, acc);                    // (G + diag) x; x = 0 for the active variables anyway
+        y = (valid && !inF) ? acc : 0.f;
+    }
+    X[(int64_t)tid * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
+}
+
 template <int KP>
 static int launch_nnls_reg(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
                            int64_t sc, int64_t nprob) {
@@ -308,7 +423,12 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
                                  : launch_nnls_reg<32>(E, G, diag_add, R, X, sj, sc, nprob);
         case 64: return lds_only ? launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob)
                                  : launch_nnls_reg<64>(E, G, diag_add, R, X, sj, sc, nprob);
-        default: return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
+        default:
+            if (lds_only) return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
+            hipLaunchKernelGGL(nnls_bpp_reg128_kernel, dim3((unsigned)nprob), dim3(128), 0, E->stream, G, diag_add, R, X, sj,
+                               sc, nprob, E->k, &E->state->flag);
+            NMFX_HIP(hipGetLastError());
+            return NMFX_OK;
     }
 }
 
