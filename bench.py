@@ -242,7 +242,7 @@ def main():
             nbytes = ml * n * 4.0 + 2.0 * ml * k * 4
             if precision == "bf16":
                 ach = nbytes / sec / 1e9
-                roof = {"kernel": "xyt_bf16_kernel<true> (W phase)", "bound": "hbm", "achieved": ach,
+                roof = {"kernel": "xyt_bf16_kernel<64, true, false> (W phase)", "bound": "hbm", "achieved": ach,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": nbytes,
                         "algorithmic_tflops": flops / sec / 1e12}
@@ -287,7 +287,7 @@ def main():
 
     if rank == 0 and world == 1 and roof is not None and not args.no_traffic:
         eng.close()               # free the HBM before the child passes allocate their own
-        roof["traffic"] = hbm_traffic("xyt_bf16_kernel<true>" if precision == "bf16" else "wphase_kernel", m, n, k)
+        roof["traffic"] = hbm_traffic("xyt_bf16_kernel<64, true" if precision == "bf16" else "wphase_kernel", m, n, k)
         roof["traffic_note"] = ("HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
                                 "FETCH_SIZE x2 (gfx950 correction)")
 
