@@ -141,6 +141,14 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
     TRY(nmfx_ensure_obj_capacity(E, 4096));
     TRYHIP(hipStreamSynchronize(E->stream));
+    {   // the split-bf16 path keeps two more V-sized buffers (tile-major V and V^T): fall back to the
+        // exact-f32 kernels (one copy of V) when they would not fit next to everything else
+        size_t free_b = 0, total_b = 0;
+        if (E->precision == 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double need = 2.0 * (double)mp * (double)np * 4.0 + 64.0 * (double)(mp + np) * kp + (256u << 20);
+            if ((double)free_b < need) E->precision = 0;
+        }
+    }
 #undef TRY
 #undef TRYHIP
     *out = E;
