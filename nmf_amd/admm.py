@@ -35,7 +35,7 @@ def l2n_operator(k, rho, lam):
 
 def admm(v, k, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_iter=10,
          max_iter=100000, tol1=1e-3, tol2=1e-3, nndsvd_init=(True, 'zero'), save_dir='./results/',
-         device=0):
+         device=0, engine=None):
     """ADMM NMF.  rho: fixed penalty; reg_w / reg_h = (lambda, 'nn' | 'l1n' | 'l2n');
     other arguments as in the reference.  Returns Results(w, h, i, obj_history, experiment)."""
     experiment = Experiment('admm', k, rho, distance_type, nndsvd_init, min_iter, max_iter, tol1, tol2,
@@ -46,8 +46,7 @@ def admm(v, k, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), 
     init = utils.initial_factors(v, k, nndsvd_init, defer_device=True)
     prox_h = _prox_code(reg_h[1])
     prox_w = _prox_code(reg_w[1])
-    with Engine(v.shape[0], v.shape[1], k, device=device) as eng:
-        eng.upload_v(v)
+    with Engine.for_data(v, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, v, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         if prox_w == L.PROX['l2n']:

@@ -21,7 +21,7 @@ Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_in
 
 def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, min_iter=10,
          max_iter=1000, tol1=1e-3, tol2=1e-3, nndsvd_init=(True, 'zero'), save_dir='./results/',
-         device=0):
+         device=0, engine=None):
     experiment = Experiment('anls', k, distance_type, nndsvd_init, max_iter, tol1, tol2, lambda_w,
                             lambda_h, use_fcnnls)
     if distance_type not in ('eu', 'kl'):
@@ -30,8 +30,7 @@ def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, 
         raise NotImplementedError("anls with distance_type='kl' (KL objective of least-squares "
                                   "iterates) is not built in nmf_amd")
     init = utils.initial_factors(x, k, nndsvd_init, uniform=True, defer_device=True)
-    with Engine(x.shape[0], x.shape[1], k, device=device) as eng:
-        eng.upload_v(x)
+    with Engine.for_data(x, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         i, history = drive(

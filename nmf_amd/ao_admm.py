@@ -37,7 +37,7 @@ def _prox_code(kind):
 
 def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_iter=10,
             max_iter=100000, admm_iter=10, tol1=1e-3, tol2=1e-3, nndsvd_init=(True, 'zero'),
-            save_dir='./results/', device=0):
+            save_dir='./results/', device=0, engine=None):
     """AO-ADMM NMF.  reg_w / reg_h = (lambda, 'nn' | 'l1n'); other arguments as
     in the reference.  Returns Results(w, h, i, obj_history, experiment)."""
     experiment = Experiment('ao_admm', k, distance_type, nndsvd_init, min_iter, max_iter, admm_iter,
@@ -50,8 +50,7 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
     prox_h = _prox_code(reg_h[1])
     prox_w = _prox_code(reg_w[1])
 
-    with Engine(v.shape[0], v.shape[1], k, device=device) as eng:
-        eng.upload_v(v)
+    with Engine.for_data(v, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, v, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         seen = {}

@@ -268,9 +268,10 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
         NMFX_HIP(hipMemsetAsync(E->W[1], 0, (size_t)E->mp * E->kp * 4, E->stream));
     }
     if (hmat) { if ((rc = put_padded(E, E->H, hmat, E->k, E->n, E->kp, E->np))) return rc; }
-    float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH};
-    const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np};
-    for (int i = 0; i < 4; ++i)
+    // (S, DV: the m x n auxiliaries of the KL-loss ADMM variants start from zero, ao_admm.py:17-30)
+    float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH, E->S, E->DV};
+    const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np, E->mp * E->np, E->mp * E->np};
+    for (int i = 0; i < 6; ++i)
         if (zero[i]) NMFX_HIP(hipMemsetAsync(zero[i], 0, (size_t)zc[i] * 4, E->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
     E->wsel = 0;

@@ -32,6 +32,13 @@ class Engine:
     def __enter__(self):
         return self
 
+    @classmethod
+    def for_data(cls, x, k, device=0, engine=None):
+        """Context manager over the engine a solver runs on: a fresh one with `x` uploaded (closed on
+        exit), or `engine` -- one that already holds this V for this k (nmf_amd.grid keeps V resident
+        across the factorizations of a parameter grid) -- which is left open."""
+        return _EngineScope(cls, x, k, device, engine)
+
     def __exit__(self, *exc):
         self.close()
 
@@ -211,3 +218,28 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.lib.nmfx_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class _EngineScope:
+    def __init__(self, cls, x, k, device, engine):
+        self.cls, self.x, self.k, self.device, self.engine = cls, x, k, device, engine
+        self.owned = None
+
+    def __enter__(self):
+        if self.engine is not None:
+            e = self.engine
+            if (e.m, e.n, e.k) != (self.x.shape[0], self.x.shape[1], int(self.k)):
+                raise ValueError(f"engine holds a {e.m}x{e.n} problem with k={e.k}, not "
+                                 f"{self.x.shape[0]}x{self.x.shape[1]} with k={self.k}")
+            return e
+        self.owned = self.cls(self.x.shape[0], self.x.shape[1], self.k, device=self.device)
+        try:
+            self.owned.upload_v(self.x)
+        except Exception:
+            self.owned.close()
+            raise
+        return self.owned
+
+    def __exit__(self, *exc):
+        if self.owned is not None:
+            self.owned.close()

@@ -17,7 +17,7 @@ Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_in
 
 
 def mur(x, k, *, distance_type='kl', min_iter=100, max_iter=100000, tol1=1e-5, tol2=1e-5,
-        lambda_w=0.0, lambda_h=0.0, nndsvd_init=(False, 'zero'), save_dir='./results/', device=0):
+        lambda_w=0.0, lambda_h=0.0, nndsvd_init=(False, 'zero'), save_dir='./results/', device=0, engine=None):
     """Lee-Seung NMF.  x: 2-D non-negative data, k: number of components.
 
     distance_type 'eu' | 'kl' (default 'kl' as in the reference), min_iter,
@@ -37,8 +37,7 @@ def mur(x, k, *, distance_type='kl', min_iter=100, max_iter=100000, tol1=1e-5, t
         logging.info('Data elevated by {}.'.format(abs(lowest)))
 
     init = utils.initial_factors(x, k, nndsvd_init, defer_device=True)
-    with Engine(x.shape[0], x.shape[1], k, device=device) as eng:
-        eng.upload_v(x)
+    with Engine.for_data(x, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         logging.info('Entering Main Loop.')

@@ -149,3 +149,35 @@ def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
     assert ref.trace["stop_rule"] == 2 and ref.i < 599
     assert out["f32"].i == ref.i
     assert abs(out["bf16"].i - ref.i) <= 1, (out["bf16"].i, ref.i)
+
+
+def test_grid_keeps_v_resident_and_matches_separate_calls(tmp_path):
+    """nmf_amd.grid: one upload per `features` value, results identical to separate solver calls
+    (same RNG draws in the same order), including a KL-ADMM run after an LS run on the SAME engine
+    (set_factors must reset every piece of solver state)."""
+    from nmf_amd.grid import factorize_grid
+    from nmf_amd.ao_admm import ao_admm
+    from nmf_amd.admm import admm
+    v = R.planted_matrix(260, 180, 6, seed=4, dtype=np.float32)
+    common = dict(distance_type="eu", min_iter=5, max_iter=5, nndsvd_init=(False, "zero"))
+    np.random.seed(5)
+    runs = factorize_grid(v.copy(), "ao_admm", features=(6, 9), lambda_w=(0.0, 0.1), lambda_h=(0.05,),
+                          prox_w="l1n", prox_h="l1n", save_dir=str(tmp_path), **common)
+    assert [p["features"] for p, _ in runs] == [6, 6, 9, 9] and [p["lambda_w"] for p, _ in runs] == [0.0, 0.1, 0.0, 0.1]
+    np.random.seed(5)
+    for params, res in runs:
+        ref = ao_admm(v.copy(), params["features"], reg_w=(params["lambda_w"], "l1n"), reg_h=(params["lambda_h"], "l1n"), **common)
+        np.testing.assert_array_equal(res.w, ref.w)
+        np.testing.assert_array_equal(res.obj_history, ref.obj_history)
+    assert len(list(tmp_path.iterdir())) == 4
+    # KL after LS on one engine
+    from nmf_amd.engine import Engine
+    kw = dict(rho=1.0, reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=4, max_iter=4, nndsvd_init=(False, "zero"))
+    with Engine(260, 180, 6) as eng:
+        eng.upload_v(v)
+        np.random.seed(8); admm(v.copy(), 6, distance_type="eu", engine=eng, **kw)
+        np.random.seed(9); again = admm(v.copy(), 6, distance_type="kl", engine=eng, **kw)
+        np.random.seed(9); twice = admm(v.copy(), 6, distance_type="kl", engine=eng, **kw)
+    np.random.seed(9); fresh = admm(v.copy(), 6, distance_type="kl", **kw)
+    np.testing.assert_array_equal(again.w, fresh.w)
+    np.testing.assert_array_equal(twice.w, fresh.w)
