@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--n", type=int, default=N)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=10)     # ~12 s of host work at 0.9 iterations/s
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--tol-max-iter", type=int, default=20000,
