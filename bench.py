@@ -134,7 +134,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch
     import torch.distributed as dist
-    from oracle.nmf_ref import planted_matrix
+    from nmf_amd.synth import planted_matrix      # (the oracle is imported by the cpu_baseline leg only)
     from nmf_amd import dist as nd
 
     m, n, k = args.m, args.n, args.k

@@ -115,3 +115,13 @@ def _reference_max_iter_zero():
     out = R.mur(np.ones((4, 3)), 2, distance_type="eu", max_iter=0)
     if out.i == -1:
         raise UnboundLocalError("local variable 'i' referenced before assignment")
+
+
+def test_benchmark_generator_equals_the_oracle_copy():
+    """bench.py draws its inputs from nmf_amd.synth (the product may not import the oracle); the
+    oracle keeps an identical generator for the tests."""
+    from nmf_amd import synth
+    from oracle import nmf_ref as R
+    a = synth.planted_matrix(300, 70, 5, seed=3, dtype=np.float32, rows=(40, 260))
+    b = R.planted_matrix(300, 70, 5, seed=3, dtype=np.float32, rows=(40, 260))
+    np.testing.assert_array_equal(a, b)

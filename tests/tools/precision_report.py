@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """WH / objective error of both arithmetic modes against the f64 oracle (GPU box)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np

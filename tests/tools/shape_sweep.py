@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity of the split-bf16 paths on awkward shapes (GPU box): MUR-eu and AO-ADMM against the oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np

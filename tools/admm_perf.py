@@ -1,7 +1,7 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo"); os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np
-from oracle.nmf_ref import planted_matrix
+from nmf_amd.synth import planted_matrix
 from nmf_amd.engine import Engine
 m, n, k = 16384, 8192, 128
 v = planted_matrix(m, n, k, seed=0, dtype=np.float32)

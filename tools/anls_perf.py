@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np
-from oracle.nmf_ref import planted_matrix
+from nmf_amd.synth import planted_matrix
 from nmf_amd.engine import Engine
 m, n, k = 16384, 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 v = planted_matrix(m, n, k, seed=0, dtype=np.float32)

@@ -19,7 +19,7 @@ os.environ.setdefault("NMF_AMD_QUIET", "1")
 import numpy as np  # noqa: E402
 
 from nmf_amd.engine import Engine  # noqa: E402
-from oracle.nmf_ref import planted_matrix  # noqa: E402
+from nmf_amd.synth import planted_matrix  # noqa: E402
 
 NEVER = 10 ** 12
 KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "sum_hht", "w_update", "pack",

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np
-from oracle import nmf_ref as R
+from nmf_amd import synth as R
 from nmf_amd.engine import Engine
 m, n = 16384, 8192
 for k in (64, 128):
