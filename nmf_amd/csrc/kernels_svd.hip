@@ -168,6 +168,59 @@ __global__ __launch_bounds__(256) void svd_resid_kernel(const double* __restrict
     part[(int64_t)blockIdx.x * L + j] = s;
 }
 
+// Tpart[chunk][i][j] = sum over the chunk's rows of A[r][i] B[r][j]   (svd_gram_kernel with two operands)
+template <int NT>
+__global__ __launch_bounds__(256) void svd_cross_gram_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                             int64_t rows_per_chunk, double* __restrict__ Tpart)
+{
+    constexpr int L = 16 * NT, NW = (NT + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+    const int ti = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+    f64x4 acc[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) acc[c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t r = r0; r < r0 + rows_per_chunk; r += 4) {
+        const double a = A[(r + q) * L + 16 * ti + x];
+        const double* brow = B + (r + q) * L;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            const int tj = wave + 4 * c;
+            if (tj < NT) acc[c] = MFMA_F64(a, brow[16 * tj + x], acc[c]);
+        }
+    }
+    double* out = Tpart + (int64_t)blockIdx.x * L * L;
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+        const int tj = wave + 4 * c;
+        if (tj < NT)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(int64_t)(16 * ti + q + 4 * r) * L + 16 * tj + x] = acc[c][r];
+    }
+}
+
+// out[r][j] = j < nlock ? a[r][j] : b[r][j]
+__global__ __launch_bounds__(256) void svd_select_cols_kernel(const double* __restrict__ a, const double* __restrict__ b, int nlock,
+                                                              int L, int64_t count, double* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    out[e] = (int)(e % L) < nlock ? a[e] : b[e];
+}
+
+// out = s1 * (ax . colscale) + s2 * x1 + s3 * x0     (column j of ax scaled by colscale[j] when given)
+__global__ __launch_bounds__(256) void svd_combine_kernel(const double* __restrict__ ax, const double* __restrict__ colscale,
+                                                          const double* __restrict__ x1, const double* __restrict__ x0,
+                                                          double s1, double s2, double s3, int L, int64_t count,
+                                                          double* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    double v = s1 * ax[e] * (colscale ? colscale[e % L] : 1.0) + s2 * x1[e];
+    if (x0) v += s3 * x0[e];
+    out[e] = v;
+}
+
 // ---- host: symmetric eigenproblem of an L x L matrix (cyclic threshold Jacobi) ----
 // a: in = the matrix (row-major, both triangles), out = destroyed; evec columns = eigenvectors,
 // eval descending.
@@ -223,9 +276,9 @@ void jacobi_eigh(int L, std::vector<double>& a, std::vector<double>& evec, std::
 struct SvdWork {
     nmfx_engine* E; int L, NT;
     double *Q = nullptr, *Qr = nullptr, *Z = nullptr, *Y = nullptr, *U = nullptr, *part = nullptr, *T = nullptr,
-           *M = nullptr, *sig = nullptr;
+           *M = nullptr, *sig = nullptr, *C1 = nullptr, *C2 = nullptr, *C3 = nullptr;
     int64_t part_count = 0;
-    ~SvdWork() { for (double* p : {Q, Qr, Z, Y, U, part, T, M, sig}) if (p) hipFree(p); }
+    ~SvdWork() { for (double* p : {Q, Qr, Z, Y, U, part, T, M, sig, C1, C2, C3}) if (p) hipFree(p); }
 };
 
 template <int NT>
@@ -266,6 +319,25 @@ int gram_to_host(SvdWork& w, const double* X, int64_t rows, std::vector<double>&
     NMFX_HIP(hipStreamSynchronize(E->stream));
     for (int i = 0; i < L; ++i)                        // exact symmetry for the host solver
         for (int j = i + 1; j < L; ++j) T[(size_t)j * L + i] = T[(size_t)i * L + j] = 0.5 * (T[(size_t)i * L + j] + T[(size_t)j * L + i]);
+    return NMFX_OK;
+}
+
+template <int NT>
+int cross_gram_to_host(SvdWork& w, const double* A, const double* B, int64_t rows, std::vector<double>& T)
+{
+    nmfx_engine* E = w.E;
+    constexpr int L = 16 * NT;
+    int64_t rpc = 512;
+    while (rows % rpc) rpc >>= 1;
+    const int64_t chunks = rows / rpc;
+    hipLaunchKernelGGL((svd_cross_gram_kernel<NT>), dim3((unsigned)chunks, NT), dim3(256), 0, E->stream, A, B, rpc, w.part);
+    NMFX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(svd_sum_kernel, dim3((unsigned)((L * L + 255) / 256)), dim3(256), 0, E->stream, w.part, (int)chunks,
+                       (int64_t)L * L, w.T);
+    NMFX_HIP(hipGetLastError());
+    T.resize((size_t)L * L);
+    NMFX_HIP(hipMemcpyAsync(T.data(), w.T, T.size() * 8, hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;
 }
 
@@ -326,7 +398,8 @@ int topk_svd(nmfx_engine* E, int k, double tol, int max_sweeps, uint64_t seed, d
     w.part_count = std::max<int64_t>({4 * std::max(mp, np) * L, (std::max(mp, np) / 128) * (int64_t)L * L, (int64_t)4096 * L});
     if ((rc = alloc(&w.Q, np * L)) || (rc = alloc(&w.Qr, np * L)) || (rc = alloc(&w.Z, np * L)) ||
         (rc = alloc(&w.Y, mp * L)) || (rc = alloc(&w.U, mp * L)) || (rc = alloc(&w.part, w.part_count)) ||
-        (rc = alloc(&w.T, (int64_t)L * L)) || (rc = alloc(&w.M, (int64_t)L * L)) || (rc = alloc(&w.sig, L))) return rc;
+        (rc = alloc(&w.T, (int64_t)L * L)) || (rc = alloc(&w.M, (int64_t)L * L)) || (rc = alloc(&w.sig, L)) ||
+        (rc = alloc(&w.C1, np * L)) || (rc = alloc(&w.C2, np * L)) || (rc = alloc(&w.C3, np * L))) return rc;
     {   // random start, zero in the padded rows
         std::vector<double> q0((size_t)np * L, 0.0);
         std::mt19937_64 gen(seed);
@@ -377,11 +450,81 @@ int topk_svd(nmfx_engine* E, int k, double tol, int max_sweeps, uint64_t seed, d
             }
         }
         if (worst <= tol || sweep >= max_sweeps) break;
-        // next block: Q = orthonormal basis of span(Z)
-        {
+        // next block.  Plain subspace iteration: Q = orth(Z) (= orth(A Qr), A = V^T V).  Its error
+        // shrinks by (s_{L+1} / s_k)^2 per sweep, which is hopeless without a gap behind the k-th
+        // singular value (noise bulk, real data): from the fourth sweep on the block is therefore
+        // passed through a Chebyshev polynomial of A that is small on [0, theta_L] (the block's
+        // smallest Ritz value bounds the unwanted spectrum) and grows fast above it (Zhou & Saad's
+        // filtered subspace iteration; scaled three-term recurrence, degree 10: the error then
+        // shrinks like exp(-2 d sqrt(gap)) instead of exp(-d gap) per d applications of A).
+        // The leading Ritz pairs that have converged are LOCKED: non-negative data always has one
+        // dominant singular value (here 30 x the next), and a polynomial that is large at theta_1 would
+        // wipe every other direction out of the block in double precision.  The filter therefore acts
+        // on the deflated operator A' = A - sum_locked theta_i q_i q_i^T and on the unlocked columns,
+        // and its degree is capped by the dynamic range it creates between theta_nl and theta_k.
+        int nl = 0;
+        while (nl < k && sigma[nl] > 0.0 && res[nl] / sigma[0] <= tol) ++nl;
+        const double cb = theta[L - 1], a0 = theta[std::min(nl, L - 1)];
+        int degree = 10;
+        if (cb > 1e-12 * a0 && a0 > 1.000001 * cb) {
+            const double e0 = 0.5 * cb;
+            auto grow = [&](double th) { const double xx = std::max((th - e0) / e0, 1.0); return xx + std::sqrt(xx * xx - 1.0); };
+            const double ratio = grow(a0) / std::max(grow(theta[k - 1]), 1.0);
+            if (ratio > 1.0) degree = (int)std::min(10.0, std::floor(std::log(1e9) / std::log(ratio)));
+        }
+        if (sweep < 3 || degree < 2 || !(cb > 1e-12 * a0) || !(a0 > 1.000001 * cb)) {
             std::vector<double> th2, S2;
             if ((rc = orthonormalize<NT>(w, w.Z, w.Q, np, th2, S2))) return rc;
             std::swap(w.Q, w.Z);                       // orthonormalize leaves its result in its first argument
+        } else {
+            const double e = 0.5 * cb, c = 0.5 * cb;
+            double sg = e / (a0 - c);
+            const double tau = 2.0 / sg;
+            const int64_t count = np * L;
+            const unsigned cgrid = (unsigned)((count + 255) / 256);
+            std::vector<double> Cm, D((size_t)L * L);
+            // A' X = A X - Qr D,  D[i][:] = theta_i (Qr^T X)[i][:] for the locked i
+            auto deflate = [&](const double* xin, double* axbuf) -> int {
+                if (nl == 0) return NMFX_OK;
+                int r2;
+                if ((r2 = cross_gram_to_host<NT>(w, w.Qr, xin, np, Cm))) return r2;
+                std::fill(D.begin(), D.end(), 0.0);
+                for (int i = 0; i < nl; ++i)
+                    for (int j = 0; j < L; ++j) D[(size_t)i * L + j] = theta[i] * Cm[(size_t)i * L + j];
+                if ((r2 = rotate<NT>(w, w.Qr, D, w.C3, np))) return r2;
+                hipLaunchKernelGGL(svd_combine_kernel, dim3(cgrid), dim3(256), 0, E->stream, w.C3, (const double*)nullptr, axbuf,
+                                   (const double*)nullptr, -1.0, 1.0, 0.0, L, count, axbuf);
+                NMFX_HIP(hipGetLastError());
+                return NMFX_OK;
+            };
+            // X0 = Qr;  A X0 = Z diag(sigma)  (made explicit in Z, then deflated)
+            double *x0 = w.Qr, *x1 = w.C1, *x2 = w.C2, *ax = w.Z;
+            hipLaunchKernelGGL(svd_combine_kernel, dim3(cgrid), dim3(256), 0, E->stream, ax, w.sig, ax, (const double*)nullptr,
+                               1.0, 0.0, 0.0, L, count, ax);
+            NMFX_HIP(hipGetLastError());
+            if ((rc = deflate(x0, ax))) return rc;
+            hipLaunchKernelGGL(svd_combine_kernel, dim3(cgrid), dim3(256), 0, E->stream, ax, (const double*)nullptr, x0,
+                               (const double*)nullptr, sg / e, -c * sg / e, 0.0, L, count, x1);
+            NMFX_HIP(hipGetLastError());
+            double* xprev = x0;                        // x0 must stay intact (it is Qr, the deflation basis)
+            for (int i = 2; i <= degree; ++i) {
+                const double sn = 1.0 / (tau - sg);
+                if ((rc = launch_apply<NT>(w, false, x1, w.Y))) return rc;           // V X1
+                if ((rc = launch_apply<NT>(w, true, w.Y, ax))) return rc;            // A X1
+                if ((rc = deflate(x1, ax))) return rc;
+                double* dst = (xprev == w.Qr) ? x2 : xprev;                          // never overwrite Qr
+                hipLaunchKernelGGL(svd_combine_kernel, dim3(cgrid), dim3(256), 0, E->stream, ax, (const double*)nullptr, x1, xprev,
+                                   2.0 * sn / e, -2.0 * sn * c / e, -sg * sn, L, count, dst);
+                NMFX_HIP(hipGetLastError());
+                xprev = x1; x1 = dst;
+                sg = sn;
+            }
+            // next block = [locked Ritz vectors | filtered columns], orthonormalised
+            hipLaunchKernelGGL(svd_select_cols_kernel, dim3(cgrid), dim3(256), 0, E->stream, w.Qr, x1, nl, L, count, ax);
+            NMFX_HIP(hipGetLastError());
+            std::vector<double> th2, S2;
+            if ((rc = orthonormalize<NT>(w, ax, w.C3, np, th2, S2))) return rc;
+            std::swap(w.Q, w.Z);                       // ax == w.Z holds the new block
         }
     }
     // polish U (orthonormal to rounding) and hand out the k leading triplets
