@@ -44,6 +44,16 @@ __device__ __forceinline__ void dma_run4(unsigned long long base, unsigned dst, 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory", "scc");
 }
+__device__ __forceinline__ void dma_run4_nt(unsigned long long base, unsigned dst, unsigned o0, unsigned o1,
+                                            unsigned o2, unsigned o3) {       // streaming (non-temporal) policy
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory", "scc");
+}
 __device__ __forceinline__ void dma_run2(unsigned long long base, unsigned dst, unsigned o0, unsigned o1) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
@@ -188,8 +198,8 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         ybase += 128ull; yq ^= 1;
     };
     auto issue_v = [&]() {                            // V loaders only
-        dma_run4(vbaseA, vdstA + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
-        dma_run4(vbaseB, vdstB + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
+        dma_run4_nt(vbaseA, vdstA + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
+        dma_run4_nt(vbaseB, vdstB + vq * 4096, voffs[0], voffs[1], voffs[2], voffs[3]);
         vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1;
     };
 
