@@ -54,7 +54,7 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
         const int64_t nobj = E->obj_count;             // the objective pass that ended the previous iteration
         if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;
         if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
-        if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, E->bt_split, nobj);
+        if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj);
         else {
             if ((rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
             rc = nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj);
@@ -79,7 +79,7 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
         { ProfScope ps(E, "sums");
-          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
           if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc; }
     } else {
     if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;

@@ -458,12 +458,12 @@ static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, d
         if ((rc = nmfx_bf16_images_h(E, false))) return rc;
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
-        if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+        if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
         if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
         if ((rc = nnls(E, E->HHt, (float)(2.0 * lam_w), E->Asum, W, 1, E->kp, E->m))) return rc;
         if ((rc = nmfx_bf16_images_w(E, W, 0))) return rc;
         if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
-        if (byprod) return nmfx_bf16_pack_t(E, E->G_part, E->bt_split, E->obj_count);
+        if (byprod) return nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), E->obj_count);
         if ((rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
         return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, E->obj_count);
     }

@@ -745,7 +745,7 @@ static int ao_h_products(nmfx_engine* E) {
     if (ao_bf16(E)) {
         if ((rc = ao_bf16_objective_product(E))) return rc;
         const int64_t nobj = (int64_t)(E->np / 128) * E->bt_split;
-        if (E->kp == 64) return nmfx_bf16_pack_t(E, E->G_part, E->bt_split, nobj);     // W^T W: by-product slabs
+        if (E->kp == 64) return nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj);     // W^T W: by-product slabs
         if ((rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
         return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj);
     }
@@ -869,7 +869,7 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
         const bool byprod = E->kp == 64;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
         { ProfScope ps(E, "sums");
-          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? E->bf_wsplit : E->gsplit, kk, E->HHt))) return rc;
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
           if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->auxW))) return rc; }
         return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);
     }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
-    int ngroups, const int* __restrict__ flag, int tiled)
+    int ngroups, const int* __restrict__ flag, int tiled, int ng)
 {
     if (*flag) return;
     constexpr int NJT = KP / 16;                      // factor tiles of the A-product
@@ -237,10 +237,13 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     f32x4 acc[NJT];
 #pragma unroll
     for (int j = 0; j < NJT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Gram by-product (KP = 64): the row blocks with blockIdx.x == 0 also accumulate Y Y^T over
-    // their column range from the Y fragments they fetch anyway (H H^T in the W phase, W^T W in
-    // the H phase).  Wave w owns tile row w>>1 and tile columns 2(w&1), 2(w&1)+1.
-    const bool do_gram = WITH_GRAM && (blockIdx.x == 0);
+    // Gram by-product (KP = 64): Y Y^T (H H^T in the W phase, W^T W in the H phase) from the Y tiles
+    // the blocks fetch anyway.  The work is SPREAD over the first `ng` row blocks -- row block b takes
+    // the groups with (grp - g0) % ng == b of every split -- because the 32 extra MFMAs per group made
+    // the single row block that used to do all of it the tail of the whole launch (W phase 150 us
+    // with it, 123 us without).  Slab (b, split) = gram_part[b * S + split].  Wave w owns tile row
+    // w>>1 and tile columns 2(w&1), 2(w&1)+1.
+    const bool do_gram = WITH_GRAM && ((int)blockIdx.x < ng);
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 }
                 NMFX_FENCE();
             }
-            if (WITH_GRAM && st == NA - 1 && do_gram) {
+            if (WITH_GRAM && st == NA - 1 && do_gram && ((grp - g0) % ng) == (int)blockIdx.x) {
                 // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
                 // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
 #pragma unroll
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             for (int r = 0; r < 4; ++r) out[(int64_t)(4 * g + r) * KP + jt * 16 + x] = acc[jt][r];
     }
     if (do_gram) {
-        float* go = gram_part + (int64_t)sp * KP * KP;
+        float* go = gram_part + ((int64_t)blockIdx.x * S + sp) * KP * KP;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -530,7 +533,7 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* p) {       // 8 con
 
 __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
-    const float* __restrict__ HHtpart, float lam, float* __restrict__ Wnew,
+    const float* __restrict__ HHtpart, int hslabs, float lam, float* __restrict__ Wnew,
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
@@ -566,13 +569,13 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
     {   // H H^T = sum of the W phase's by-product slabs (fixed order); the loads of four slabs
         // (16 x 16 bytes per thread) are in flight together -- a short row shard has many slabs
         float v[4][4] = {};
-        for (int p0 = 0; p0 < wsplit; p0 += 4) {
+        for (int p0 = 0; p0 < hslabs; p0 += 4) {
             float4 t[4][4];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    t[pp][u] = (p0 + pp < wsplit)
+                    t[pp][u] = (p0 + pp < hslabs)
                         ? reinterpret_cast<const float4*>(HHtpart + (int64_t)(p0 + pp) * KP * KP)[tid + 256 * u]
                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -783,7 +786,7 @@ bool nmfx_bf16_supported(const nmfx_engine* E) { return (E->kp == 64 || E->kp ==
 template <int KP, bool OBJ, bool KL>
 static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                         const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
-                        const unsigned short* Zlo, float* Apart, float* gram_part) {
+                        const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
     static bool attr = false;
@@ -791,18 +794,19 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
     if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                       gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0);
+                       gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0, ng);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
-                      const unsigned short* Zlo, float* Apart, float* gram_part, const char* name, bool kl = false) {
+                      const unsigned short* Zlo, float* Apart, float* gram_part, const char* name, bool kl = false,
+                      int ng = 1) {
     ProfScope ps(E, name);
     if (obj) E->obj_count = (R / 128) * splits;
 #define NMFX_XYT(KP_, OBJ_, KL_) \
-    launch_xyt_t<KP_, OBJ_, KL_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part)
+    launch_xyt_t<KP_, OBJ_, KL_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
     if (E->kp == 64) {
         if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
@@ -837,6 +841,9 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     ws2 = std::min<int64_t>(ws2, std::max<int64_t>(1, (np / 64) / 4));
     ws2 = std::min<int64_t>(ws2, E->wsplit);           // A_part was sized for wsplit slabs
     E->bf_wsplit = (int)ws2;
+    // row blocks that share the Gram by-product: few enough that the consumers' slab sums stay short
+    E->gram_ng_w = (int)std::min<int64_t>(8, mp / 128);
+    E->gram_ng_h = (int)std::min<int64_t>(4, np / 128);
     if ((rc = lazy_alloc(E, &E->Bt_part, hs2 * np * kp))) return rc;
     hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
                        E->V, np, E->Vt, mp);
@@ -877,7 +884,7 @@ int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl)
     const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                       z ? E->Whi[zbuf] : nullptr, z ? E->Wlo[zbuf] : nullptr, E->A_part,
-                      E->kp == 64 ? E->HHt_part : nullptr, name, kl);
+                      E->kp == 64 ? E->HHt_part : nullptr, name, kl, E->gram_ng_w);
 }
 
 // Bt_part[bt_split][np][kp] = V^T W (+ obj_part[(np/128) * bt_split] = residual objective, Z = H^T images)
@@ -886,7 +893,7 @@ int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl) {
     const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
                       z ? E->HThi : nullptr, z ? E->HTlo : nullptr, E->Bt_part,
-                      E->kp == 64 ? E->G_part : nullptr, name, kl);
+                      E->kp == 64 ? E->G_part : nullptr, name, kl, E->gram_ng_h);
 }
 
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
@@ -973,17 +980,17 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     float* Wnew = E->W[nxt];
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
     if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase"))) return rc;
+                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w))) return rc;
     { ProfScope ps(E, "w_update");
       hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
-                         E->bf_wsplit, E->mp, Wold, E->HHt_part, (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
+                         E->bf_wsplit, E->mp, Wold, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
                          E->WThi, E->WTlo, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase"))) return rc;
+                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h))) return rc;
     if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
-    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->bt_split,
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, nmfx_bf16_g_slabs(E),
                                  (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
@@ -1003,7 +1010,7 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
     }
     if (E->fused_pack)
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
-                           E->G_part, E->bt_split, E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
+                           E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
                            (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
                            E->Hhi, E->Hlo);
     else

@@ -69,6 +69,7 @@ struct nmfx_engine {
     bool bf_ready = false;
     bool fused_pack = false;       // nmfx_mur_run (single GPU): no pack launch, h_update reads the slabs
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
+    int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     bool ht_ready = false;         // H^T images are current (KL split-bf16 path)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
@@ -126,6 +127,8 @@ int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const 
                           int64_t nobj);
 int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj = 0);    // xf64[0] = sum obj_part (nobj 0: the f32 W phase's count)
 bool nmfx_bf16_supported(const nmfx_engine* E);
+inline int nmfx_bf16_hht_slabs(const nmfx_engine* E) { return E->gram_ng_w * E->bf_wsplit; }   // H H^T by-product slabs
+inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt_split; }      // W^T W by-product slabs
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
