@@ -171,6 +171,12 @@ def function_vectors():
         out["prox_l2n_aoadmm_raises"] = np.int64(0)
     except ValueError:
         out["prox_l2n_aoadmm_raises"] = np.int64(1)
+    # prox l1inf / l1inf_transpose (admm.py:158-210): rows that pass the sum test and rows that do not
+    aux_s = aux * np.linspace(0.02, 1.0, aux.shape[0])[:, None]
+    for tag, a_ in (("", aux), ("_mixed", aux_s)):
+        out["prox_l1inf" + tag] = quiet(ref_admm.prox, "l1inf", a_, dual, rho=2.5, lambda_=0.4)[0]
+        out["prox_l1inf_t" + tag] = quiet(ref_admm.prox, "l1inf_transpose", a_, dual, rho=2.5, lambda_=0.4)[0]
+    out["prox_l1inf_aux_mixed"] = aux_s
     # terminate (ao_admm.py:33-43), incl. zero dual -> inf
     mat, prev = np.abs(rs.randn(4, 7)), np.abs(rs.randn(4, 7))
     aux2 = mat + 1e-3 * rs.randn(4, 7)
@@ -267,6 +273,15 @@ def main():
                 dict(rho=2, distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=25, max_iter=25))
     solver_case("admm_eu_l2n", "admm", D, 8, 16,
                 dict(rho=1, distance_type="eu", reg_w=(0, "nn"), reg_h=(0.5, "l2n"), min_iter=25, max_iter=25))
+    # l1inf*: 6 iterations only -- as written the operator makes the iteration diverge (objective 4 -> 1e31
+    # within 25 iterations on this matrix) and amplify rounding differences ~10x per iteration, so longer
+    # runs pin nothing ("out of scope")
+    solver_case("admm_eu_l1inf", "admm", D, 8, 16,
+                dict(rho=1, distance_type="eu", reg_w=(0.05, "l1inf"), reg_h=(0.05, "l1inf"), min_iter=6, max_iter=6),
+                snaps=(1, 2))
+    solver_case("admm_eu_l1inf_t", "admm", D, 8, 16,
+                dict(rho=2, distance_type="eu", reg_w=(0.05, "l1inf_transpose"), reg_h=(0.05, "l1inf_transpose"),
+                     min_iter=6, max_iter=6), snaps=(1, 2))
     solver_case("admm_kl_nn", "admm", D, 8, 16,
                 dict(rho=1, distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=25, max_iter=25))
     # ---- ANLS ----

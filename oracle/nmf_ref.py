@@ -190,7 +190,48 @@ def prox(kind, aux, dual, *, rho=None, lam=None, ragged_raises=False):
         a = 1 / rho * (lam * t.T @ t + rho * sp.eye(n))
         out = spla.spsolve(a, aux - dual)
         return np.where(out < 0, 0, out)
+    if kind in ("l1inf", "l1inf_transpose"):
+        return prox_l1inf(aux, dual, rho, lam, by_columns=(kind == "l1inf_transpose"))
     raise TypeError("Unknown prox_type.")
+
+
+def prox_l1inf(aux, dual, rho, lam, by_columns=False, upper_bound=1):
+    """nmf/admm.py:158-183 ('l1inf', one vector per row) and :185-210
+    ('l1inf_transpose', one vector per column), restated as written -- including
+    the `aux + dual` sign of the shifted vector (the other prox types use
+    `aux - dual`), the sorted vector taken from `aux - dual`, the count that is one
+    less than the first failing index, and, by columns, the sorted vector built
+    with column 1 of the dual for every column (admm.py:196) and the clamp of
+    theta at zero (admm.py:206).  Only ADMM reaches these: in ao_admm the same
+    text divides by a zero count in its first call and the next Cholesky raises."""
+    a = aux.T if by_columns else aux
+    u = dual.T if by_columns else dual
+    out = np.zeros_like(a)
+    shift = lam / rho
+    pos = a + u - shift
+    pos = np.where(pos < 0, 0, pos)
+    length = a.shape[1]
+    for i in range(a.shape[0]):
+        if np.sum(pos[i]) <= upper_bound:
+            out[i] = pos[i]
+            continue
+        val = -np.sort(-(a[i] - (u[1] if by_columns else u[i])))
+        run = np.cumsum(val)
+        j = np.arange(1, length + 1)
+        test = rho * val + lam - rho / j * (run + shift - upper_bound)
+        bad = np.nonzero(test < 0)[0]
+        if bad.size:
+            count = int(bad[0])                 # first failing 1-based index, minus one
+            total = run[count]                  # sum of the first count + 1 entries
+        else:
+            count = length + 1
+            total = run[-1]
+        theta = rho / count * (total + shift - upper_bound)
+        if by_columns and not theta > 0:
+            theta = 0
+        z = a[i] + u[i] - shift - theta / rho
+        out[i] = np.where(z < 0, 0, z)
+    return out.T if by_columns else out
 
 
 def inner_residuals(mat, mat_prev, aux, dual):

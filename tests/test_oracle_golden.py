@@ -69,6 +69,10 @@ def test_function_vectors():
     for kind in ("nn", "l1n", "l2n"):
         got = R.prox(kind, f["prox_aux"], f["prox_dual"], rho=2.5, lam=0.4)
         assert close(got, f["prox_" + kind])
+    # l1inf / l1inf_transpose as written in admm.py:158-210; "_mixed" has rows on both sides of the sum test
+    for kind, key in (("l1inf", "prox_l1inf"), ("l1inf_transpose", "prox_l1inf_t")):
+        assert close(R.prox(kind, f["prox_aux"], f["prox_dual"], rho=2.5, lam=0.4), f[key])
+        assert close(R.prox(kind, f["prox_l1inf_aux_mixed"], f["prox_dual"], rho=2.5, lam=0.4), f[key + "_mixed"])
     assert int(f["prox_l2n_aoadmm_raises"]) == 1
     with pytest.raises(ValueError):
         R.prox("l2n", f["prox_aux"], f["prox_dual"], rho=2.5, lam=0.4, ragged_raises=True)
