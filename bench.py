@@ -229,7 +229,8 @@ def main():
     # sanity: objective history is finite and decreasing
     _, _, n_obj = eng.state()
     obj = eng.objectives(0, n_obj)
-    assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], "bench run produced a bad objective"
+    if not os.environ.get("NMFX_BENCH_NOASSERT"):      # (timing experiments with deliberately wrong kernels)
+        assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], "bench run produced a bad objective"
 
     # profiled pass: per-kernel device time from HIP events on the engine's stream
     roof = None

@@ -131,7 +131,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->H, kp * np));
     TRY(dev_alloc(E, &E->HHt, kp * kp));
     // (the split-bf16 path spreads its Gram by-products over up to 8 row blocks x splits slabs)
-    TRY(dev_alloc(E, &E->HHt_part, std::max<int64_t>(std::max(gs, ws), 8 * ws + 8) * kp * kp));
+    TRY(dev_alloc(E, &E->HHt_part, std::max<int64_t>(std::max(gs, ws), 40) * kp * kp));
     TRY(dev_alloc(E, &E->G_part, std::max<int64_t>(std::max(gs, hs), 4 * std::max<int64_t>(hs, (int64_t)ncu) + 8) * kp * kp));
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));

@@ -122,6 +122,12 @@ __device__ __forceinline__ uint2 lds_read_tr(const unsigned char* p) {
 // 2s + 1), and the B operand follows with two 8-byte reads of the same Y image instead of one
 // 16-byte read.  With WITH_OBJ the objective term x log(x / zy) - x + zy (nmf/utils.py:23-26) is
 // accumulated from the same registers.
+#ifdef NMFX_EXP_BLOCKTIME      // experiment (tools/lab/block_times.py): start / end time of every block of the last product launches
+__device__ unsigned long long nmfx_dbg_times[2][2][1024];      // [with objective][start | end][block]
+extern "C" int nmfx_debug_block_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmfx_dbg_times), sizeof(nmfx_dbg_times)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int KP, bool WITH_OBJ, bool KL>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
@@ -131,6 +137,10 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     int ngroups, const int* __restrict__ flag, int tiled, int ng)
 {
     if (*flag) return;
+#ifdef NMFX_EXP_BLOCKTIME
+    const int dbg_b = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && dbg_b < 1024) nmfx_dbg_times[WITH_OBJ][0][dbg_b] = wall_clock64();
+#endif
     constexpr int NJT = KP / 16;                      // factor tiles of the A-product
     constexpr int YT = KP * 128;                      // bytes of one Y tile (KP rows x 64 bf16)
     constexpr int YBUF = 2 * YT;                      // Yhi tile, Ylo tile
@@ -448,6 +458,10 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             for (int r = 0; r < 4; ++r)
                 go[(int64_t)(16 * git + 4 * g + r) * KP + 16 * (gj0 + c) + x] = gacc[c][r];
     }
+#ifdef NMFX_EXP_BLOCKTIME
+    __syncthreads();
+    if (threadIdx.x == 0 && dbg_b < 1024) nmfx_dbg_times[WITH_OBJ][1][dbg_b] = wall_clock64();
+#endif
     if (WITH_OBJ) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
@@ -841,9 +855,10 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     ws2 = std::min<int64_t>(ws2, std::max<int64_t>(1, (np / 64) / 4));
     ws2 = std::min<int64_t>(ws2, E->wsplit);           // A_part was sized for wsplit slabs
     E->bf_wsplit = (int)ws2;
-    // row blocks that share the Gram by-product: few enough that the consumers' slab sums stay short
-    E->gram_ng_w = (int)std::min<int64_t>(8, mp / 128);
-    E->gram_ng_h = (int)std::min<int64_t>(4, np / 128);
+    // row blocks that share the Gram by-product: every consumer block sums all ng x splits slabs
+    // (a chain of dependent L2 reads), so keep that product at 16 -- short shards already have many splits
+    E->gram_ng_w = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 16 / ws2), mp / 128));
+    E->gram_ng_h = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, 16 / hs2), np / 128));
     if ((rc = lazy_alloc(E, &E->Bt_part, hs2 * np * kp))) return rc;
     hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream,
                        E->V, np, E->Vt, mp);

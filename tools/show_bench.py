@@ -1,6 +1,7 @@
-"""Pretty-print the one-line JSON of bench.py read from stdin (value, ms/step, loop, kernels)."""
-import json, sys
-for ln in sys.stdin:
+"""Pretty-print the one-line JSON of bench.py (value, ms/step, loop, kernels): from the files named on the
+command line, or from stdin when there are none."""
+import fileinput, json, sys
+for ln in fileinput.input():
     ln = ln.strip()
     if not ln.startswith("{"):
         continue
