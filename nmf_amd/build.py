@@ -43,6 +43,11 @@ def build(force=False, verbose=True):
     srcs = sorted(f for f in os.listdir(SRC) if f.endswith(".hip"))
     hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "nmfx.h"))
+    # a change of flags (NMFX_EXTRA_DEFS experiments) rebuilds everything, in both directions
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     jobs = []
     for s in srcs:
         src = os.path.join(SRC, s)
@@ -66,6 +71,8 @@ def build(force=False, verbose=True):
                 sys.stderr.write(f"hipcc failed: {src}\n")
     if failed:
         raise RuntimeError("libnmfx build failed")
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
