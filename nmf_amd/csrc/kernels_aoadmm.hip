@@ -20,6 +20,7 @@
 // numbers in the same order, so all agree) and turns into a no-op once it fired.
 #include "nmfx_internal.h"
 #include "kernels_small.h"
+#include <cstdlib>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -119,6 +120,167 @@ __global__ __launch_bounds__((KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4)
             *reinterpret_cast<float4*>(Minv + (int64_t)(4 * ti + r) * KP + 4 * tj) =
                 make_float4((float)a[r][0], (float)a[r][1], (float)a[r][2], (float)a[r][3]);
     }
+}
+
+// The same inverse for KP = 64 / 128 as a BLOCKED Gauss-Jordan on v_mfma_f64_16x16x4_f64: the scalar
+// kernel above pays one workgroup barrier per pivot (128 of them at ~1 us), this one pays one per
+// 16 x 16 block step.  NB = KP / 16 waves; wave w keeps block row w (NB tiles of 16 x 16 f64) in
+// registers in the MFMA C/D layout (lane: column c = lane & 15, rows q + 4 r, q = lane >> 4).
+// Block step kb:
+//   (a) wave kb inverts its diagonal tile D in place (16 scalar pivots inside ONE wave, row broadcast by
+//       ds_bpermute, column broadcast by DPP row_share, no barrier; these are the pivots of the unblocked
+//       elimination, so "not positive definite" is detected on the same condition),
+//   (b) wave kb turns its row panel into D^-1 T[kb][j] (MFMA) and publishes it with D^-1,
+//       -- one workgroup barrier --
+//   (c) every other wave i: T[i][j] -= T[i][kb] (D^-1 T[kb][j]),  T[i][kb] = -T[i][kb] D^-1  (MFMA).
+// Wave kb+1 goes on to (a), (b) of the next step as soon as its own (c) is done; the published
+// panels are double buffered, so the one barrier per step is enough.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// value of lane P of the caller's row of 16 lanes (DPP row_share: a VALU move, no LDS round trip)
+template <int P> __device__ __forceinline__ double row_share_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + P, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + P, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// One scalar pivot of the in-wave 16 x 16 Gauss-Jordan (tile in the C/D layout: a[r] = D[q + 4r][c]).
+// Row P lives in the lanes with q == P & 3 (one ds_bpermute brings it to every row of lanes), column P
+// in lane P of every row of lanes (row_share).  Same adjusted-pivot update as the scalar kernel.
+template <int P> __device__ __forceinline__ bool gj16_pivot(f64x4& a, int c, int q) {
+    const double rowp = __shfl(a[P >> 2], (P & 3) * 16 + c, 64);       // D[P][c]
+    const double piv = row_share_f64<P>(rowp);                          // D[P][P]
+    if (!(piv > 0.0)) return false;                                     // scipy cholesky would raise LinAlgError
+    double inv = __builtin_amdgcn_rcp(piv);                             // + two Newton steps: full f64 accuracy
+    inv = fma(fma(-piv, inv, 1.0), inv, inv);
+    inv = fma(fma(-piv, inv, 1.0), inv, inv);
+    const double rv = (c == P) ? 1.0 + inv : rowp * inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double colv = row_share_f64<P>(a[r]);                     // D[q + 4r][P]
+        const double cv = (q + 4 * r == P) ? piv - 1.0 : colv;
+        a[r] = fma(-cv, rv, a[r]);
+    }
+    return true;
+}
+
+template <int KP>
+__global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
+    const float* __restrict__ src, int k, float* __restrict__ Minv, DevState* __restrict__ st,
+    int record_obj, const double* __restrict__ xf64, long long j, long long min_iter,
+    double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho)
+{
+    if (st->flag) return;
+    if (record_obj) {
+        const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
+                                               threadIdx.x == 0);
+        if (rule) return;
+    }
+    constexpr int NB = KP / 16, LDP = KP + 2, LDD = 17;
+    extern __shared__ __attribute__((aligned(16))) double prep_lds[];
+    double* dinv = prep_lds;                            // [2][16][LDD]   D^-1 of the step (A and B operand source)
+    double* rown = dinv + 2 * 16 * LDD;                 // [2][16][LDP]   new row panel of the step
+    double* rowo = rown + 2 * 16 * LDP;                 // [16][LDP]      old row panel (owner wave only)
+    double* colp = rowo + 16 * LDP;                     // [NB][16][LDD]  own column tile of every wave
+    double* misc = colp + NB * 16 * LDD;                // [0] rho, [1] bad
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
+
+    if (w == 0) {                                       // rho = trace(G) / k (ao_admm.py:54), or the fixed one (ADMM)
+        double tr = 0.0;
+        for (int i = lane; i < k; i += 64) tr += (double)src[(int64_t)i * KP + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
+        if (lane == 0) {
+            const double rho = (fixed_rho >= 0.0) ? fixed_rho : tr / (double)k;
+            misc[0] = rho; misc[1] = 0.0;
+            st->rho = rho; st->inner_stop = 0; st->inner_count = 0;
+        }
+    }
+    f64x4 t[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[jb][r] = (double)src[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c];
+    __syncthreads();
+    const double rho = misc[0];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+        if (jb == w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (q + 4 * r == c) t[jb][r] += rho;
+        }
+
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        double* dv = dinv + (kb & 1) * 16 * LDD;
+        double* rn = rown + (kb & 1) * 16 * LDP;
+        if (w == kb) {
+            // (a) in-wave inversion of the diagonal tile; same adjusted-pivot update as the scalar kernel
+            f64x4 a = t[kb];
+            const bool bad = !(gj16_pivot<0>(a, c, q) && gj16_pivot<1>(a, c, q) && gj16_pivot<2>(a, c, q) &&
+                               gj16_pivot<3>(a, c, q) && gj16_pivot<4>(a, c, q) && gj16_pivot<5>(a, c, q) &&
+                               gj16_pivot<6>(a, c, q) && gj16_pivot<7>(a, c, q) && gj16_pivot<8>(a, c, q) &&
+                               gj16_pivot<9>(a, c, q) && gj16_pivot<10>(a, c, q) && gj16_pivot<11>(a, c, q) &&
+                               gj16_pivot<12>(a, c, q) && gj16_pivot<13>(a, c, q) && gj16_pivot<14>(a, c, q) &&
+                               gj16_pivot<15>(a, c, q));
+            if (bad) { if (lane == 0) misc[1] = 1.0; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dv[(q + 4 * r) * LDD + c] = a[r];
+                // (b) row panel: old tiles through LDS into the B layout, new = D^-1 * old
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rowo[(q + 4 * r) * LDP + 16 * jb + c] = t[jb][r];
+                __builtin_amdgcn_wave_barrier();
+                double af[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) af[s4] = dv[c * LDD + 4 * s4 + q];
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    if (jb == kb) { t[jb] = a; continue; }
+                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(af[s4], rowo[(4 * s4 + q) * LDP + 16 * jb + c], acc);
+                    t[jb] = acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rn[(q + 4 * r) * LDP + 16 * jb + c] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (misc[1] != 0.0) {
+            if (tid == 0) { st->notpd = 1; st->flag = 3; }
+            return;
+        }
+        if (w != kb) {
+            // (c) A operand = -T[w][kb] (through this wave's own LDS tile), B = the published panel / D^-1
+            double* cp = colp + w * 16 * LDD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[(q + 4 * r) * LDD + c] = t[kb][r];
+            __builtin_amdgcn_wave_barrier();
+            double af[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) af[s4] = -cp[c * LDD + 4 * s4 + q];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                if (jb == kb) {
+                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(af[s4], dv[(4 * s4 + q) * LDD + c], acc);
+                    t[jb] = acc;
+                } else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) t[jb] = MFMA_F64(af[s4], rn[(4 * s4 + q) * LDP + 16 * jb + c], t[jb]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Minv[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c] = (float)t[jb][r];
 }
 
 // ---- inner stop test -------------------------------------------------------
@@ -647,6 +809,21 @@ int nmfx_aoadmm_alloc(nmfx_engine* E) {
 template <int KP>
 static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
                           double tol1, double tol2, double fixed_rho) {
+    static const bool scalar = getenv("NMFX_PREPARE_SCALAR") != nullptr;      // the one-barrier-per-pivot kernel
+    if constexpr (KP >= 64) {
+        if (!scalar) {
+            constexpr int NB = KP / 16;
+            constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 2) * sizeof(double);
+            static bool attr = false;
+            if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+            hipLaunchKernelGGL((ao_prepare_mfma_kernel<KP>), dim3(1), dim3(KP * 4), shm, E->stream, src, E->k, E->Minv,
+                               E->state, record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                               E->obj_hist, fixed_rho);
+            NMFX_HIP(hipGetLastError());
+            return NMFX_OK;
+        }
+    }
     constexpr int NT = (KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4);
     hipLaunchKernelGGL((ao_prepare_kernel<KP>), dim3(1), dim3(NT), 0, E->stream, src, E->k, E->Minv, E->state,
                        record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
