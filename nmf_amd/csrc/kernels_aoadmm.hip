@@ -529,47 +529,109 @@ __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
     if (threadIdx.x == 0) { *slot = count | (fired << 16); st->inner_stop = 0; }
 }
 
+// The decision of a speculative launch, derived identically by EVERY block of the launch that follows it:
+// the first round whose four norm sums satisfy `terminate` (ao_admm.py:33-43), i.e. how many rounds count.
+// Wave w sums component w of up to 8 rounds at a time (their loads are in flight together); per (round,
+// component) the per-lane strides and the shuffle tree are those of inner_round_fired, so the sums are
+// the same numbers.  sh: 32 doubles.  256 threads.
+__device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_rounds, int nblk, int admm_iter,
+                                            double* sh, int* fired_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int count = admm_iter, fired = 0;
+    for (int r0 = 0; r0 < admm_iter && !fired; r0 += 8) {
+        double sums[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sums[u] = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + u < admm_iter) sums[u] += nrm_rounds[((int64_t)(r0 + u) * nblk + b) * 4 + wave];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sums[u] += __shfl_down(sums[u], off, 64);
+            if (lane == 0) sh[u * 4 + wave] = sums[u];
+        }
+        __syncthreads();
+        // the f64 square roots and divisions of one test are ~1500 cycles: lane u tests round r0 + u
+        bool hit = false;
+        if (lane < 8 && r0 + lane < admm_iter) {
+            const double r = sqrt(sh[lane * 4 + 0]) / sqrt(sh[lane * 4 + 1]);  // ||X - aux|| / ||X||
+            const double d = sqrt(sh[lane * 4 + 2]) / sqrt(sh[lane * 4 + 3]);  // ||X - X_prev|| / ||U||
+            hit = (r < 1e-2) && (d < 1e-2);
+        }
+        const unsigned long long mask = __ballot(hit);                          // the same in every wave
+        if (mask) { count = r0 + __ffsll((long long)mask); fired = 1; }
+        __syncthreads();
+    }
+    *fired_out = fired;
+    return count;
+}
+
 // ---- all rounds of a sub-problem in ONE launch ------------------------------
 // A round only couples the blocks through `terminate` (four global norms, ao_admm.py:33-43).
 // The fused kernels therefore run ALL admm_iter rounds speculatively with X, U (and the
 // right-hand side) resident in registers / LDS, leave the per-round norm partials in
 // nrm_rounds[round][block][4] and a copy of the initial X, U in the backup buffers.
-// ao_fused_decide_kernel then finds the round at which the reference would have stopped; if that
-// is before the last round, the same kernel is launched again in REPAIR mode: it restarts from
-// the backup and runs exactly that many rounds (the common case -- no early stop -- costs one
-// no-op launch).  Same arithmetic, same norm partials, same inner counts as the round-by-round
-// kernels above, 3 launches instead of admm_iter + 1.
+// The same kernel is then launched again in REPAIR mode: every block first finds, from those partials,
+// the round at which the reference would have stopped (fused_decide; block 0 records it); only if that is
+// before the last round does it restart from the backup and run exactly that many rounds (the common
+// case -- no early stop -- is a launch that reads 80 KiB per block and leaves).  Same arithmetic and
+// inner counts as the round-by-round kernels above, 2 launches instead of admm_iter + 1.
 //
-// H side: block = 64 columns, wave w owns the factor tiles w, w + 4, ...; M^-1 staged in LDS once.
-template <int KP>
+// H side: block = CB columns (64, or 32 when 64-column blocks would leave CUs idle: the rounds are bound
+// by the f32 MFMA rate of the CU a block runs on), wave w owns the factor tiles w, w + 4, ...; M^-1 staged
+// in LDS once.  Lane (x, q) holds columns NE x .. NE x + NE - 1 (NE = CB / 16) of rows 16 it + 4 q + g.
+template <int NE> struct VecN;
+template <> struct VecN<4> { typedef float4 T; };
+template <> struct VecN<2> { typedef float2 T; };
+template <int NE> __device__ __forceinline__ void ldv(float* d, const float* p) {
+    const typename VecN<NE>::T v = *reinterpret_cast<const typename VecN<NE>::T*>(p);
+    const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) d[e] = f[e];
+}
+template <int NE> __device__ __forceinline__ void stv(float* p, const float* s) {
+    typename VecN<NE>::T v;
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) f[e] = s[e];
+    *reinterpret_cast<typename VecN<NE>::T*>(p) = v;
+}
+
+template <int KP, int CB>
 __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int64_t np, int prox, float lam, int admm_iter,
-    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair)
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot)
 {
     if (st->flag) return;
-    int rounds = admm_iter;
-    if (repair) {
-        rounds = st->inner_count;
-        if (rounds >= admm_iter) return;               // nothing to repair: the speculative result stands
-    }
     constexpr int JT = KP / 16;
     constexpr int ITW = (JT + 3) / 4;
     constexpr int LDM = KP + 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [KP][64] | M^-1 [KP][LDM] | 16 doubles
-    float* ms = lds + KP * 64;
+    constexpr int NE = CB / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [KP][CB] | M^-1 [KP][LDM] | 32 doubles
+    float* ms = lds + KP * CB;
     double* sh = reinterpret_cast<double*>(ms + KP * LDM);
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
-    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    int rounds = admm_iter;
+    if (repair) {
+        int fired;
+        rounds = fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
+        if (blockIdx.x == 0 && tid == 0) { st->inner_count = rounds; st->inner_stop = 0; *slot = rounds | (fired << 16); }
+        if (rounds >= admm_iter) return;               // nothing to repair: the speculative result stands
+    }
+    const int64_t c0 = (int64_t)blockIdx.x * CB;
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
     for (int i = tid; i < KP * (KP / 4); i += 256) {
         const int r = i / (KP / 4), c4 = i % (KP / 4);
         *reinterpret_cast<float4*>(ms + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
     }
-    // this wave's part of X, U, B in the accumulator layout: [r][g] = rows 16 it + 4 q + g, columns 4 x .. 4 x + 3
-    float4 hx[ITW][4], ux[ITW][4], bx[ITW][4];
+    float hx[ITW][4][NE], ux[ITW][4][NE], bx[ITW][4][NE];
     const float* srcX = repair ? Xb : X;
     const float* srcU = repair ? Ub : U;
 #pragma unroll
@@ -578,13 +640,13 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
         if (it < JT) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
-                hx[r][g] = *reinterpret_cast<const float4*>(srcX + idx);
-                ux[r][g] = *reinterpret_cast<const float4*>(srcU + idx);
-                bx[r][g] = *reinterpret_cast<const float4*>(Bsum + idx);
+                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + NE * x;
+                ldv<NE>(hx[r][g], srcX + idx);
+                ldv<NE>(ux[r][g], srcU + idx);
+                ldv<NE>(bx[r][g], Bsum + idx);
                 if (!repair) {
-                    *reinterpret_cast<float4*>(Xb + idx) = hx[r][g];
-                    *reinterpret_cast<float4*>(Ub + idx) = ux[r][g];
+                    stv<NE>(Xb + idx, hx[r][g]);
+                    stv<NE>(Ub + idx, ux[r][g]);
                 }
             }
         }
@@ -597,50 +659,63 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
             if (it < JT) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 t;
-                    t.x = bx[r][g].x + rho * (hx[r][g].x + ux[r][g].x); t.y = bx[r][g].y + rho * (hx[r][g].y + ux[r][g].y);
-                    t.z = bx[r][g].z + rho * (hx[r][g].z + ux[r][g].z); t.w = bx[r][g].w + rho * (hx[r][g].w + ux[r][g].w);
-                    *reinterpret_cast<float4*>(lds + (16 * it + 4 * q + g) * 64 + 4 * x) = t;
+                    float t[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) t[e] = bx[r][g][e] + rho * (hx[r][g][e] + ux[r][g][e]);
+                    stv<NE>(lds + (16 * it + 4 * q + g) * CB + NE * x, t);
                 }
             }
         }
         __syncthreads();
         float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+        // CB = 32: the wave's B fragments of the whole RHS tile (KP x NE floats per lane) are read ONCE per
+        // round and shared by its row tiles; read inside the MFMA loop they cost one LDS latency per k-step
+        constexpr bool PRE = (CB == 32);
+        float rball[PRE ? JT : 1][4][NE];
+        if (PRE) {
+#pragma unroll
+            for (int u = 0; u < JT; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) ldv<NE>(rball[PRE ? u : 0][s2], lds + (16 * u + 4 * q + s2) * CB + NE * x);
+        }
 #pragma unroll
         for (int r = 0; r < ITW; ++r) {
             const int it = wave + 4 * r;
             if (it < JT) {
-                f32x4 acc[4];
+                f32x4 acc[NE];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < NE; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float4 mfa[JT];
+#pragma unroll
+                for (int u = 0; u < JT; ++u)
+                    mfa[u] = *reinterpret_cast<const float4*>(ms + (16 * it + x) * LDM + 16 * u + 4 * q);
 #pragma unroll
                 for (int u = 0; u < JT; ++u) {
-                    const float4 mf = *reinterpret_cast<const float4*>(ms + (16 * it + x) * LDM + 16 * u + 4 * q);
-                    const float ma[4] = {mf.x, mf.y, mf.z, mf.w};
+                    const float ma[4] = {mfa[u].x, mfa[u].y, mfa[u].z, mfa[u].w};
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) {
-                        const float4 rb = *reinterpret_cast<const float4*>(lds + (16 * u + 4 * q + s2) * 64 + 4 * x);
-                        acc[0] = MFMA(ma[s2], rb.x, acc[0]);
-                        acc[1] = MFMA(ma[s2], rb.y, acc[1]);
-                        acc[2] = MFMA(ma[s2], rb.z, acc[2]);
-                        acc[3] = MFMA(ma[s2], rb.w, acc[3]);
+                        float rb[NE];
+                        if (PRE) {
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) rb[e] = rball[PRE ? u : 0][s2][e];
+                        } else {
+                            ldv<NE>(rb, lds + (16 * u + 4 * q + s2) * CB + NE * x);
+                        }
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = MFMA(ma[s2], rb[e], acc[e]);
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float ax[4] = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
-                    const float ho[4] = {hx[r][g].x, hx[r][g].y, hx[r][g].z, hx[r][g].w};
-                    const float uo[4] = {ux[r][g].x, ux[r][g].y, ux[r][g].z, ux[r][g].w};
-                    float hn[4], un[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hn[e] = prox_apply(ax[e], uo[e], shift);
-                        un[e] = uo[e] + hn[e] - ax[e];
-                        const float d0 = hn[e] - ax[e], d2 = hn[e] - ho[e];
-                        n0 += d0 * d0; n1 += hn[e] * hn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
+                    for (int e = 0; e < NE; ++e) {
+                        const float ax = acc[e][g], ho = hx[r][g][e], uo = ux[r][g][e];
+                        const float hn = prox_apply(ax, uo, shift);
+                        const float un = uo + hn - ax;
+                        const float d0 = hn - ax, d2 = hn - ho;
+                        n0 += d0 * d0; n1 += hn * hn; n2 += d2 * d2; n3 += un * un;
+                        hx[r][g][e] = hn; ux[r][g][e] = un;
                     }
-                    hx[r][g] = make_float4(hn[0], hn[1], hn[2], hn[3]);
-                    ux[r][g] = make_float4(un[0], un[1], un[2], un[3]);
                 }
             }
         }
@@ -653,9 +728,9 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
         if (it < JT) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
-                *reinterpret_cast<float4*>(X + idx) = hx[r][g];
-                *reinterpret_cast<float4*>(U + idx) = ux[r][g];
+                const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + NE * x;
+                stv<NE>(X + idx, hx[r][g]);
+                stv<NE>(U + idx, ux[r][g]);
             }
         }
     }
@@ -667,22 +742,24 @@ template <int KP>
 __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
     const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
-    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair)
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot)
 {
     if (st->flag) return;
-    int rounds = admm_iter;
-    if (repair) {
-        rounds = st->inner_count;
-        if (rounds >= admm_iter) return;
-    }
     constexpr int JT = KP / 16;
     constexpr int LDM = KP + 4;
     constexpr int LDR = KP + 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS 4 x [16][LDR] | 16 doubles
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS 4 x [16][LDR] | 32 doubles
     float* rs = lds + KP * LDM;
     double* sh = reinterpret_cast<double*>(rs + 64 * LDR);
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    int rounds = admm_iter;
+    if (repair) {
+        int fired;
+        rounds = fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
+        if (blockIdx.x == 0 && tid == 0) { st->inner_count = rounds; st->inner_stop = 0; *slot = rounds | (fired << 16); }
+        if (rounds >= admm_iter) return;
+    }
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
     for (int i = tid; i < KP * (KP / 4); i += 256) {
@@ -745,19 +822,6 @@ __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
             const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
             X[idx] = wx[it][g]; U[idx] = dx[it][g];
         }
-}
-
-// The round at which `terminate` first fires decides how many rounds count: inner_count (what the
-// repair launch restarts for) and the (rounds | fired << 16) word of this sub-problem.
-__global__ __launch_bounds__(256) void ao_fused_decide_kernel(
-    DevState* __restrict__ st, const double* __restrict__ nrm_rounds, int nblk, int admm_iter, int32_t* __restrict__ slot)
-{
-    if (st->flag) return;
-    __shared__ double sh[16];
-    int count = admm_iter, fired = 0;
-    for (int r = 0; r < admm_iter; ++r)
-        if (inner_round_fired(nrm_rounds + (int64_t)r * nblk * 4, nblk, sh)) { count = r + 1; fired = 1; break; }
-    if (threadIdx.x == 0) { st->inner_count = count; st->inner_stop = 0; *slot = count | (fired << 16); }
 }
 
 // Row-sharded runs: this rank's four norm sums of round `round` -> out[0..3] (fixed order), to be
@@ -963,7 +1027,7 @@ static int ao_fused_alloc(nmfx_engine* E, int admm_iter) {
     const int64_t big = std::max(E->mp, E->np) * E->kp;
     if ((rc = lazy_alloc(E, &E->bkX, big))) return rc;
     if ((rc = lazy_alloc(E, &E->bkU, big))) return rc;
-    const int64_t need = (int64_t)admm_iter * (std::max(E->mp, E->np) / 64) * 4 + 64;
+    const int64_t need = (int64_t)admm_iter * std::max(E->mp / 64, E->np / 32) * 4 + 64;
     if (need > E->nrm_rounds_cap) {
         if (E->nrm_rounds) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->nrm_rounds); E->nrm_rounds = nullptr; }
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->nrm_rounds), (size_t)need * sizeof(double)));
@@ -973,26 +1037,34 @@ static int ao_fused_alloc(nmfx_engine* E, int admm_iter) {
     return NMFX_OK;
 }
 
-template <int KP>
-static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter, int repair) {
-    const size_t shm = (size_t)(KP * 64 + KP * (KP + 4)) * sizeof(float) + 16 * sizeof(double);
-    auto kern = ao_fused_cols_kernel<KP>;
+// columns per block of the fused H-side kernel: 32 when 64-column blocks would not fill the CUs
+static int ao_fused_cols_cb(const nmfx_engine* E) { return (E->np / 64 < (int64_t)E->ncu) ? 32 : 64; }
+
+template <int KP, int CB>
+static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+    const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
+    auto kern = ao_fused_cols_kernel<KP, CB>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
-                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, repair);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
+                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
+template <int KP>
+static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+    return ao_fused_cols_cb(E) == 32 ? launch_fused_cols_cb<KP, 32>(E, prox, lam, admm_iter, repair, slot)
+                                     : launch_fused_cols_cb<KP, 64>(E, prox, lam, admm_iter, repair, slot);
+}
 
 template <int KP>
-static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair) {
-    const size_t shm = (size_t)(KP * (KP + 4) + 64 * (KP + 4)) * sizeof(float) + 16 * sizeof(double);
+static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+    const size_t shm = (size_t)(KP * (KP + 4) + 64 * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, E->auxW, W, E->dualW, E->bkX, E->bkU,
-                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair);
+                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -1003,25 +1075,20 @@ static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, fl
     for (int repair = 0; repair < 2; ++repair) {
         if (cols) {
             switch (E->kp) {
-                case 16: rc = launch_fused_cols<16>(E, prox, lam, admm_iter, repair); break;
-                case 32: rc = launch_fused_cols<32>(E, prox, lam, admm_iter, repair); break;
-                case 64: rc = launch_fused_cols<64>(E, prox, lam, admm_iter, repair); break;
-                default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, repair); break;
+                case 16: rc = launch_fused_cols<16>(E, prox, lam, admm_iter, repair, slot); break;
+                case 32: rc = launch_fused_cols<32>(E, prox, lam, admm_iter, repair, slot); break;
+                case 64: rc = launch_fused_cols<64>(E, prox, lam, admm_iter, repair, slot); break;
+                default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, repair, slot); break;
             }
         } else {
             switch (E->kp) {
-                case 16: rc = launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair); break;
-                case 32: rc = launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair); break;
-                case 64: rc = launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair); break;
-                default: rc = launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair); break;
+                case 16: rc = launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair, slot); break;
+                case 32: rc = launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair, slot); break;
+                case 64: rc = launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair, slot); break;
+                default: rc = launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair, slot); break;
             }
         }
         if (rc) return rc;
-        if (repair == 0) {
-            hipLaunchKernelGGL(ao_fused_decide_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_rounds,
-                               (int)((cols ? E->np : E->mp) / 64), admm_iter, slot);
-            NMFX_HIP(hipGetLastError());
-        }
     }
     return NMFX_OK;
 }
