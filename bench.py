@@ -252,7 +252,7 @@ def main():
             nbytes = ml * n * 4.0 + 2.0 * ml * k * 4
             if precision == "bf16":
                 ach = nbytes / sec / 1e9
-                roof = {"kernel": "xyt_bf16_kernel<64, true, false> (W phase)", "bound": "hbm", "achieved": ach,
+                roof = {"kernel": "xyt_bf16_kernel<64, true, false, 3> (W phase)", "bound": "hbm", "achieved": ach,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": nbytes,
                         "algorithmic_tflops": flops / sec / 1e12}
@@ -317,7 +317,7 @@ def main():
             "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "preheat_iterations": args.preheat,
-            "dtype": "bf16 hi+lo split MFMA, f32 accumulate, f64 objective" if precision == "bf16" else "f32",
+            "dtype": "bf16 hi+lo split MFMA (3 terms), f32 accumulate, f64 objective" if precision == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
                                    "|randn| init, objective every iteration",

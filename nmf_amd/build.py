@@ -18,8 +18,6 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-ffp-contract=off"]
 if os.environ.get("NMFX_EXTRA_DEFS"):          # e.g. "-DNMFX_NNLS_STATS" for tools/anls_perf.py --stats
     FLAGS.extend(os.environ["NMFX_EXTRA_DEFS"].split())
-if os.environ.get("NMFX_BF16_TERMS"):
-    FLAGS.append("-DNMFX_BF16_TERMS=" + os.environ["NMFX_BF16_TERMS"])
 
 
 def _hipcc():

@@ -18,10 +18,18 @@
 // produced (W: [m][64] for the residual and [64][m] for the H phase; H: [64][n]).
 #include "nmfx_internal.h"
 #include "kernels_small.h"
+#include <cstdlib>
 
-#ifndef NMFX_BF16_TERMS
-#define NMFX_BF16_TERMS 4      // 4: hi*hi + hi*lo + lo*hi + lo*lo;  3: without lo*lo (2^-16 relative, random sign)
-#endif
+// Terms of a split product x y with x = xh + xl + ex, y = yh + yl + ey (|xl| <= 2^-8 |x|, |ex| <= 2^-16 |x|):
+//   4: xh yh + xh yl + xl yh + xl yl;
+//   3: without xl yl.  The dropped term is <= 2^-16 |x y|, the size of the representation errors ex y + x ey
+//      that the four-term form has anyway (worst case 3 x 2^-16 instead of 2 x 2^-16, random signs), and it is
+//      25 % of the MFMAs: the W phase of config 2 takes 121-125 us instead of 139-141 on the same box.
+// The multiplicative updates (MUR, both divergences) take 3: an update is a ratio of two such sums and the
+// iteration is self-correcting.  The solvers that put the products into normal equations (ANLS, ADMM,
+// AO-ADMM) keep 4: there the same perturbation is amplified by the conditioning of the Gram matrix (ANLS
+// test matrix 300 x 220, k = 40: objective history 8e-4 off the oracle with 3 terms, < 5e-4 with 4).
+// NMFX_BF16_TERMS=4 in the environment forces 4 everywhere.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union Frag8 { uint4 u; bf16x8 v; };
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
@@ -128,7 +136,7 @@ extern "C" int nmfx_debug_block_times(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmfx_dbg_times), sizeof(nmfx_dbg_times)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int KP, bool WITH_OBJ, bool KL>
+template <int KP, bool WITH_OBJ, bool KL, int TERMS>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -361,8 +369,10 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fh[set][j], acc[j0 + j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vh[ks], fl[set][j], acc[j0 + j]);
+                if (TERMS >= 4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fl[set][j], acc[j0 + j]);
+                    for (int j = 0; j < 4; ++j) acc[j0 + j] = MFMA_BF16(vl[ks], fl[set][j], acc[j0 + j]);
+                }
             } else {
                 const int s = KL ? st : st - NA;
 #pragma unroll
@@ -371,8 +381,10 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zh[WITH_D ? s : 0], d[e]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zl[WITH_D ? s : 0], d[e]);
+                if (TERMS >= 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_D ? s : 0], d[e]);
+                    for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_D ? s : 0], d[e]);
+                }
             }
             NMFX_FENCE();
             if (KL && st == ND - 1) {
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                         gacc[c] = MFMA_BF16(ah, bh, gacc[c]);
                         gacc[c] = MFMA_BF16(al, bh, gacc[c]);
                         gacc[c] = MFMA_BF16(ah, bl, gacc[c]);
-                        gacc[c] = MFMA_BF16(al, bl, gacc[c]);
+                        if (TERMS >= 4) gacc[c] = MFMA_BF16(al, bl, gacc[c]);
                     }
                 }
             }
@@ -797,14 +809,14 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 
 bool nmfx_bf16_supported(const nmfx_engine* E) { return (E->kp == 64 || E->kp == 128) && E->mp % 128 == 0 && E->np % 128 == 0; }
 
-template <int KP, bool OBJ, bool KL>
+template <int KP, bool OBJ, bool KL, int TERMS>
 static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                         const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                         const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
     static bool attr = false;
-    auto kern = xyt_bf16_kernel<KP, OBJ, KL>;
+    auto kern = xyt_bf16_kernel<KP, OBJ, KL, TERMS>;
     if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
@@ -816,17 +828,21 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
 static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                       const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                       const unsigned short* Zlo, float* Apart, float* gram_part, const char* name, bool kl = false,
-                      int ng = 1) {
+                      int ng = 1, int terms = 4) {
+    static const bool force4 = getenv("NMFX_BF16_TERMS") && atoi(getenv("NMFX_BF16_TERMS")) == 4;
+    if (force4) terms = 4;
     ProfScope ps(E, name);
     if (obj) E->obj_count = (R / 128) * splits;
-#define NMFX_XYT(KP_, OBJ_, KL_) \
-    launch_xyt_t<KP_, OBJ_, KL_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
+#define NMFX_XYT2(KP_, OBJ_, KL_, T_) \
+    launch_xyt_t<KP_, OBJ_, KL_, T_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
+#define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))
     if (E->kp == 64) {
         if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
     }
     if (kl) return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
     return obj ? NMFX_XYT(128, true, false) : NMFX_XYT(128, false, false);
+#undef NMFX_XYT2
 #undef NMFX_XYT
 }
 
@@ -895,20 +911,20 @@ int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src) {   //
 
 // A_part[bf_wsplit][mp][kp] = V H^T (+ obj_part[(mp/128) * bf_wsplit] = residual objective of (W images `zbuf`, H))
 // kl: A_part = (V / (W H + 1e-9)) H^T and the KL objective (the W images `zbuf` are then always read)
-int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl) {
+int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl, int terms) {
     const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                       z ? E->Whi[zbuf] : nullptr, z ? E->Wlo[zbuf] : nullptr, E->A_part,
-                      E->kp == 64 ? E->HHt_part : nullptr, name, kl, E->gram_ng_w);
+                      E->kp == 64 ? E->HHt_part : nullptr, name, kl, E->gram_ng_w, terms);
 }
 
 // Bt_part[bt_split][np][kp] = V^T W (+ obj_part[(np/128) * bt_split] = residual objective, Z = H^T images)
 // kl: Bt_part = (V / (W H + 1e-9))^T W
-int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl) {
+int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl, int terms) {
     const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
                       z ? E->HThi : nullptr, z ? E->HTlo : nullptr, E->Bt_part,
-                      E->kp == 64 ? E->G_part : nullptr, name, kl, E->gram_ng_h);
+                      E->kp == 64 ? E->G_part : nullptr, name, kl, E->gram_ng_h, terms);
 }
 
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
@@ -970,11 +986,11 @@ static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) 
     const int64_t kk = (int64_t)E->kp * E->kp;
     { ProfScope ps(E, "sum_hht");
       if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc; }
-    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase"))) return rc;
+    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", false, 3))) return rc;
     if ((rc = nmfx_launch_w_update(E, E->W[cur], E->W[nxt], (float)lambda_w, E->bf_wsplit))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[nxt], nxt))) return rc;
     if ((rc = nmfx_launch_gram_tn(E, E->W[nxt], E->mp, E->G_part, E->gsplit))) return rc;
-    if ((rc = nmfx_bf16_vtw(E, false, "hphase"))) return rc;
+    if ((rc = nmfx_bf16_vtw(E, false, "hphase", false, 3))) return rc;
     return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
@@ -995,7 +1011,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     float* Wnew = E->W[nxt];
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
     if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w))) return rc;
+                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3))) return rc;
     { ProfScope ps(E, "w_update");
       hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
                          E->bf_wsplit, E->mp, Wold, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
@@ -1003,7 +1019,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
       NMFX_HIP(hipGetLastError()); }
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h))) return rc;
+                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h, 3))) return rc;
     if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
     return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, nmfx_bf16_g_slabs(E),
                                  (int64_t)(E->mp / 128) * E->bf_wsplit);

@@ -337,7 +337,7 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
       hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)E->kp), dim3(256), 0, E->stream, E->H, E->np, E->np,
                          E->HHt, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
-    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", true))) return rc;
+    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", true, 3))) return rc;
     { ProfScope ps(E, "w_update");
       const int64_t count = E->mp * E->kp;
       hipLaunchKernelGGL(kl_w_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, E->stream,
@@ -345,7 +345,7 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
                          &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     if ((rc = nmfx_bf16_images_w(E, Wnew, nxt))) return rc;
-    if ((rc = nmfx_bf16_vtw(E, false, "hphase", true))) return rc;
+    if ((rc = nmfx_bf16_vtw(E, false, "hphase", true, 3))) return rc;
     { ProfScope ps(E, "row_sums");        // d = W^T 1 into the first kp floats of G_part, slabs behind it
       const int nblk = (int)(E->mp / 128);
       float* part = E->B_part;                                   // scratch: the exact-f32 H phase's slabs are unused here
