@@ -557,119 +557,112 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* p) {       // 8 con
                       p[4] | ((unsigned)p[5] << 16), p[6] | ((unsigned)p[7] << 16));
 }
 
-__global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
+__global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
     const float* __restrict__ HHtpart, int hslabs, float lam, float* __restrict__ Wnew,
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
-    constexpr int KP = 64, RB = 64, LDW = 68, LDH = 80;          // padded LDS rows: conflict-free dword reads
+    constexpr int KP = 64, RB = 64, LDW = 68, LDH = 80, NT = 512;   // padded LDS rows: conflict-free dword reads
     __shared__ __attribute__((aligned(16))) float hs[KP * LDH];  // H H^T, later the product tile D [row][LDW]
     __shared__ __attribute__((aligned(16))) float ws[RB * LDW];
     __shared__ unsigned short th[KP][RB + 2], tl[KP][RB + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * RB;
-    // The kernel is a chain of dependent memory round trips, so everything that can be requested up
-    // front is: the stop flag, and the A slabs of this thread's 16 outputs (epilogue layout: row
-    // tid / 4, factors 16 (tid % 4) ..), whose latency then hides under the H H^T sum and the MFMAs.
+    // The kernel is a chain of dependent memory round trips, so it is built to have as few as possible: 512
+    // threads, and everything is requested before the first wait -- the stop flag, the W tile, the A slabs
+    // of this thread's 8 outputs (epilogue layout: row tid / 8, factors 8 (tid % 8) ..) four slabs at a time,
+    // and the H H^T by-product slabs 16 at a time (2 x 16 bytes per thread and slab).
     const int stop = *flag;
-    const int64_t eidx = (r0 + (tid >> 2)) * KP + 16 * (tid & 3);
-    float a[16] = {};
-    for (int p0 = 0; p0 < wsplit; p0 += 4) {
-        float4 t[4][4];
+    const int erow = tid >> 3, ej0 = 8 * (tid & 7);
+    const int64_t eidx = (r0 + erow) * KP + ej0;
+    float4 wt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wt[u] = reinterpret_cast<const float4*>(Wold + r0 * KP)[tid + NT * u];
+    float a[8] = {};
+    float v[2][4] = {};
+    for (int p0 = 0, h0 = 0; p0 < wsplit || h0 < hslabs; p0 += 4, h0 += 16) {
+        float4 ta[4][2], tv[16][2];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4)
-                t[pp][v4] = (p0 + pp < wsplit)
+            for (int v4 = 0; v4 < 2; ++v4)
+                ta[pp][v4] = (p0 + pp < wsplit)
                     ? *reinterpret_cast<const float4*>(Apart + (int64_t)(p0 + pp) * mp * KP + eidx + 4 * v4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                tv[pp][u] = (h0 + pp < hslabs)
+                    ? reinterpret_cast<const float4*>(HHtpart + (int64_t)(h0 + pp) * KP * KP)[tid + NT * u]
                     : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) {
-                a[4 * v4] += t[pp][v4].x; a[4 * v4 + 1] += t[pp][v4].y; a[4 * v4 + 2] += t[pp][v4].z; a[4 * v4 + 3] += t[pp][v4].w;
+            for (int v4 = 0; v4 < 2; ++v4) {
+                a[4 * v4] += ta[pp][v4].x; a[4 * v4 + 1] += ta[pp][v4].y; a[4 * v4 + 2] += ta[pp][v4].z; a[4 * v4 + 3] += ta[pp][v4].w;
+            }
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                v[u][0] += tv[pp][u].x; v[u][1] += tv[pp][u].y; v[u][2] += tv[pp][u].z; v[u][3] += tv[pp][u].w;
             }
     }
     if (stop) return;
-    {   // H H^T = sum of the W phase's by-product slabs (fixed order); the loads of four slabs
-        // (16 x 16 bytes per thread) are in flight together -- a short row shard has many slabs
-        float v[4][4] = {};
-        for (int p0 = 0; p0 < hslabs; p0 += 4) {
-            float4 t[4][4];
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    t[pp][u] = (p0 + pp < hslabs)
-                        ? reinterpret_cast<const float4*>(HHtpart + (int64_t)(p0 + pp) * KP * KP)[tid + 256 * u]
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u][0] += t[pp][u].x; v[u][1] += t[pp][u].y; v[u][2] += t[pp][u].z; v[u][3] += t[pp][u].w;
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u;
-            *reinterpret_cast<float4*>(hs + (i >> 4) * LDH + 4 * (i & 15)) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
-        }
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + NT * u;
+        *reinterpret_cast<float4*>(hs + (i >> 4) * LDH + 4 * (i & 15)) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        *reinterpret_cast<float4*>(ws + (i >> 4) * LDW + 4 * (i & 15)) = wt[u];
     }
-    for (int i = tid; i < RB * KP / 4; i += 256)
-        *reinterpret_cast<float4*>(ws + (i >> 4) * LDW + 4 * (i & 15)) = reinterpret_cast<const float4*>(Wold + r0 * KP)[i];
     __syncthreads();
-    // D[row][j] = sum_l W[row][l] HHt[l][j]; wave = 16 rows, 4 column tiles
-    f32x4 acc[4];
+    // D[row][j] = sum_l W[row][l] HHt[l][j]; wave = 16 rows (wave & 3), 2 column tiles (half wave >> 2)
+    const int rt = wave & 3, ch = wave >> 2;
+    f32x4 acc[2];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < 2; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int u = 0; u < KP / 4; ++u) {
-        const float a = ws[(16 * wave + x) * LDW + 4 * u + q];
+        const float av = ws[(16 * rt + x) * LDW + 4 * u + q];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = MFMA_F32(a, hs[(4 * u + q) * LDH + 16 * jt + x], acc[jt]);
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = MFMA_F32(av, hs[(4 * u + q) * LDH + 16 * (2 * ch + jt) + x], acc[jt]);
     }
     __syncthreads();                                   // everybody is done with H H^T
     // volatile: hipcc 7.2's DS store merging (ds_write2_b32) mis-encodes offset0 for these
     // strided stores (17/34/51 dwords instead of 68/136/204); volatile keeps them single.
     volatile float* dt = hs;                           // D tile [row][LDW]
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dt[(16 * wave + 4 * q + r) * LDW + 16 * jt + x] = acc[jt][r];
+        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDW + 16 * (2 * ch + jt) + x] = acc[jt][r];
     __syncthreads();
-    {   // epilogue, vectorised along the factor index: thread = (row, 16 consecutive j)
-        const int row = tid >> 2, j0 = 16 * (tid & 3);
-        const int64_t idx = (r0 + row) * KP + j0;
-        float wn[16];
-        unsigned ph[8], pl[8];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float w = ws[row * LDW + j0 + e];
-            wn[e] = w * a[e] / (dt[row * LDW + j0 + e] + lam * w + 1e-9f);
-        }
+    {   // epilogue, vectorised along the factor index: thread = (row, 8 consecutive j)
+        float wn[8];
+        unsigned ph[4], pl[4];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            split2(wn[2 * e], wn[2 * e + 1], ph[e], pl[e]);
-            th[j0 + 2 * e][row] = (unsigned short)(ph[e] & 0xffffu); th[j0 + 2 * e + 1][row] = (unsigned short)(ph[e] >> 16);
-            tl[j0 + 2 * e][row] = (unsigned short)(pl[e] & 0xffffu); tl[j0 + 2 * e + 1][row] = (unsigned short)(pl[e] >> 16);
+            const float w = ws[erow * LDW + ej0 + e];
+            wn[e] = w * a[e] / (dt[erow * LDW + ej0 + e] + lam * w + 1e-9f);
         }
 #pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4)
-            *reinterpret_cast<float4*>(Wnew + idx + 4 * v4) = make_float4(wn[4 * v4], wn[4 * v4 + 1], wn[4 * v4 + 2], wn[4 * v4 + 3]);
-        uint4* oh = reinterpret_cast<uint4*>(Whi + idx);
-        uint4* ol = reinterpret_cast<uint4*>(Wlo + idx);
-        oh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); oh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-        ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        for (int e = 0; e < 4; ++e) {
+            split2(wn[2 * e], wn[2 * e + 1], ph[e], pl[e]);
+            th[ej0 + 2 * e][erow] = (unsigned short)(ph[e] & 0xffffu); th[ej0 + 2 * e + 1][erow] = (unsigned short)(ph[e] >> 16);
+            tl[ej0 + 2 * e][erow] = (unsigned short)(pl[e] & 0xffffu); tl[ej0 + 2 * e + 1][erow] = (unsigned short)(pl[e] >> 16);
+        }
+#pragma unroll
+        for (int v4 = 0; v4 < 2; ++v4)
+            *reinterpret_cast<float4*>(Wnew + eidx + 4 * v4) = make_float4(wn[4 * v4], wn[4 * v4 + 1], wn[4 * v4 + 2], wn[4 * v4 + 3]);
+        *reinterpret_cast<uint4*>(Whi + eidx) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *reinterpret_cast<uint4*>(Wlo + eidx) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
     __syncthreads();
-    {   // transposed images: thread (f = tid/4, quarter = tid%4) stores 16 rows = 32 bytes per image
-        const int f = tid >> 2, qd = tid & 3;
-        uint4* oh = reinterpret_cast<uint4*>(WThi + (int64_t)f * mp + r0 + 16 * qd);
-        uint4* ol = reinterpret_cast<uint4*>(WTlo + (int64_t)f * mp + r0 + 16 * qd);
-        oh[0] = pack8(&th[f][16 * qd]); oh[1] = pack8(&th[f][16 * qd + 8]);
-        ol[0] = pack8(&tl[f][16 * qd]); ol[1] = pack8(&tl[f][16 * qd + 8]);
+    {   // transposed images: thread (f = tid / 8, eighth = tid % 8) stores 8 rows = 16 bytes per image
+        const int f = tid >> 3, oc = tid & 7;
+        *reinterpret_cast<uint4*>(WThi + (int64_t)f * mp + r0 + 8 * oc) = pack8(&th[f][8 * oc]);
+        *reinterpret_cast<uint4*>(WTlo + (int64_t)f * mp + r0 + 8 * oc) = pack8(&tl[f][8 * oc]);
     }
 }
 
@@ -681,55 +674,58 @@ __global__ __launch_bounds__(256) void mur_w_update_bf16_kernel(
 // objective partials directly (no `pack` launch); sharded runs read the all-reduced
 // exchange buffers.
 template <bool FROM_SLABS>
-__global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
+__global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const float* __restrict__ bsrc, int bsplit, const float* __restrict__ gsrc, int gsplit,
     const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
     int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo)
 {
-    constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80;
+    constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80, NT = 512;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDG]
     float* hs = gs + KP * LDG;                         // H tile [j][LDC]
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
-    __shared__ double shd[4];
+    __shared__ double shd[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t c0 = (int64_t)blockIdx.x * CB;
     const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
-    // A chain of dependent memory round trips: request everything that does not depend on a decision
-    // first -- the stop flag, the objective partials, the H tile, and the G / B^T slabs two at a time
-    // (16 x 16 bytes per thread in flight) -- and decide afterwards.
+    // The kernel is a chain of dependent memory round trips, so it is built to have as few as possible:
+    // 512 threads hold two 16-byte pieces of every 64 x 64 tile, and everything that does not depend on
+    // a decision -- the stop flag, the objective partials, the H tile, and ALL G / B^T slabs of up to 8
+    // slab indices (up to 32 x 16 bytes per thread) -- is requested before the first wait.  (With 256
+    // threads and two slabs per round the 16 Gram slabs of config 2 were 8 round trips: 17.5 us.)
     const int stop = st->flag;
     double sacc = 0.0;
-    if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += 256) sacc += osrc[i]; }
+    if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += NT) sacc += osrc[i]; }
     else sacc = osrc[0];
-    float4 ht[4];
+    float4 ht[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = tid + 256 * u;
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + NT * u;
         ht[u] = *reinterpret_cast<const float4*>(H + (int64_t)(i >> 4) * np + c0 + 4 * (i & 15));
     }
-    float g[4][4] = {}, b[4][4] = {};
+    float g[2][4] = {}, b[2][4] = {};
     {   // G and the B^T tile: slab sums (fixed order)
-        const int nslab = FROM_SLABS ? (gsplit > bsplit ? gsplit : bsplit) : 1;
-        for (int p0 = 0; p0 < nslab; p0 += 2) {
-            float4 tg[2][4], tb[2][4];
+        const int ng = FROM_SLABS ? gsplit : 1, nb = FROM_SLABS ? bsplit : 1;
+        const int nslab = ng > nb ? ng : nb;
+        for (int p0 = 0; p0 < nslab; p0 += 8) {
+            float4 tg[8][2], tb[8][2];
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const bool pg = p0 + pp < (FROM_SLABS ? gsplit : 1), pb = p0 + pp < (FROM_SLABS ? bsplit : 1);
+            for (int pp = 0; pp < 8; ++pp) {
+                const bool pg = p0 + pp < ng, pb = p0 + pp < nb;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = tid + 256 * u;
+                for (int u = 0; u < 2; ++u) {
+                    const int i = tid + NT * u;
                     tg[pp][u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)(p0 + pp) * kk)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                     tb[pp][u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)(p0 + pp) * bn + (c0 + (i >> 4)) * KP + 4 * (i & 15))
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+            for (int pp = 0; pp < 8; ++pp)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     g[u][0] += tg[pp][u].x; g[u][1] += tg[pp][u].y; g[u][2] += tg[pp][u].z; g[u][3] += tg[pp][u].w;
                     b[u][0] += tb[pp][u].x; b[u][1] += tb[pp][u].y; b[u][2] += tb[pp][u].z; b[u][3] += tb[pp][u].w;
                 }
@@ -742,7 +738,7 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
         if (lane == 0) shd[wave] = sacc;
         __syncthreads();
-        obj = ((shd[0] + shd[1]) + shd[2]) + shd[3];
+        obj = ((((((shd[0] + shd[1]) + shd[2]) + shd[3]) + shd[4]) + shd[5]) + shd[6]) + shd[7];
     } else {
         obj = sacc;
     }
@@ -750,49 +746,48 @@ __global__ __launch_bounds__(256) void mur_h_update_bf16_kernel(
                                            blockIdx.x == 0 && tid == 0);
     if (rule) return;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = tid + 256 * u;
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + NT * u;
         *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) = ht[u];
         *reinterpret_cast<float4*>(gs + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
         *reinterpret_cast<float4*>(bt + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
     }
     __syncthreads();
-    // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows, 4 column tiles
-    f32x4 acc[4];
+    // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows (wave & 3), 2 column tiles (half wave >> 2)
+    const int rt = wave & 3, ch = wave >> 2;
+    f32x4 acc[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int u = 0; u < KP / 4; ++u) {
-        const float a = gs[(16 * wave + x) * LDG + 4 * u + q];
+        const float a = gs[(16 * rt + x) * LDG + 4 * u + q];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA_F32(a, hs[(4 * u + q) * LDC + 16 * ct + x], acc[ct]);
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMA_F32(a, hs[(4 * u + q) * LDC + 16 * (2 * ch + ct) + x], acc[ct]);
     }
     __syncthreads();                                   // everybody is done with G
     volatile float* dt = gs;                           // see mur_w_update_bf16_kernel
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dt[(16 * wave + 4 * q + r) * LDG + 16 * ct + x] = acc[ct][r];
+        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDG + 16 * (2 * ch + ct) + x] = acc[ct][r];
     __syncthreads();
-    {   // epilogue, vectorised along the columns: thread = (factor row jr, 16 consecutive c)
-        const int jr = tid >> 2, cq = 16 * (tid & 3);
-        float hn[16];
-        unsigned ph[8], pl[8];
+    {   // epilogue, vectorised along the columns: thread = (factor row jr, 8 consecutive c)
+        const int jr = tid >> 3, cq = 8 * (tid & 7);
+        float hn[8];
+        unsigned ph[4], pl[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const float h = hs[jr * LDC + cq + e];
             hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDG + cq + e] + lam * h + 1e-9f);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
+        for (int e = 0; e < 4; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
         const int64_t idx = (int64_t)jr * np + c0 + cq;
 #pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4)
+        for (int v4 = 0; v4 < 2; ++v4)
             *reinterpret_cast<float4*>(H + idx + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
-        uint4* oh = reinterpret_cast<uint4*>(Hhi + idx);
-        uint4* ol = reinterpret_cast<uint4*>(Hlo + idx);
-        oh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); oh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-        ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        *reinterpret_cast<uint4*>(Hhi + idx) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *reinterpret_cast<uint4*>(Hlo + idx) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
 }
 
@@ -1013,7 +1008,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                          E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3))) return rc;
     { ProfScope ps(E, "w_update");
-      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), 0, E->stream, E->A_part,
+      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(512), 0, E->stream, E->A_part,
                          E->bf_wsplit, E->mp, Wold, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
                          E->WThi, E->WTlo, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
@@ -1029,7 +1024,7 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
                              int64_t j) {
     if (E->kp != 64) return mur_eu_phase_b_bf16_k128(E, lambda_h, min_iter, tol1, tol2, j);
     ProfScope ps(E, "h_update");
-    const dim3 grid((unsigned)(E->np / 64)), block(256);
+    const dim3 grid((unsigned)(E->np / 64)), block(512);
     const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float);
     static bool ok = false;
     if (!ok) {
