@@ -548,6 +548,10 @@ __global__ __launch_bounds__(256) void split_images_kernel(
 // phase).  Block = 64 rows; the 64 x 64 x 64 product W (H H^T) runs on the f32 MFMA.
 // ---------------------------------------------------------------------------
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef __attribute__((address_space(3))) float lds_f32;      // (a volatile access through a generic pointer would be a flat_ instruction)
+__device__ __forceinline__ volatile lds_f32* lds_volatile(void* p) {
+    return (volatile lds_f32*)(__attribute__((address_space(3))) void*)p;
+}
 __device__ __forceinline__ void add4(float* acc, const float* src) {   // acc[0..3] += one 16-byte load
     const float4 t = *reinterpret_cast<const float4*>(src);
     acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
@@ -557,123 +561,140 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* p) {       // 8 con
                       p[4] | ((unsigned)p[5] << 16), p[6] | ((unsigned)p[7] << 16));
 }
 
+template <int KP>
 __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
     const float* __restrict__ HHtpart, int hslabs, float lam, float* __restrict__ Wnew,
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
     unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
 {
-    constexpr int KP = 64, RB = 64, LDW = 68, LDH = 80, NT = 512;   // padded LDS rows: conflict-free dword reads
-    __shared__ __attribute__((aligned(16))) float hs[KP * LDH];  // H H^T, later the product tile D [row][LDW]
-    __shared__ __attribute__((aligned(16))) float ws[RB * LDW];
-    __shared__ unsigned short th[KP][RB + 2], tl[KP][RB + 2];
+    constexpr int RB = 64, LDW = KP + 4, LDH = KP + 16, NT = 512;   // padded LDS rows: conflict-free dword reads
+    constexpr int WV = KP / 32;                        // 16-byte pieces of the 64 x KP W tile per thread
+    constexpr int HV = KP * KP / 2048;                 // ... of one KP x KP Gram slab per thread
+    constexpr int HCH = 32 / HV;                       // Gram slabs requested together (32 pieces per thread)
+    constexpr int EP = KP / 8;                         // outputs per thread: row tid / 8, factors EP (tid % 8) ..
+    constexpr int CT = KP / 32;                        // column tiles of the product per wave
+    extern __shared__ __attribute__((aligned(16))) float wdyn[];
+    float* hs = wdyn;                                  // H H^T [KP][LDH], later the product tile D [row][LDW]
+    float* ws = hs + KP * LDH;                         // W tile [RB][LDW]
+    unsigned short* th = reinterpret_cast<unsigned short*>(ws + RB * LDW);   // [KP][RB + 2] transposed hi image
+    unsigned short* tl = th + KP * (RB + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * RB;
     // The kernel is a chain of dependent memory round trips, so it is built to have as few as possible: 512
     // threads, and everything is requested before the first wait -- the stop flag, the W tile, the A slabs
-    // of this thread's 8 outputs (epilogue layout: row tid / 8, factors 8 (tid % 8) ..) four slabs at a time,
-    // and the H H^T by-product slabs 16 at a time (2 x 16 bytes per thread and slab).
+    // of this thread's outputs four slabs at a time, and the H H^T slabs HCH at a time.
     const int stop = *flag;
-    const int erow = tid >> 3, ej0 = 8 * (tid & 7);
+    const int erow = tid >> 3, ej0 = EP * (tid & 7);
     const int64_t eidx = (r0 + erow) * KP + ej0;
-    float4 wt[2];
+    float4 wt[WV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) wt[u] = reinterpret_cast<const float4*>(Wold + r0 * KP)[tid + NT * u];
-    float a[8] = {};
-    float v[2][4] = {};
-    for (int p0 = 0, h0 = 0; p0 < wsplit || h0 < hslabs; p0 += 4, h0 += 16) {
-        float4 ta[4][2], tv[16][2];
+    for (int u = 0; u < WV; ++u) wt[u] = reinterpret_cast<const float4*>(Wold + r0 * KP)[tid + NT * u];
+    float a[EP] = {};
+    float v[HV][4] = {};
+    for (int p0 = 0, h0 = 0; p0 < wsplit || h0 < hslabs; p0 += 4, h0 += HCH) {
+        float4 ta[4][EP / 4], tv[HCH][HV];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int v4 = 0; v4 < 2; ++v4)
+            for (int v4 = 0; v4 < EP / 4; ++v4)
                 ta[pp][v4] = (p0 + pp < wsplit)
                     ? *reinterpret_cast<const float4*>(Apart + (int64_t)(p0 + pp) * mp * KP + eidx + 4 * v4)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp)
+        for (int pp = 0; pp < HCH; ++pp)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < HV; ++u)
                 tv[pp][u] = (h0 + pp < hslabs)
                     ? reinterpret_cast<const float4*>(HHtpart + (int64_t)(h0 + pp) * KP * KP)[tid + NT * u]
                     : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int v4 = 0; v4 < 2; ++v4) {
+            for (int v4 = 0; v4 < EP / 4; ++v4) {
                 a[4 * v4] += ta[pp][v4].x; a[4 * v4 + 1] += ta[pp][v4].y; a[4 * v4 + 2] += ta[pp][v4].z; a[4 * v4 + 3] += ta[pp][v4].w;
             }
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp)
+        for (int pp = 0; pp < HCH; ++pp)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < HV; ++u) {
                 v[u][0] += tv[pp][u].x; v[u][1] += tv[pp][u].y; v[u][2] += tv[pp][u].z; v[u][3] += tv[pp][u].w;
             }
     }
     if (stop) return;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < HV; ++u) {
         const int i = tid + NT * u;
-        *reinterpret_cast<float4*>(hs + (i >> 4) * LDH + 4 * (i & 15)) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
-        *reinterpret_cast<float4*>(ws + (i >> 4) * LDW + 4 * (i & 15)) = wt[u];
+        *reinterpret_cast<float4*>(hs + (i / (KP / 4)) * LDH + 4 * (i % (KP / 4))) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < WV; ++u) {
+        const int i = tid + NT * u;
+        *reinterpret_cast<float4*>(ws + (i / (KP / 4)) * LDW + 4 * (i % (KP / 4))) = wt[u];
     }
     __syncthreads();
-    // D[row][j] = sum_l W[row][l] HHt[l][j]; wave = 16 rows (wave & 3), 2 column tiles (half wave >> 2)
+    // D[row][j] = sum_l W[row][l] HHt[l][j]; wave = 16 rows (wave & 3), CT column tiles (half wave >> 2)
     const int rt = wave & 3, ch = wave >> 2;
-    f32x4 acc[2];
+    f32x4 acc[CT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < CT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int u = 0; u < KP / 4; ++u) {
         const float av = ws[(16 * rt + x) * LDW + 4 * u + q];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = MFMA_F32(av, hs[(4 * u + q) * LDH + 16 * (2 * ch + jt) + x], acc[jt]);
+        for (int jt = 0; jt < CT; ++jt) acc[jt] = MFMA_F32(av, hs[(4 * u + q) * LDH + 16 * (CT * ch + jt) + x], acc[jt]);
     }
     __syncthreads();                                   // everybody is done with H H^T
     // volatile: hipcc 7.2's DS store merging (ds_write2_b32) mis-encodes offset0 for these
     // strided stores (17/34/51 dwords instead of 68/136/204); volatile keeps them single.
-    volatile float* dt = hs;                           // D tile [row][LDW]
+    volatile lds_f32* dt = lds_volatile(hs);           // D tile [row][LDW]
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < CT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDW + 16 * (2 * ch + jt) + x] = acc[jt][r];
+        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDW + 16 * (CT * ch + jt) + x] = acc[jt][r];
     __syncthreads();
-    {   // epilogue, vectorised along the factor index: thread = (row, 8 consecutive j)
-        float wn[8];
-        unsigned ph[4], pl[4];
+    {   // epilogue, vectorised along the factor index: thread = (row, EP consecutive j)
+        float wn[EP];
+        unsigned ph[EP / 2], pl[EP / 2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < EP; ++e) {
             const float w = ws[erow * LDW + ej0 + e];
             wn[e] = w * a[e] / (dt[erow * LDW + ej0 + e] + lam * w + 1e-9f);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EP / 2; ++e) {
             split2(wn[2 * e], wn[2 * e + 1], ph[e], pl[e]);
-            th[ej0 + 2 * e][erow] = (unsigned short)(ph[e] & 0xffffu); th[ej0 + 2 * e + 1][erow] = (unsigned short)(ph[e] >> 16);
-            tl[ej0 + 2 * e][erow] = (unsigned short)(pl[e] & 0xffffu); tl[ej0 + 2 * e + 1][erow] = (unsigned short)(pl[e] >> 16);
+            th[(ej0 + 2 * e) * (RB + 2) + erow] = (unsigned short)(ph[e] & 0xffffu); th[(ej0 + 2 * e + 1) * (RB + 2) + erow] = (unsigned short)(ph[e] >> 16);
+            tl[(ej0 + 2 * e) * (RB + 2) + erow] = (unsigned short)(pl[e] & 0xffffu); tl[(ej0 + 2 * e + 1) * (RB + 2) + erow] = (unsigned short)(pl[e] >> 16);
         }
 #pragma unroll
-        for (int v4 = 0; v4 < 2; ++v4)
+        for (int v4 = 0; v4 < EP / 4; ++v4)
             *reinterpret_cast<float4*>(Wnew + eidx + 4 * v4) = make_float4(wn[4 * v4], wn[4 * v4 + 1], wn[4 * v4 + 2], wn[4 * v4 + 3]);
-        *reinterpret_cast<uint4*>(Whi + eidx) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        *reinterpret_cast<uint4*>(Wlo + eidx) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+#pragma unroll
+        for (int v8 = 0; v8 < EP / 8; ++v8) {
+            *reinterpret_cast<uint4*>(Whi + eidx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
+            *reinterpret_cast<uint4*>(Wlo + eidx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
+        }
     }
     __syncthreads();
-    {   // transposed images: thread (f = tid / 8, eighth = tid % 8) stores 8 rows = 16 bytes per image
-        const int f = tid >> 3, oc = tid & 7;
-        *reinterpret_cast<uint4*>(WThi + (int64_t)f * mp + r0 + 8 * oc) = pack8(&th[f][8 * oc]);
-        *reinterpret_cast<uint4*>(WTlo + (int64_t)f * mp + r0 + 8 * oc) = pack8(&tl[f][8 * oc]);
+    {   // transposed images: thread (f = tid / 8 (+ 64), eighth = tid % 8) stores 8 rows = 16 bytes per image
+        const int oc = tid & 7;
+#pragma unroll
+        for (int f = tid >> 3; f < KP; f += 64) {
+            *reinterpret_cast<uint4*>(WThi + (int64_t)f * mp + r0 + 8 * oc) = pack8(th + f * (RB + 2) + 8 * oc);
+            *reinterpret_cast<uint4*>(WTlo + (int64_t)f * mp + r0 + 8 * oc) = pack8(tl + f * (RB + 2) + 8 * oc);
+        }
     }
 }
 
 // H epilogue (nmf/mur.py:45): H_new = H * B / (G H + lam H + 1e-9) from B^T = V^T W (stored
-// [np][64]) + objective bookkeeping + the bf16 images of the new H ([64][np]; the W phase takes
+// [np][KP]) + objective bookkeeping + the bf16 images of the new H ([KP][np]; the W phase takes
 // its transposed fragments from the same image).  Block = 64 columns; the product G H runs on the f32
 // MFMA and every global access is a 16-byte vector (tiles are turned through LDS).
 // FROM_SLABS: single-GPU runs read the split slabs of the H phase, the Gram slabs and the
 // objective partials directly (no `pack` launch); sharded runs read the all-reduced
 // exchange buffers.
-template <bool FROM_SLABS>
+template <int KP, bool FROM_SLABS>
 __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const float* __restrict__ bsrc, int bsplit, const float* __restrict__ gsrc, int gsplit,
     const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
@@ -681,9 +702,15 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo)
 {
-    constexpr int KP = 64, CB = 64, LDG = 68, LDC = 80, NT = 512;
+    constexpr int CB = 64, LDG = KP + 4, LDC = 80, LDD = 68, NT = 512;
+    constexpr int TV = KP / 32;                        // 16-byte pieces per thread of the KP x 64 H tile / the 64 x KP B^T tile
+    constexpr int GV = KP * KP / 2048;                 // ... of one KP x KP Gram slab
+    constexpr int SCH = 16 / GV;                       // slab indices requested together (<= 16 + 2 SCH pieces per thread)
+    constexpr int RTN = KP / 16;                       // row tiles of the product; wave -> (row tile, group of column tiles)
+    constexpr int CT = 4 * RTN / 8;                    // column tiles per wave
+    constexpr int EP = KP / 8, TPR = CB / EP;          // outputs per thread, threads per factor row
     extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDG]
+    float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDD]
     float* hs = gs + KP * LDG;                         // H tile [j][LDC]
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
     __shared__ double shd[8];
@@ -691,44 +718,50 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const int64_t c0 = (int64_t)blockIdx.x * CB;
     const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
     // The kernel is a chain of dependent memory round trips, so it is built to have as few as possible:
-    // 512 threads hold two 16-byte pieces of every 64 x 64 tile, and everything that does not depend on
-    // a decision -- the stop flag, the objective partials, the H tile, and ALL G / B^T slabs of up to 8
-    // slab indices (up to 32 x 16 bytes per thread) -- is requested before the first wait.  (With 256
-    // threads and two slabs per round the 16 Gram slabs of config 2 were 8 round trips: 17.5 us.)
+    // 512 threads, and everything that does not depend on a decision -- the stop flag, the objective
+    // partials, the H tile, and the G / B^T slabs of SCH slab indices at a time -- is requested before the
+    // first wait.  (With 256 threads and two slabs per round the 16 Gram slabs of config 2 were 8 round
+    // trips: 17.5 us; now 13.)
     const int stop = st->flag;
     double sacc = 0.0;
     if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += NT) sacc += osrc[i]; }
     else sacc = osrc[0];
-    float4 ht[2];
+    float4 ht[TV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TV; ++u) {
         const int i = tid + NT * u;
         ht[u] = *reinterpret_cast<const float4*>(H + (int64_t)(i >> 4) * np + c0 + 4 * (i & 15));
     }
-    float g[2][4] = {}, b[2][4] = {};
+    float g[GV][4] = {}, b[TV][4] = {};
     {   // G and the B^T tile: slab sums (fixed order)
         const int ng = FROM_SLABS ? gsplit : 1, nb = FROM_SLABS ? bsplit : 1;
         const int nslab = ng > nb ? ng : nb;
-        for (int p0 = 0; p0 < nslab; p0 += 8) {
-            float4 tg[8][2], tb[8][2];
+        for (int p0 = 0; p0 < nslab; p0 += SCH) {
+            float4 tg[SCH][GV], tb[SCH][TV];
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp) {
+            for (int pp = 0; pp < SCH; ++pp) {
                 const bool pg = p0 + pp < ng, pb = p0 + pp < nb;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < GV; ++u)
+                    tg[pp][u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)(p0 + pp) * kk)[tid + NT * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < TV; ++u) {
                     const int i = tid + NT * u;
-                    tg[pp][u] = pg ? reinterpret_cast<const float4*>(gsrc + (int64_t)(p0 + pp) * kk)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    tb[pp][u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)(p0 + pp) * bn + (c0 + (i >> 4)) * KP + 4 * (i & 15))
+                    tb[pp][u] = pb ? *reinterpret_cast<const float4*>(bsrc + (int64_t)(p0 + pp) * bn + (c0 + i / (KP / 4)) * KP + 4 * (i % (KP / 4)))
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp)
+            for (int pp = 0; pp < SCH; ++pp) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < GV; ++u) {
                     g[u][0] += tg[pp][u].x; g[u][1] += tg[pp][u].y; g[u][2] += tg[pp][u].z; g[u][3] += tg[pp][u].w;
+                }
+#pragma unroll
+                for (int u = 0; u < TV; ++u) {
                     b[u][0] += tb[pp][u].x; b[u][1] += tb[pp][u].y; b[u][2] += tb[pp][u].z; b[u][3] += tb[pp][u].w;
                 }
+            }
         }
     }
     if (stop) return;
@@ -746,48 +779,55 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
                                            blockIdx.x == 0 && tid == 0);
     if (rule) return;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TV; ++u) {
         const int i = tid + NT * u;
         *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) = ht[u];
-        *reinterpret_cast<float4*>(gs + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
-        *reinterpret_cast<float4*>(bt + (i >> 4) * LDG + 4 * (i & 15)) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
+        *reinterpret_cast<float4*>(bt + (i / (KP / 4)) * LDG + 4 * (i % (KP / 4))) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < GV; ++u) {
+        const int i = tid + NT * u;
+        *reinterpret_cast<float4*>(gs + (i / (KP / 4)) * LDG + 4 * (i % (KP / 4))) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
     }
     __syncthreads();
-    // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows (wave & 3), 2 column tiles (half wave >> 2)
-    const int rt = wave & 3, ch = wave >> 2;
-    f32x4 acc[2];
+    // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows (tile wave % RTN), CT column tiles
+    const int rt = wave % RTN, cb = (wave / RTN) * CT;
+    f32x4 acc[CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int u = 0; u < KP / 4; ++u) {
         const float a = gs[(16 * rt + x) * LDG + 4 * u + q];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMA_F32(a, hs[(4 * u + q) * LDC + 16 * (2 * ch + ct) + x], acc[ct]);
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA_F32(a, hs[(4 * u + q) * LDC + 16 * (cb + ct) + x], acc[ct]);
     }
     __syncthreads();                                   // everybody is done with G
-    volatile float* dt = gs;                           // see mur_w_update_bf16_kernel
+    volatile lds_f32* dt = lds_volatile(gs);           // D tile [j][LDD]; volatile: see mur_w_update_bf16_kernel
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDG + 16 * (2 * ch + ct) + x] = acc[ct][r];
+        for (int r = 0; r < 4; ++r) dt[(16 * rt + 4 * q + r) * LDD + 16 * (cb + ct) + x] = acc[ct][r];
     __syncthreads();
-    {   // epilogue, vectorised along the columns: thread = (factor row jr, 8 consecutive c)
-        const int jr = tid >> 3, cq = 8 * (tid & 7);
-        float hn[8];
-        unsigned ph[4], pl[4];
+    {   // epilogue, vectorised along the columns: thread = (factor row jr, EP consecutive c)
+        const int jr = tid / TPR, cq = EP * (tid % TPR);
+        float hn[EP];
+        unsigned ph[EP / 2], pl[EP / 2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < EP; ++e) {
             const float h = hs[jr * LDC + cq + e];
-            hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDG + cq + e] + lam * h + 1e-9f);
+            hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDD + cq + e] + lam * h + 1e-9f);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
+        for (int e = 0; e < EP / 2; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
         const int64_t idx = (int64_t)jr * np + c0 + cq;
 #pragma unroll
-        for (int v4 = 0; v4 < 2; ++v4)
+        for (int v4 = 0; v4 < EP / 4; ++v4)
             *reinterpret_cast<float4*>(H + idx + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
-        *reinterpret_cast<uint4*>(Hhi + idx) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        *reinterpret_cast<uint4*>(Hlo + idx) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+#pragma unroll
+        for (int v8 = 0; v8 < EP / 8; ++v8) {
+            *reinterpret_cast<uint4*>(Hhi + idx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
+            *reinterpret_cast<uint4*>(Hlo + idx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
+        }
     }
 }
 
@@ -973,7 +1013,49 @@ int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nob
     return NMFX_OK;
 }
 
-// MUR-Euclidean, k = 128: split-bf16 products, the exact-f32 path's epilogues and Gram kernels
+template <int KP>
+static int launch_w_update_bf16(nmfx_engine* E, const float* Wold, float* Wnew, int nxt, const float* hht, int hslabs, float lam) {
+    ProfScope ps(E, "w_update");
+    constexpr size_t shm = (size_t)(KP * (KP + 16) + 64 * (KP + 4)) * sizeof(float) + (size_t)2 * KP * 66 * sizeof(unsigned short);
+    static bool ok = false;
+    if (!ok) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_w_update_bf16_kernel<KP>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok = true; }
+    hipLaunchKernelGGL(mur_w_update_bf16_kernel<KP>, dim3((unsigned)(E->mp / 64)), dim3(512), shm, E->stream, E->A_part,
+                       E->bf_wsplit, E->mp, Wold, hht, hslabs, lam, Wnew, E->Whi[nxt], E->Wlo[nxt], E->WThi, E->WTlo,
+                       &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// from_slabs: B^T, G and the objective partials straight from the H phase's slabs (single GPU, kp = 64);
+// otherwise from the (all-reduced) exchange buffers: xf32 = [B^T sums [np][kp] | G], xf64[0] = objective
+template <int KP>
+static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int64_t j, int64_t min_iter, double tol1, double tol2) {
+    ProfScope ps(E, "h_update");
+    const dim3 grid((unsigned)(E->np / 64)), block(512);
+    constexpr size_t shm = (size_t)(KP * (KP + 4) + KP * 80 + 64 * (KP + 4)) * sizeof(float);
+    static bool ok = false;
+    if (!ok) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        ok = true;
+    }
+    if (from_slabs)
+        hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
+                           E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
+                           lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo);
+    else
+        hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, false>), grid, block, shm, E->stream, E->xf32, 1,
+                           E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
+                           lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// MUR-Euclidean, k = 128: split-bf16 products, the same epilogue kernels as k = 64 (they also write the
+// images of the new factors), Gram matrices from the Gram kernels (no by-product at this width)
 // between them, and one image pass per factor update.
 static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) {
     int rc;
@@ -982,18 +1064,16 @@ static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) 
     { ProfScope ps(E, "sum_hht");
       if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc; }
     if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", false, 3))) return rc;
-    if ((rc = nmfx_launch_w_update(E, E->W[cur], E->W[nxt], (float)lambda_w, E->bf_wsplit))) return rc;
-    if ((rc = nmfx_bf16_images_w(E, E->W[nxt], nxt))) return rc;
+    if ((rc = launch_w_update_bf16<128>(E, E->W[cur], E->W[nxt], nxt, E->HHt, 1, (float)lambda_w))) return rc;
     if ((rc = nmfx_launch_gram_tn(E, E->W[nxt], E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_bf16_vtw(E, false, "hphase", false, 3))) return rc;
-    return nmfx_bf16_pack_t(E, E->G_part, E->gsplit, (int64_t)(E->mp / 128) * E->bf_wsplit);
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->gsplit, (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
 static int mur_eu_phase_b_bf16_k128(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
-    if ((rc = nmfx_launch_h_update(E, (float)lambda_h, j, min_iter, tol1, tol2))) return rc;
-    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
-    return nmfx_bf16_images_h(E, false);
+    if ((rc = launch_h_update_bf16<128>(E, false, (float)lambda_h, j, min_iter, tol1, tol2))) return rc;
+    return nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit);
 }
 
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
@@ -1007,11 +1087,7 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
     if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
                          E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3))) return rc;
-    { ProfScope ps(E, "w_update");
-      hipLaunchKernelGGL(mur_w_update_bf16_kernel, dim3((unsigned)(E->mp / 64)), dim3(512), 0, E->stream, E->A_part,
-                         E->bf_wsplit, E->mp, Wold, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w, Wnew, E->Whi[nxt], E->Wlo[nxt],
-                         E->WThi, E->WTlo, &E->state->flag);
-      NMFX_HIP(hipGetLastError()); }
+    if ((rc = launch_w_update_bf16<64>(E, Wold, Wnew, nxt, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w))) return rc;
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
     if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
                          nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h, 3))) return rc;
@@ -1023,27 +1099,5 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,
                              int64_t j) {
     if (E->kp != 64) return mur_eu_phase_b_bf16_k128(E, lambda_h, min_iter, tol1, tol2, j);
-    ProfScope ps(E, "h_update");
-    const dim3 grid((unsigned)(E->np / 64)), block(512);
-    const size_t shm = (size_t)(64 * 68 + 64 * 80 + 64 * 68) * sizeof(float);
-    static bool ok = false;
-    if (!ok) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        ok = true;
-    }
-    if (E->fused_pack)
-        hipLaunchKernelGGL((mur_h_update_bf16_kernel<true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
-                           E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
-                           (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
-                           E->Hhi, E->Hlo);
-    else
-        hipLaunchKernelGGL((mur_h_update_bf16_kernel<false>), grid, block, shm, E->stream, E->xf32, 1,
-                           E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
-                           (float)lambda_h, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist,
-                           E->Hhi, E->Hlo);
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
+    return launch_h_update_bf16<64>(E, E->fused_pack, (float)lambda_h, j, min_iter, tol1, tol2);
 }
