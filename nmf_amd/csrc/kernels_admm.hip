@@ -40,7 +40,7 @@ static int admm_objective(nmfx_engine* E) {
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
     if ((rc = nmfx_bf16_images_h(E, false))) return rc;
-    return nmfx_bf16_vht(E, true, 1, "objective");
+    return nmfx_bf16_objective(E, 1, "objective");
 }
 
 static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,

@@ -444,7 +444,7 @@ static int anls_objective(nmfx_engine* E) {
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
     if ((rc = nmfx_bf16_images_h(E, false))) return rc;
-    return nmfx_bf16_vht(E, true, 1, "objective");
+    return nmfx_bf16_objective(E, 1, "objective");
 }
 
 static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, double tol1, double tol2, int64_t j) {

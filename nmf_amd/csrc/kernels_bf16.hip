@@ -136,7 +136,9 @@ extern "C" int nmfx_debug_block_times(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmfx_dbg_times), sizeof(nmfx_dbg_times)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int KP, bool WITH_OBJ, bool KL, int TERMS>
+// WITH_A = false (with WITH_OBJ, Euclidean): only the residual objective -- no A-product, no Gram by-product,
+// nothing written but objpart (the objective passes of ADMM and ANLS).
+template <int KP, bool WITH_OBJ, bool KL, int TERMS, bool WITH_A = true>
 __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -154,10 +156,11 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     constexpr int YBUF = 2 * YT;                      // Yhi tile, Ylo tile
     constexpr int VOFF = 2 * YBUF;                    // start of the V rings
     constexpr int VRING = (KP == 64) ? 4 : 3;         // V ring depth (LDS: 2*YBUF + 8*VRING*4 KiB = 160 KiB)
-    constexpr bool WITH_GRAM = (KP == 64) && !KL;
+    static_assert(WITH_A || (WITH_OBJ && !KL), "without the A-product the launch must at least compute the objective");
+    constexpr bool WITH_GRAM = (KP == 64) && !KL && WITH_A;
     constexpr bool WITH_D = WITH_OBJ || KL;           // the product Z Y is formed
     constexpr int YPW = 2 * (KP / 8) / 4;             // Y pieces (8 rows x 128 B) per loader wave and group
-    constexpr int NA = 2 * (NJT / 4);                 // pipeline stages of the A-product: (k-step, half of the tiles)
+    constexpr int NA = WITH_A ? 2 * (NJT / 4) : 0;    // pipeline stages of the A-product: (k-step, half of the tiles)
     constexpr int ND = WITH_D ? KP / 32 : 0;          // stages of the product Z Y: k-steps over the factors
     constexpr int NS = NA + ND;                       // order: A.. then D.. (Euclidean), D.. then A.. (KL)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 }
             }
         };
-        if (!KL) {
+        if (!KL && WITH_A) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         issue(0, 0);
         NMFX_FENCE();
         Frag8 vh[2], vl[2];
-        if (!KL) {
+        if (!KL && WITH_A) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
         }
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
     }
 
-    {
+    if (WITH_A) {
         float* out = Apart + ((int64_t)sp * R + r0) * KP;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt)
@@ -844,14 +847,14 @@ static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
 
 bool nmfx_bf16_supported(const nmfx_engine* E) { return (E->kp == 64 || E->kp == 128) && E->mp % 128 == 0 && E->np % 128 == 0; }
 
-template <int KP, bool OBJ, bool KL, int TERMS>
+template <int KP, bool OBJ, bool KL, int TERMS, bool WITH_A = true>
 static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx, int64_t R, int ngroups, int splits,
                         const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                         const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
     static bool attr = false;
-    auto kern = xyt_bf16_kernel<KP, OBJ, KL, TERMS>;
+    auto kern = xyt_bf16_kernel<KP, OBJ, KL, TERMS, WITH_A>;
     if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
@@ -871,6 +874,12 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
 #define NMFX_XYT2(KP_, OBJ_, KL_, T_) \
     launch_xyt_t<KP_, OBJ_, KL_, T_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
 #define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))
+    if (!Apart) {                                      // objective only (Euclidean, four terms)
+        if (!obj || kl) { E->err = "xyt: a launch without the A-product must compute the Euclidean objective"; return NMFX_E_ARG; }
+        if (E->kp == 64)
+            return launch_xyt_t<64, true, false, 4, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+        return launch_xyt_t<128, true, false, 4, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+    }
     if (E->kp == 64) {
         if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
@@ -955,6 +964,12 @@ int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl,
 
 // Bt_part[bt_split][np][kp] = V^T W (+ obj_part[(np/128) * bt_split] = residual objective, Z = H^T images)
 // kl: Bt_part = (V / (W H + 1e-9))^T W
+// obj_part[(mp/128) * bf_wsplit] = residual objective of (W images `zbuf`, H images): one pass over V, no product output
+int nmfx_bf16_objective(nmfx_engine* E, int zbuf, const char* name) {
+    return launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                      E->Whi[zbuf], E->Wlo[zbuf], nullptr, nullptr, name);
+}
+
 int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl, int terms) {
     const bool z = obj || kl;
     return launch_xyt(E, obj, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,

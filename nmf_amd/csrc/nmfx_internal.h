@@ -134,6 +134,7 @@ int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
 int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl = false, int terms = 4);   // terms: kernels_bf16.hip, top
 int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl = false, int terms = 4);
+int nmfx_bf16_objective(nmfx_engine* E, int zbuf, const char* name);
 int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_kl_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nobj);
