@@ -29,7 +29,9 @@
 // iteration is self-correcting.  The solvers that put the products into normal equations (ANLS, ADMM,
 // AO-ADMM) keep 4: there the same perturbation is amplified by the conditioning of the Gram matrix (ANLS
 // test matrix 300 x 220, k = 40: objective history 8e-4 off the oracle with 3 terms, < 5e-4 with 4).
-// NMFX_BF16_TERMS=4 in the environment forces 4 everywhere.
+// The residual product Z Y of the Euclidean objective always takes 3: the objective is only recorded and
+// compared, nothing is computed from it (3 vs 4 terms moves it by ~1e-8 relative).
+// NMFX_BF16_TERMS=4 in the environment forces 4 for every product that is fed back.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union Frag8 { uint4 u; bf16x8 v; };
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
                 for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zh[WITH_D ? s : 0], d[e]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fh[set][e], zl[WITH_D ? s : 0], d[e]);
-                if (TERMS >= 4) {
-#pragma unroll
+                if (TERMS >= 4 && KL) {               // (the Euclidean residual is only summed into the objective, which
+#pragma unroll                                        //  nothing is computed from: three terms whatever TERMS is)
                     for (int e = 0; e < 4; ++e) d[e] = MFMA_BF16(fl[set][e], zl[WITH_D ? s : 0], d[e]);
                 }
             }
@@ -874,11 +876,11 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
 #define NMFX_XYT2(KP_, OBJ_, KL_, T_) \
     launch_xyt_t<KP_, OBJ_, KL_, T_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
 #define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))
-    if (!Apart) {                                      // objective only (Euclidean, four terms)
+    if (!Apart) {                                      // objective only (Euclidean; three terms: nothing is fed back from it)
         if (!obj || kl) { E->err = "xyt: a launch without the A-product must compute the Euclidean objective"; return NMFX_E_ARG; }
         if (E->kp == 64)
-            return launch_xyt_t<64, true, false, 4, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
-        return launch_xyt_t<128, true, false, 4, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+            return launch_xyt_t<64, true, false, 3, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+        return launch_xyt_t<128, true, false, 3, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
     }
     if (E->kp == 64) {
         if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
