@@ -40,12 +40,16 @@ def test_aoadmm_error_behaviour():
         ao_admm(v, 3, max_iter=2, nndsvd_init=(False, "zero"))
     with pytest.raises(TypeError):
         ao_admm(v, 3, max_iter=2, reg_h=(0, "bogus"), nndsvd_init=(False, "zero"))
-    with pytest.raises(np.linalg.LinAlgError):   # W = 0 -> Gram + rho I = 0 -> not PD (ao_admm.py:55)
-        import nmf_amd.utils as U
+    import nmf_amd.utils as U
+    # W = 0 -> Gram + rho I = 0 -> not PD (ao_admm.py:55): the scalar prepare kernel (k = 3) and the blocked
+    # f64-MFMA one (k padded to 64 and to 128) must both report it
+    for k, m in ((3, 40), (40, 96), (100, 160)):
+        vv = np.random.RandomState(k).rand(m, 120)
         orig = U.initial_factors
-        U.initial_factors = lambda x, k, init, **kw: (np.zeros((40, 3)), np.abs(np.random.randn(3, 30)))
+        U.initial_factors = lambda x, kk, init, **kw: (np.zeros((x.shape[0], kk)), np.abs(np.random.randn(kk, x.shape[1])))
         try:
-            ao_admm(v, 3, max_iter=3, reg_h=(0, "nn"), nndsvd_init=(False, "zero"))
+            with pytest.raises(np.linalg.LinAlgError):
+                ao_admm(vv, k, max_iter=3, reg_h=(0, "nn"), nndsvd_init=(False, "zero"))
         finally:
             U.initial_factors = orig
 
