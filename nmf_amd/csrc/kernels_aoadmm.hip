@@ -740,7 +740,8 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
 // turned from the accumulator layout to the A-operand layout through a wave-private LDS tile.
 template <int KP>
 __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
-    const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
+    const float* __restrict__ Asum, int asplit, int64_t astride,     // right-hand side = sum of asplit slabs (slab order)
+    float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
     DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot)
 {
@@ -777,7 +778,10 @@ __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
-            wx[it][g] = srcX[idx]; dx[it][g] = srcU[idx]; ax0[it][g] = Asum[idx];
+            wx[it][g] = srcX[idx]; dx[it][g] = srcU[idx];
+            float av = Asum[idx];
+            for (int p = 1; p < asplit; ++p) av += Asum[(int64_t)p * astride + idx];
+            ax0[it][g] = av;
             if (!repair) { Xb[idx] = wx[it][g]; Ub[idx] = dx[it][g]; }
         }
     __syncthreads();                                   // M^-1 is in place
@@ -1063,7 +1067,10 @@ static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int 
     auto kern = ao_fused_rows_kernel<KP>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, E->auxW, W, E->dualW, E->bkX, E->bkU,
+    // ao_a_slabs > 0: the W-side product's slabs are added here instead of by a sum_partials launch
+    const bool slabs = E->ao_a_slabs > 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, slabs ? E->A_part : E->auxW,
+                       slabs ? E->ao_a_slabs : 1, (int64_t)E->mp * E->kp, W, E->dualW, E->bkX, E->bkU,
                        E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -1104,9 +1111,10 @@ static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, i
     return nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2);
 }
 
-static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2) {
+static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2, bool sum_a = true) {
     int rc;
     const int64_t kk = (int64_t)E->kp * E->kp;
+    E->ao_a_slabs = 0;
     if (ao_bf16(E)) {
         if ((rc = nmfx_bf16_images_h(E, false))) return rc;                    // the H the sub-problem above produced
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;      // kp = 64: H H^T slabs as a by-product
@@ -1114,7 +1122,8 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
         { ProfScope ps(E, "sums");
           if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
-          if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->auxW))) return rc; }
+          if (sum_a) { if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->auxW))) return rc; }
+          else E->ao_a_slabs = E->bf_wsplit; }          // the fused W-side kernel adds the slabs itself
         return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);
     }
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
@@ -1133,7 +1142,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     if ((rc = ao_h_products(E))) return rc;
     if ((rc = ao_h_solve(E, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j))) return rc;
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
-    if ((rc = ao_w_products(E, j, min_iter, tol1, tol2))) return rc;
+    if ((rc = ao_w_products(E, j, min_iter, tol1, tol2, !ao_fused_enabled(E, admm_iter)))) return rc;
     { ProfScope ps(E, "inner_w");
       if (ao_fused_enabled(E, admm_iter)) {
           if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;

@@ -72,6 +72,7 @@ struct nmfx_engine {
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     bool ht_ready = false;         // H^T images are current (KL split-bf16 path)
+    int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
     float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
     float* Vt = nullptr;           // V^T, tile-major: [np/128][mp/64] tiles of [128][64] (bf16-path H phase)
