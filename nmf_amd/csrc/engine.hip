@@ -189,6 +189,7 @@ int nmfx_reset_stream(nmfx_handle_t E) {
 }
 
 int nmfx_set_precision(nmfx_handle_t E, int mode) {
+    if (E) E->himg_both = false;
     if (!E || (mode != 0 && mode != 1)) { if (E) E->err = "precision must be 0 (f32) or 1 (split bf16)"; return NMFX_E_ARG; }
     E->precision = mode;
     return NMFX_OK;
@@ -279,6 +280,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->have_f = true;
     E->bf_ready = false;
     E->ht_ready = false;
+    E->himg_both = false;
     E->lazy_objective = false;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
@@ -398,6 +400,7 @@ static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
 }
 
 int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
+    if (E) E->himg_both = false;
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     if (distance == NMFX_EU)
@@ -411,6 +414,7 @@ int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) 
 
 int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min_iter, double tol1,
                      double tol2, int64_t j) {
+    if (E) E->himg_both = false;
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     E->wsel = (int)((j + 1) & 1);

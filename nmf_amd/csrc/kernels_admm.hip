@@ -145,6 +145,7 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
                              double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
                              int64_t count) {
     if (!E) return NMFX_E_ARG;
+    E->himg_both = false;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
     auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N; };

@@ -514,6 +514,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
 // ---- row-sharded form: objective partial -> [all-reduce f64] -> phase_w -> [all-reduce f32]
 // -> phase_h ----
 extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
+    if (E) E->himg_both = false;
     int rc = anls_ready(E, j, 0.0); if (rc) return rc;
     if (j == 0 && (rc = anls_objective(E))) return rc;   // obj[0] partials
     return nmfx_launch_obj_reduce(E);
@@ -521,17 +522,20 @@ extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
 
 extern "C" int nmfx_anls_phase_w(nmfx_handle_t E, double lambda_w, int64_t min_iter, double tol1, double tol2,
                                  int64_t j) {
+    if (E) E->himg_both = false;
     int rc = anls_ready(E, j, lambda_w); if (rc) return rc;
     return anls_w_and_products(E, lambda_w, min_iter, tol1, tol2, j);
 }
 
 extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
+    if (E) E->himg_both = false;
     int rc = anls_ready(E, j, lambda_h); if (rc) return rc;
     return anls_h(E, lambda_h);
 }
 
 extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, int64_t min_iter, double tol1,
                              double tol2, int64_t first, int64_t count) {
+    if (E) E->himg_both = false;
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (first < 0 || count < 0 || lambda_w < 0 || lambda_h < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }

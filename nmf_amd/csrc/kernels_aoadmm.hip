@@ -980,7 +980,7 @@ static int ao_bf16_objective_product(nmfx_engine* E) {   // Bt_part, obj_part (a
     int rc;
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
-    if ((rc = nmfx_bf16_images_h(E, true))) return rc;
+    if (!E->himg_both && (rc = nmfx_bf16_images_h(E, true))) return rc;   // (the W side of the previous iteration built both)
     return nmfx_bf16_vtw(E, true, "hphase");
 }
 
@@ -1104,6 +1104,7 @@ static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, i
                       double tol2, int64_t j) {
     int rc;
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+    E->himg_both = false;                              // H changes below
     ProfScope ps(E, "inner_h");
     if (ao_fused_enabled(E, admm_iter))
         return ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2);
@@ -1116,7 +1117,7 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
     const int64_t kk = (int64_t)E->kp * E->kp;
     E->ao_a_slabs = 0;
     if (ao_bf16(E)) {
-        if ((rc = nmfx_bf16_images_h(E, false))) return rc;                    // the H the sub-problem above produced
+        if ((rc = nmfx_bf16_images_h(E, true))) return rc;   // the H the sub-problem above produced; H^T images for the next H-side product
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;      // kp = 64: H H^T slabs as a by-product
         const bool byprod = E->kp == 64;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
@@ -1206,7 +1207,7 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
     E->wsel = 0;
     E->w_in_place = true;
-    if (distance != NMFX_EU) E->lazy_objective = false;
+    if (distance != NMFX_EU) { E->lazy_objective = false; E->himg_both = false; }
     if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
         if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
     }

@@ -944,6 +944,7 @@ int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf) {      // Whi/Wl
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src) {   // Hhi/Hlo ([kp][np]) (+ HThi/HTlo ([np][kp])) of src (default H)
     ProfScope ps(E, "images");
     int rc;
+    E->himg_both = transposed && !src;
     if (transposed) {
         if ((rc = lazy_alloc(E, &E->HThi, (int64_t)E->kp * E->np))) return rc;
         if ((rc = lazy_alloc(E, &E->HTlo, (int64_t)E->kp * E->np))) return rc;

@@ -73,6 +73,7 @@ struct nmfx_engine {
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     bool ht_ready = false;         // H^T images are current (KL split-bf16 path)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
+    bool himg_both = false;        // Hhi/Hlo AND HThi/HTlo are the images of the current H (AO-ADMM skips a rebuild)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
     float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
     float* Vt = nullptr;           // V^T, tile-major: [np/128][mp/64] tiles of [128][64] (bf16-path H phase)
