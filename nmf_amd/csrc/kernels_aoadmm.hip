@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
 // the first round whose four norm sums satisfy `terminate` (ao_admm.py:33-43), i.e. how many rounds count.
 // Wave w sums component w of up to 8 rounds at a time (their loads are in flight together); per (round,
 // component) the per-lane strides and the shuffle tree are those of inner_round_fired, so the sums are
-// the same numbers.  sh: 32 doubles.  256 threads.
+// the same numbers.  sh: 32 doubles.  256 or 512 threads.
 __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_rounds, int nblk, int admm_iter,
                                             double* sh, int* fired_out)
 {
@@ -543,16 +543,18 @@ __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_round
         double sums[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) sums[u] = 0.0;
-        for (int b = lane; b < nblk; b += 64) {
+        if (wave < 4) {                                // (blocks of 512 threads: waves 4..7 only wait)
+            for (int b = lane; b < nblk; b += 64) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (r0 + u < admm_iter) sums[u] += nrm_rounds[((int64_t)(r0 + u) * nblk + b) * 4 + wave];
-        }
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u < admm_iter) sums[u] += nrm_rounds[((int64_t)(r0 + u) * nblk + b) * 4 + wave];
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 8; ++u) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sums[u] += __shfl_down(sums[u], off, 64);
-            if (lane == 0) sh[u * 4 + wave] = sums[u];
+                for (int off = 32; off > 0; off >>= 1) sums[u] += __shfl_down(sums[u], off, 64);
+                if (lane == 0) sh[u * 4 + wave] = sums[u];
+            }
         }
         __syncthreads();
         // the f64 square roots and divisions of one test are ~1500 cycles: lane u tests round r0 + u
@@ -738,8 +740,10 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
 
 // W side: block = 64 rows (4 waves x 16), M^-1 in LDS; the right-hand side of a wave's 16 rows is
 // turned from the accumulator layout to the A-operand layout through a wave-private LDS tile.
-template <int KP>
-__global__ __launch_bounds__(256) void ao_fused_rows_kernel(
+// RB = 64 rows per block (4 waves), or 128 (8 waves = two per SIMD, which overlap each other's serial parts;
+// used when 128-row blocks still fill the CUs).
+template <int KP, int RB>
+__global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     const float* __restrict__ Asum, int asplit, int64_t astride,     // right-hand side = sum of asplit slabs (slab order)
     float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
@@ -749,9 +753,9 @@ __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
     constexpr int JT = KP / 16;
     constexpr int LDM = KP + 4;
     constexpr int LDR = KP + 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS 4 x [16][LDR] | 32 doubles
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS RB/16 x [16][LDR] | 32 doubles
     float* rs = lds + KP * LDM;
-    double* sh = reinterpret_cast<double*>(rs + 64 * LDR);
+    double* sh = reinterpret_cast<double*>(rs + RB * LDR);
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     int rounds = admm_iter;
@@ -763,11 +767,11 @@ __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
     }
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
-    for (int i = tid; i < KP * (KP / 4); i += 256) {
+    for (int i = tid; i < KP * (KP / 4); i += RB * 4) {
         const int r = i / (KP / 4), c4 = i % (KP / 4);
         *reinterpret_cast<float4*>(lds + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
     }
-    const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    const int64_t r0 = (int64_t)blockIdx.x * RB + wave * 16;
     float* myrs = rs + wave * 16 * LDR;
     // accumulator layout: [it][g] = row 4 q + g, column 16 it + x
     float wx[JT][4], dx[JT][4], ax0[JT][4];
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(256) void ao_fused_rows_kernel(
                 wx[it][g] = wn; dx[it][g] = dn;
             }
         }
-        if (!repair) block_store_norms<4>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
+        if (!repair) block_store_norms<RB / 16>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
         __syncthreads();
     }
 #pragma unroll
@@ -1061,19 +1065,33 @@ static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter,
                                      : launch_fused_cols_cb<KP, 64>(E, prox, lam, admm_iter, repair, slot);
 }
 
-template <int KP>
-static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
-    const size_t shm = (size_t)(KP * (KP + 4) + 64 * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
-    auto kern = ao_fused_rows_kernel<KP>;
+// rows per block of the fused W-side kernel (also the granularity of its norm partials)
+static int ao_fused_rows_rb(const nmfx_engine* E) {
+    static const int forced = getenv("NMFX_AO_ROWS_RB") ? atoi(getenv("NMFX_AO_ROWS_RB")) : 0;
+    if (forced == 64 || (forced == 128 && E->mp % 128 == 0)) return forced;
+    return (E->kp >= 64 && E->mp % 128 == 0 && E->mp / 128 >= (int64_t)E->ncu) ? 128 : 64;
+}
+
+template <int KP, int RB>
+static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+    const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
+    auto kern = ao_fused_rows_kernel<KP, RB>;
     if (shm > 64 * 1024)
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     // ao_a_slabs > 0: the W-side product's slabs are added here instead of by a sum_partials launch
     const bool slabs = E->ao_a_slabs > 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, slabs ? E->A_part : E->auxW,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / RB)), dim3(RB * 4), shm, E->stream, slabs ? E->A_part : E->auxW,
                        slabs ? E->ao_a_slabs : 1, (int64_t)E->mp * E->kp, W, E->dualW, E->bkX, E->bkU,
                        E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+template <int KP>
+static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+    if constexpr (KP >= 64) {
+        if (ao_fused_rows_rb(E) == 128) return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, repair, slot);
+    }
+    return launch_fused_rows_rb<KP, 64>(E, W, prox, lam, admm_iter, repair, slot);
 }
 
 static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, float lam, int admm_iter, int32_t* slot) {
