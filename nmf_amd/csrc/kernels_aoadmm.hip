@@ -306,18 +306,31 @@ __device__ __forceinline__ float prox_apply(float aux, float dual, float shift) 
     return (d < 0.f) ? 0.f : d;                        // np.where(d < 0, 0, d): NaN stays NaN
 }
 
+// wave64 sum of an f32 on the DPP network (quad swaps, row mirrors, row broadcasts: ~6 VALU moves instead of
+// 12 dependent LDS-crossbar shuffles for an f64); the total lands in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define NMFX_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+    NMFX_DPP_ADD(0xB1, 0xf);       // quad_perm [1,0,3,2]
+    NMFX_DPP_ADD(0x4E, 0xf);       // quad_perm [2,3,0,1]
+    NMFX_DPP_ADD(0x141, 0xf);      // row_half_mirror
+    NMFX_DPP_ADD(0x140, 0xf);      // row_mirror: every lane of a row of 16 holds the row sum
+    NMFX_DPP_ADD(0x142, 0xa);      // row_bcast15 into rows 1 and 3
+    NMFX_DPP_ADD(0x143, 0xc);      // row_bcast31 into rows 2 and 3: lane 63 holds the wave sum
+#undef NMFX_DPP_ADD
+    return v;
+}
+
+// The four norm sums of a block: per-thread f32 partials -> f32 wave sums -> f64 across the waves.  (The
+// per-round norm reduction is on the serial path of every inner-round kernel: with f64 shuffles it was
+// ~1.3 us of each round.)  Used by every inner-round kernel, so all of them see the same numbers.
 template <int NW>
 __device__ __forceinline__ void block_store_norms(float n0, float n1, float n2, float n3,
                                                   double* __restrict__ out, double* sh)
 {
-    double v[4] = {(double)n0, (double)n1, (double)n2, (double)n3};
+    const float w0 = wave_sum_to_lane63(n0), w1 = wave_sum_to_lane63(n1);
+    const float w2 = wave_sum_to_lane63(n2), w3 = wave_sum_to_lane63(n3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
-        if (lane == 0) sh[wave * 4 + c] = v[c];
-    }
+    if (lane == 63) { sh[wave * 4 + 0] = (double)w0; sh[wave * 4 + 1] = (double)w1; sh[wave * 4 + 2] = (double)w2; sh[wave * 4 + 3] = (double)w3; }
     __syncthreads();
     if (threadIdx.x < 4) {
         double t = 0.0;
