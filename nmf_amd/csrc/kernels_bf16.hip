@@ -248,15 +248,6 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     }
     const unsigned char* vring = smem + VOFF + wave * (VRING * 4096);
 
-    Frag8 zh[WITH_D ? KP / 32 : 1], zl[WITH_D ? KP / 32 : 1];
-    if (WITH_D) {
-#pragma unroll
-        for (int s = 0; s < KP / 32; ++s) {
-            zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + x) * KP + 32 * s + 8 * g);
-            zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + x) * KP + 32 * s + 8 * g);
-            pinu(zh[s].u); pinu(zl[s].u);
-        }
-    }
     f32x4 acc[NJT];
 #pragma unroll
     for (int j = 0; j < NJT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -270,13 +261,24 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
-    // the Z loads above are ordinary vector loads: retire them before DMAs enter the queue
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
     if (yrole) { if (g0 < g1) issue_y(); }
     else {
 #pragma unroll
         for (int a = 0; a < VRING - 1; ++a) if (g0 + a < g1) issue_v();
+    }
+    // The Z fragments (ordinary vector loads) go out BEHIND the first DMAs, so the block pays one memory round
+    // trip at its start instead of two.  vmcnt retires in order: the wait below also lands the DMAs issued
+    // above, which the first group needs anyway, and every later counted wait only sees DMAs again.
+    Frag8 zh[WITH_D ? KP / 32 : 1], zl[WITH_D ? KP / 32 : 1];
+    if (WITH_D) {
+#pragma unroll
+        for (int s = 0; s < KP / 32; ++s) {
+            zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + x) * KP + 32 * s + 8 * g);
+            zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + x) * KP + 32 * s + 8 * g);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < KP / 32; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
     }
     int ycur = 0, vcur = 0;
     for (int grp = g0; grp < g1; ++grp) {
