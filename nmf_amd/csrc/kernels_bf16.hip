@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
             }
             if (WITH_GRAM && st == NA - 1 && do_gram && ((grp - g0) % ng) == (int)blockIdx.x) {
                 // Gram by-product: operands straight from the LDS tiles at wave-uniform tile rows
-                // (A = rows 16*git.., B = rows 16*(gj0+c)..); only the blockIdx.x == 0 row blocks
+                // (A = rows 16*git.., B = rows 16*(gj0+c)..); row block b < ng takes every ng-th group
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const unsigned char* ys = ybuf + ylane[s];
