@@ -176,7 +176,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.f) ? x[t] : 0.f;
 }
 
-__device__ unsigned long long nnls_dbg[4];     // [sum of iterations, max, problems, exchanges in back-up mode]
+__device__ unsigned long long nnls_dbg[8];     // [sum of iterations, max, problems, exchanges in back-up mode, pivots, final support]
 
 // Register-resident variant for k <= 64 (one variable per lane, one right-hand side per wave):
 // lane i keeps row i of G in registers, the elimination works on a register copy with the pivot
@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if ((Im >> lane) & 1ull) inF = !inF;
         }
         const unsigned long long Fm = __ballot(inF);
+#ifdef NMFX_NNLS_STATS
+        if (lane == 0) atomicAdd(&nnls_dbg[4], (unsigned long long)__popcll(Fm));
+#endif
         float m[KP], rhs = r;
 #pragma unroll
         for (int cc = 0; cc < KP; ++cc) m[cc] = g[cc];
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     if (owner) X[(int64_t)lane * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
 #ifdef NMFX_NNLS_STATS
+    const int nfinal = __popcll(__ballot(valid && x > 0.f));
     if (lane == 0) {
+        atomicAdd(&nnls_dbg[5], (unsigned long long)nfinal);
         atomicAdd(&nnls_dbg[0], (unsigned long long)iter); atomicMax(&nnls_dbg[1], (unsigned long long)iter);
         atomicAdd(&nnls_dbg[2], 1ull); atomicAdd(&nnls_dbg[3], (unsigned long long)nbackup);
     }

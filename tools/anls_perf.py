@@ -22,6 +22,7 @@ print(f"ANLS {m}x{n} k={k}: {1/dt:.1f} iter/s {dt*1e3:.2f} ms", prof)
 if "--stats" in sys.argv:          # library built with NMFX_EXTRA_DEFS=-DNMFX_NNLS_STATS
     import ctypes
     from nmf_amd import _lib
-    out = (ctypes.c_ulonglong * 4)()
+    out = (ctypes.c_ulonglong * 8)()
     _lib.load().nmfx_debug_nnls_stats(out)
-    print("nnls: problems", out[2], "mean iterations", out[0] / max(out[2], 1), "max", out[1], "back-up exchanges per problem", out[3] / max(out[2], 1))
+    print("nnls: problems", out[2], "mean iterations", out[0] / max(out[2], 1), "max", out[1], "back-up exchanges per problem", out[3] / max(out[2], 1),
+          "pivots per problem", out[4] / max(out[2], 1), "mean final support", out[5] / max(out[2], 1))
