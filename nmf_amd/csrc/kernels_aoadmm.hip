@@ -998,7 +998,7 @@ static int ao_bf16_objective_product(nmfx_engine* E) {   // Bt_part, obj_part (a
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
     if (!E->himg_both && (rc = nmfx_bf16_images_h(E, true))) return rc;   // (the W side of the previous iteration built both)
-    return nmfx_bf16_vtw(E, true, "hphase");
+    return nmfx_bf16_vtw(E, true, "hphase", false, 3);
 }
 
 static int ao_h_products(nmfx_engine* E) {
@@ -1149,7 +1149,7 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
     E->ao_a_slabs = 0;
     if (ao_bf16(E)) {
         if ((rc = nmfx_bf16_images_h(E, true))) return rc;   // the H the sub-problem above produced; H^T images for the next H-side product
-        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;      // kp = 64: H H^T slabs as a by-product
+        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj", false, 3))) return rc;      // kp = 64: H H^T slabs as a by-product
         const bool byprod = E->kp == 64;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
         { ProfScope ps(E, "sums");

@@ -26,9 +26,10 @@
 //      that the four-term form has anyway (worst case 3 x 2^-16 instead of 2 x 2^-16, random signs), and it is
 //      25 % of the MFMAs: the W phase of config 2 takes 121-125 us instead of 139-141 on the same box.
 // The multiplicative updates (MUR, both divergences) take 3: an update is a ratio of two such sums and the
-// iteration is self-correcting.  The solvers that put the products into normal equations (ANLS, ADMM,
-// AO-ADMM) keep 4: there the same perturbation is amplified by the conditioning of the Gram matrix (ANLS
-// test matrix 300 x 220, k = 40: objective history 8e-4 off the oracle with 3 terms, < 5e-4 with 4).
+// iteration is self-correcting.  AO-ADMM takes 3 as well: its systems are G + rho I with rho = trace(G) / k,
+// condition number <= k + 1.  ANLS and ADMM keep 4: their systems use the unshifted Gram matrix or the
+// caller's fixed rho, and the perturbation is amplified by the conditioning (ANLS 300 x 220, k = 40: objective
+// history 8e-4 off the oracle with 3 terms, < 5e-4 with 4; ADMM 64 x 64, k = 64, rho = 1: W H 1.02e-4 off).
 // The residual product Z Y of the Euclidean objective always takes 3: the objective is only recorded and
 // compared, nothing is computed from it (3 vs 4 terms moves it by ~1e-8 relative).
 // NMFX_BF16_TERMS=4 in the environment forces 4 for every product that is fed back.
