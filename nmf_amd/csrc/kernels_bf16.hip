@@ -101,8 +101,9 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& 
 //     the lane groups of MI355X_MICROARCH.md, LDS table).  A second, transposed copy of the tile
 //     would double the L2 -> LDS traffic, which is what bounds the W phase.
 //   V side, a 4-deep ring per wave: [16][64] f32, chunk c of row r at position c ^ r;
-//     this is the HBM stream, requested three groups ahead (96 KiB in flight per CU: the stream
-//     rate follows the bytes in flight until HBM saturates).  X is either row-major (ldx) or
+//     this is the HBM stream, requested four groups ahead (the slot of the tile being consumed is
+//     refilled as soon as every wave holds its tile in registers: 128 KiB in flight per CU; the
+//     stream rate follows the bytes in flight until HBM saturates).  X is either row-major (ldx) or
 //     tile-major ([128 rows][64 cols] tiles, one contiguous 32 KiB read per block and group).
 // Everything is filled by LDS-DMA and retired with a COUNTED s_waitcnt vmcnt.  The DMA work
 // is split by wave (4 "Y loaders", 4 "V loaders" that each fetch the tiles of two waves) so
@@ -262,10 +263,16 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
+    // Launches without the objective are bound by the bytes in flight: they refill a V slot as soon as every
+    // wave holds its tile in registers (VRING groups ahead, one more barrier per group).  The launches that also
+    // carry the objective are bound by instruction issue and the extra barrier costs more than the deeper
+    // prefetch brings (config 5 W phase 3014 -> 3168 us, MUR-KL W phase 748 -> 812): those keep VRING - 1.
+    constexpr bool EARLY = !WITH_OBJ;                  // (also the KL H phase: 730 -> 695 us with it)
+    constexpr int VAHEAD = EARLY ? VRING : VRING - 1;  // groups requested ahead of the one being consumed
     if (yrole) { if (g0 < g1) issue_y(); }
     else {
 #pragma unroll
-        for (int a = 0; a < VRING - 1; ++a) if (g0 + a < g1) issue_v();
+        for (int a = 0; a < VAHEAD; ++a) if (g0 + a < g1) issue_v();
     }
     // The Z fragments (ordinary vector loads) go out BEHIND the first DMAs, so the block pays one memory round
     // trip at its start instead of two.  vmcnt retires in order: the wait below also lands the DMAs issued
@@ -283,16 +290,16 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     }
     int ycur = 0, vcur = 0;
     for (int grp = g0; grp < g1; ++grp) {
-        // Y loaders: Y(grp) is their newest request.  V loaders: V(grp+1 .. grp+VRING-2) may
+        // Y loaders: Y(grp) is their newest request.  V loaders: V(grp+1 .. grp+VRING-1) may
         // stay in flight (8 DMAs per group), V(grp) must have landed.
         if (yrole) dma_wait_le<0>();
         else {
-            const int ahead = min(VRING - 2, g1 - 1 - grp);
-            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+            const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
+            if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
         }
         __syncthreads();
         if (yrole) { if (grp + 1 < g1) issue_y(); }
-        else if (grp + VRING - 1 < g1) issue_v();
+        else if (!EARLY && grp + VRING - 1 < g1) issue_v();
         const unsigned char* ybuf = smem + ycur * YBUF;
         const unsigned char* vt = vring + vcur * 4096;
 
@@ -357,6 +364,15 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
         if (!KL && WITH_A) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], vh[s], vl[s]);
+        }
+        if (EARLY) {
+            // Every wave now has its V tile of this group in registers, so the slot is refilled HERE, VRING groups
+            // ahead, instead of at the next group boundary (VRING - 1 ahead): the stream rate follows the bytes in
+            // flight (H phase of config 2: 96 -> 128 KiB per CU, 96 -> 87 us = 6.2 TB/s).  Costs one more barrier
+            // per group: the V loader waves must know that the OTHER waves have read their tiles too.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!yrole && grp + VRING < g1) issue_v();
         }
         float klpart = 0.f;
         f32x4 d[4];                                    // D tiles: d[e][reg] = (Z Y)[row x][16 e + 4 g + reg]
