@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
     // wave holds its tile in registers (VRING groups ahead, one more barrier per group).  The launches that also
     // carry the objective are bound by instruction issue and the extra barrier costs more than the deeper
     // prefetch brings (config 5 W phase 3014 -> 3168 us, MUR-KL W phase 748 -> 812): those keep VRING - 1.
-    constexpr bool EARLY = !WITH_OBJ;                  // (also the KL H phase: 730 -> 695 us with it)
+    constexpr bool EARLY = !WITH_OBJ || !WITH_A;       // (also the KL H phase: 730 -> 695 us with it, and the objective-only pass)
     constexpr int VAHEAD = EARLY ? VRING : VRING - 1;  // groups requested ahead of the one being consumed
     if (yrole) { if (g0 < g1) issue_y(); }
     else {
