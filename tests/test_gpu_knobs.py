@@ -1,0 +1,56 @@
+"""The environment knobs that select an alternative kernel path (read once per process, hence child
+processes): every path must keep the parity bar, ||W H - W_ref H_ref|| / ||V|| < 1e-4 against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+os.environ["NMF_AMD_QUIET"] = "1"
+import numpy as np
+from oracle import nmf_ref as R
+spec = json.loads(sys.argv[1])
+m, n, k = spec["shape"]
+v = R.planted_matrix(m, n, min(k, 32), seed=m + n + k, dtype=np.float32)
+import nmf_amd.mur, nmf_amd.ao_admm, nmf_amd.admm, nmf_amd.anls
+fn = {"mur": nmf_amd.mur.mur, "ao_admm": nmf_amd.ao_admm.ao_admm, "admm": nmf_amd.admm.admm, "anls": nmf_amd.anls.anls}[spec["method"]]
+ref_fn = {"mur": R.mur, "ao_admm": R.ao_admm, "admm": R.admm, "anls": R.anls}[spec["method"]]
+kw = {key: (tuple(val) if isinstance(val, list) else val) for key, val in spec["kwargs"].items()}
+np.random.seed(5); res = fn(v.copy(), k, **kw)
+np.random.seed(5)
+with np.errstate(all="ignore"):
+    ref = ref_fn(v.astype(np.float64), k, **kw)
+err = float(np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)))
+print(json.dumps({"err": err, "i": int(res.i), "ref_i": int(ref.i)}))
+'''
+
+NNDSVD = [True, "zero"]
+CASES = [
+    # (environment, method, shape, kwargs)
+    ({"NMFX_BF16_TERMS": "4"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),
+    ({"NMFX_BF16_TERMS": "4"}, "mur", (384, 256, 40), dict(distance_type="kl", min_iter=15, max_iter=15)),
+    ({"NMFX_PRECISION": "f32"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),
+    ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_AO_FUSED": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
+]
+
+
+@pytest.mark.parametrize("env,method,shape,kwargs", CASES, ids=[f"{list(c[0].items())[0][0]}={list(c[0].items())[0][1]}-{c[1]}-{c[3].get('distance_type', '')}" for c in CASES])
+def test_alternative_paths_keep_parity(env, method, shape, kwargs):
+    spec = json.dumps({"method": method, "shape": list(shape), "kwargs": kwargs})
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, spec], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["i"] == got["ref_i"]
+    assert got["err"] < 1e-4, got
