@@ -77,6 +77,12 @@ int nmfx_get_precision(nmfx_handle_t h);
  * of negative data, nmf/mur.py:99-101, is done by the caller on its array).   */
 int nmfx_upload_v(nmfx_handle_t h, const void* host, int dtype, int64_t ld,
                   int64_t row0, int64_t rows);
+/* The same from DEVICE memory of the handle's GPU (a block the caller produced there, e.g. a
+ * torch tensor's data_ptr): device-to-device copy into the engine's padded layout, no PCIe.
+ * The caller makes sure the producer of `dev` has finished (the copy runs on the handle's
+ * stream); the call returns when the copy is done, `dev` may then be freed.                 */
+int nmfx_upload_v_device(nmfx_handle_t h, const void* dev, int dtype, int64_t ld,
+                         int64_t row0, int64_t rows);
 /* W (m x k) and H (k x n), float64 row-major; either may be NULL to skip.
  * set_factors also zeroes all dual/auxiliary state and the iteration state.   */
 int nmfx_set_factors(nmfx_handle_t h, const double* w, const double* hmat);

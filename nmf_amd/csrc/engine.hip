@@ -19,12 +19,12 @@ static thread_local std::string g_err;
 
 static int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-__global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t n, float* __restrict__ dst,
+__global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t lds, int64_t n, float* __restrict__ dst,
                                     int64_t ldd, int64_t rows)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r = blockIdx.y;
-    if (c < n && r < rows) dst[r * ldd + c] = (float)src[r * n + c];
+    if (c < n && r < rows) dst[r * ldd + c] = (float)src[r * lds + c];
 }
 
 __global__ void init_state_kernel(DevState* st) {
@@ -229,13 +229,38 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
                                             (size_t)E->n * 8, (size_t)cnt, hipMemcpyHostToDevice, E->stream);
             if (e != hipSuccess) { hipFree(stage); E->err = hipGetErrorString(e); return NMFX_E_HIP; }
             dim3 grid((unsigned)((E->n + 255) / 256), (unsigned)cnt);
-            hipLaunchKernelGGL(cvt_f64_rows_kernel, grid, dim3(256), 0, E->stream, stage, E->n,
+            hipLaunchKernelGGL(cvt_f64_rows_kernel, grid, dim3(256), 0, E->stream, stage, E->n, E->n,
                                dst + r * E->np, E->np, cnt);
             e = hipStreamSynchronize(E->stream);
             if (e != hipSuccess) { hipFree(stage); E->err = hipGetErrorString(e); return NMFX_E_HIP; }
         }
         hipFree(stage);
     } else { E->err = "upload_v: dtype must be NMFX_F32 or NMFX_F64"; return NMFX_E_ARG; }
+    E->have_v = true;
+    E->bf_ready = false;
+    return NMFX_OK;
+}
+
+int nmfx_upload_v_device(nmfx_handle_t E, const void* dev, int dtype, int64_t ld, int64_t row0, int64_t rows) {
+    if (!E) return NMFX_E_ARG;
+    if (!dev || row0 < 0 || rows < 0 || row0 + rows > E->m || ld < E->n) {
+        E->err = "upload_v_device: bad row range or leading dimension"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    if (rows == 0) return NMFX_OK;
+    float* dst = E->V + row0 * E->np;
+    if (dtype == NMFX_F32) {
+        NMFX_HIP(hipMemcpy2DAsync(dst, (size_t)E->np * 4, dev, (size_t)ld * 4, (size_t)E->n * 4,
+                                  (size_t)rows, hipMemcpyDeviceToDevice, E->stream));
+    } else if (dtype == NMFX_F64) {
+        for (int64_t r = 0; r < rows; r += 32768) {          // (grid.y limit)
+            const int64_t cnt = std::min<int64_t>(32768, rows - r);
+            dim3 grid((unsigned)((E->n + 255) / 256), (unsigned)cnt);
+            hipLaunchKernelGGL(cvt_f64_rows_kernel, grid, dim3(256), 0, E->stream,
+                               static_cast<const double*>(dev) + r * ld, ld, E->n, dst + r * E->np, E->np, cnt);
+        }
+        NMFX_HIP(hipGetLastError());
+    } else { E->err = "upload_v_device: dtype must be NMFX_F32 or NMFX_F64"; return NMFX_E_ARG; }
+    NMFX_HIP(hipStreamSynchronize(E->stream));
     E->have_v = true;
     E->bf_ready = false;
     return NMFX_OK;

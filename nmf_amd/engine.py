@@ -74,6 +74,14 @@ class Engine:
         self._ck(self.lib.nmfx_upload_v(self.h, _ptr(v), L.F32 if v.dtype == np.float32 else L.F64,
                                         ld, int(row0), v.shape[0]))
 
+    def upload_v_device(self, ptr, rows, row0=0, dtype=np.float32, ld=None):
+        """Rows [row0, row0 + rows) of V from device memory of this GPU (`ptr` = a raw device
+        pointer such as torch.Tensor.data_ptr(), row stride `ld` elements, default n).  The
+        producer of the block must have finished (torch.cuda.synchronize())."""
+        code = L.F32 if np.dtype(dtype) == np.float32 else L.F64
+        self._ck(self.lib.nmfx_upload_v_device(self.h, C.c_void_p(int(ptr)), code, int(ld or self.n),
+                                               int(row0), int(rows)))
+
     def set_factors(self, w, h):
         w = np.ascontiguousarray(w, dtype=np.float64)
         h = np.ascontiguousarray(h, dtype=np.float64)

@@ -35,3 +35,24 @@ def snapshot_errors(name, solver):
             res = solver(v, meta["k"], **kw)
             out[s] = wh_error(res.w, res.h, z[f"snap{s}_w"], z[f"snap{s}_h"], v)
     return out
+
+
+def wh_error_blocked(w, h, w_ref, h_ref, v, block=2048):
+    """wh_error without m x n float64 temporaries (full-size configs): row blocks."""
+    num = den = 0.0
+    for a in range(0, v.shape[0], block):
+        b = min(v.shape[0], a + block)
+        d = w[a:b] @ h - w_ref[a:b] @ h_ref
+        num += float(np.sum(d * d))
+        vb = np.asarray(v[a:b], dtype=np.float64)
+        den += float(np.sum(vb * vb))
+    return np.sqrt(num / den)
+
+
+def direct_objective(v, w, h, kind="eu", block=2048):
+    """nmf/utils.py:18-33 evaluated in float64 from the returned factors, by row blocks."""
+    tot = 0.0
+    for a in range(0, v.shape[0], block):
+        b = min(v.shape[0], a + block)
+        tot += float(R.objective(np.asarray(v[a:b], dtype=np.float64), w[a:b] @ h, kind))
+    return tot
