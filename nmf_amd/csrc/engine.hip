@@ -4,6 +4,8 @@
 #include <cstring>
 #include <cmath>
 #include <tuple>
+#include <mutex>
+#include <utility>
 
 int nmfx_mur_eu_phase_a(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
@@ -16,6 +18,19 @@ int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j);
 #define NMFX_DEFAULT_PRECISION 1   /* split bf16 where available (k padded to 64, MUR-eu); NMFX_PRECISION=f32 for exact f32 */
 #endif
 static thread_local std::string g_err;
+
+int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes) {
+    if (bytes <= 64 * 1024) return NMFX_OK;            // within the default limit
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    int& have = granted[std::make_pair(E->device, kernel)];
+    if (have >= bytes) return NMFX_OK;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return NMFX_OK;
+}
 
 static int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 

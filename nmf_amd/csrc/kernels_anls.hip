@@ -405,12 +405,7 @@ static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const flo
     constexpr int NW = KP <= 64 ? 4 : 2;
     const size_t shm = (size_t)NW * (KP * (KP + 1) + KP) * sizeof(float);
     auto kern = nnls_bpp_kernel<KP>;
-    static bool big_lds_ok = false;
-    if (shm > 64 * 1024 && !big_lds_ok) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        big_lds_ok = true;
-    }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)((nprob + NW - 1) / NW)), dim3(64 * NW), shm, E->stream, G, diag_add,
                        R, X, sj, sc, nprob, E->k, &E->state->flag);
     NMFX_HIP(hipGetLastError());

@@ -899,9 +899,7 @@ static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int6
         if (!scalar) {
             constexpr int NB = KP / 16;
             constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 2) * sizeof(double);
-            static bool attr = false;
-            if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+            { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>), (int)shm); if (rc_) return rc_; }
             hipLaunchKernelGGL((ao_prepare_mfma_kernel<KP>), dim3(1), dim3(KP * 4), shm, E->stream, src, E->k, E->Minv,
                                E->state, record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
                                E->obj_hist, fixed_rho);
@@ -941,9 +939,7 @@ static int launch_inner_rows(nmfx_engine* E, const float* Asum, float* W, const 
                              int prox, float lam, int round, const double* nrm_global) {
     const size_t shm = (size_t)KP * (KP + 4) * sizeof(float) + 16 * sizeof(double);
     auto kern = ao_inner_rows_kernel<KP>;
-    if (shm > 64 * 1024)
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, Asum, W, E->dualW,
                        M, aux, mode, prox, lam, round, E->state, E->nrm_part, nrm_global);
     NMFX_HIP(hipGetLastError());
@@ -1065,8 +1061,7 @@ template <int KP, int CB>
 static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
     const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
     auto kern = ao_fused_cols_kernel<KP, CB>;
-    if (shm > 64 * 1024)
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
                        E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
     NMFX_HIP(hipGetLastError());
@@ -1089,8 +1084,7 @@ template <int KP, int RB>
 static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
     const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP, RB>;
-    if (shm > 64 * 1024)
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     // ao_a_slabs > 0: the W-side product's slabs are added here instead of by a sum_partials launch
     const bool slabs = E->ao_a_slabs > 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / RB)), dim3(RB * 4), shm, E->stream, slabs ? E->A_part : E->auxW,

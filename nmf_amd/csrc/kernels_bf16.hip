@@ -72,6 +72,13 @@ __device__ __forceinline__ void dma_run2(unsigned long long base, unsigned dst, 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1) : "memory", "scc");
 }
+__device__ __forceinline__ void dma_run2_nt(unsigned long long base, unsigned dst, unsigned o0, unsigned o1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1) : "memory", "scc");
+}
 template <int N> __device__ __forceinline__ void dma_wait_le() {      // at most N DMAs still in flight
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
@@ -515,6 +522,428 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------
+// The 32-row form of the Euclidean product launch for KP = 64 (W phase and H phase of MUR, the
+// products of AO-ADMM / ADMM / ANLS): same arguments, same LDS budget, same DMA plan and the same
+// results layout as xyt_bf16_kernel<64, WITH_OBJ, false, TERMS>, but on v_mfma_f32_32x32x16_bf16
+// with the block's 8 waves arranged as 4 row groups (32 rows) x 2 column halves (32 of the group's
+// 64 columns).  Why: the 16-row form reads every Y fragment for 16 rows of V and each wave reads its
+// V tile twice (operand layout + accumulator layout): 2176 LDS-array cycles per 64-column group and
+// CU against 1536 MFMA cycles per SIMD -- the LDS array, not the matrix pipe or HBM, was the W phase's
+// longest queue.  Here a Y fragment feeds 32 rows (half the fragment reads per flop), the MFMA holds
+// the vector issue port for 8 of 32 cycles instead of 8 of 16, and per wave and group there are
+// 32 LDS reads (8 V, 8 Y rows, 16 transposed) instead of 56.
+//   wave (rg = w & 3, hh = w >> 2): rows 32 rg .. + 31 of the block, columns 32 hh .. + 31 of each group
+//   A-product  A[32 rows][64 factors] += V[32][32 cols] Y^T : 2 k-steps (16 columns) x 2 factor tiles
+//   residual   D^T[32 cols][32 rows]  = Y^T[32 cols][64 factors] Z^T : 4 k-steps (16 factors); the
+//              accumulator layout (lane = row, registers = columns 8 a + 4 b + 0..3) is the layout the
+//              second V read uses, so residual = vr - d needs no data movement
+//   the two column halves of a row group hold partial A tiles; they are exchanged through LDS once,
+//   after the last group (each wave finishes one factor tile).
+// LDS: Y images as before ([64 factors][128 B] hi, lo; double buffered) with the chunk swizzle yswz32
+// (tools/lab/swizzle_search.py: conflict free for the b128 row reads of the 32x32x16 B operand, its
+// transposed b64 reads AND the 16x16x32 row reads of the Gram by-product); V ring per row group,
+// [32 rows][64 cols] f32, chunk c of row r at c ^ (r & 15), 4 deep.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).v, (b).v, (c), 0, 0, 0)
+__device__ __forceinline__ int yswz32(int row) {
+    const int b1 = (row >> 1) & 1;
+    return b1 | ((b1 ^ ((row >> 2) & 1)) << 1) | ((b1 ^ ((row >> 3) & 1)) << 2);
+}
+
+#ifdef NMFX_EXP_STAMPS         // experiment (tools/lab/stamps.py): where a wave's cycles go, per segment of the group loop
+__device__ unsigned long long nmfx_dbg_stamps[2][256][8][6];   // [with objective][block][wave][wait, head, early barrier, mfma, cycles, realtime ticks]
+extern "C" int nmfx_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmfx_dbg_stamps), sizeof(nmfx_dbg_stamps)) == hipSuccess ? 0 : -1;
+}
+#define NMFX_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NMFX_STAMP(var) do { } while (0)
+#endif
+#pragma clang fp contract(fast)
+// ABL (experiments only, NMFX_EXP_ABLATE builds; results are then WRONG): bit 0 no DMA in the loop, bit 1 no bf16 split,
+// bit 2 no residual arithmetic, bit 3 no fragment reads after the first group, bit 4 no MFMAs
+template <bool WITH_OBJ, int TERMS, int ABL = 0>
+__global__ __launch_bounds__(512) void xyt32_bf16_kernel(
+    const float* __restrict__ X, int64_t ldx,
+    const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
+    const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
+    float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
+    int ngroups, const int* __restrict__ flag, int ng)
+{
+#define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
+    if (*flag) return;
+    constexpr int KP = 64;
+    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = 2 * YBUF, VRING = 4, VSLOT = 8192;
+    constexpr int NA = 2, ND = WITH_OBJ ? 2 : 0, NS = NA + ND;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, hh = wave >> 2;           // compute role: row group, column half
+    const int n31 = lane & 31, b = lane >> 5;          // 32x32x16 coordinates
+    const int x = lane & 15, g = lane >> 4;            // 16x16x32 coordinates (Gram by-product)
+    const int S = gridDim.y, sp = blockIdx.y;
+    const int g0 = (int)((int64_t)ngroups * sp / S);
+    const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
+    const int64_t r0 = (int64_t)blockIdx.x * 128 + rg * 32;
+
+    // ---- DMA plan (roles by wave as in xyt_bf16_kernel: homogeneous vmcnt queues) ----
+    //   waves 4..7: 4 of the 16 pieces (8 rows x 128 B) of the Y tiles of group grp + 1
+    //   waves 0..3: the V tile [32][64] of row group lw (8 pieces of 4 rows x 256 B), VRING (- 1) groups ahead
+    const bool yrole = wave >= 4;
+    const int lw = wave & 3;
+    const int ytile = lw >> 1, p0 = (lw & 1) * 4;
+    const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
+    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * 128ull;
+    unsigned yoffs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ yswz32(row);
+        yoffs[i] = (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2);
+    }
+    const unsigned ydst = (unsigned)(ytile * YT + p0 * 1024);
+    // X is tile-major: [R/128][ldx/64] tiles of [128 rows][64 cols], 32 KiB contiguous each
+    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)blockIdx.x * (ldx / 64) + g0) * 32768ull;
+    unsigned long long vbaseA = tile0 + (unsigned long long)lw * 32 * 256, vbaseB = vbaseA + 16 * 256;
+    unsigned voffs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }   // rows 4t+g (< 16): row & 15 = row
+    const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
+    const unsigned vdstA = smem0 + VOFF + lw * (VRING * VSLOT), vdstB = vdstA + 4096;
+    int yq = 0, vq = 0;
+    auto issue_y = [&]() {
+        dma_run4(ybase, smem0 + yq * YBUF + ydst, yoffs[0], yoffs[1], yoffs[2], yoffs[3]);
+        ybase += 128ull; yq ^= 1;
+    };
+    auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
+        if (yrole) {
+            if (st < 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * st], yoffs[2 * st + 1]);
+            if (st == 1) { ybase += 128ull; yq ^= 1; }
+        } else {
+            dma_run2_nt(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
+            if (st == 3) { vbaseA += 32768ull; vbaseB += 32768ull; vq = (vq == VRING - 1) ? 0 : vq + 1; }
+        }
+    };
+    auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
+        dma_run4_nt(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+        dma_run4_nt(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+        vbaseA += 32768ull; vbaseB += 32768ull; vq = (vq == VRING - 1) ? 0 : vq + 1;
+    };
+
+    // ---- loop-invariant LDS read offsets ----
+    int vaoff[2][2], vroff[4], yrow[2], tro[2], ylane[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) vaoff[s][e] = n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
+        yrow[s] = n31 * 128 + 16 * ((4 * hh + 2 * s + b) ^ yswz32(n31));          // + 4096 * (factor tile) + YT * (lo image)
+        ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz32(x));                       // + 2048 * (16-factor tile)
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) vroff[a] = n31 * 256 + 16 * ((8 * hh + 2 * a + b) ^ (n31 & 15));
+    {   // transposed reads: lane (G = lane >> 4, q, p) addresses factor row 16 s + 8 (G >> 1) + 4 u + q,
+        // columns 32 hh + 16 (G & 1) + 4 p .. + 3; lane i of the group receives column 16 (G & 1) + i
+        const int q = (lane >> 2) & 3, pp = lane & 3, G = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 8 * (G >> 1) + 4 * u + q;
+            tro[u] = 128 * row + 16 * ((4 * hh + 2 * (G & 1) + (pp >> 1)) ^ yswz32(row)) + 8 * (pp & 1);   // + 2048 * s
+        }
+    }
+    const unsigned char* vring = smem + VOFF + rg * (VRING * VSLOT);
+
+    f32x16 accA[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
+    const bool do_gram = (int)blockIdx.x < ng;         // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
+    const int git = wave >> 1, gj0 = 2 * (wave & 1);
+    f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    double osum = 0.0;
+    // Two loop structures.
+    //  !WITH_OBJ (H phase and the other objective-free products; bound by the bytes in flight): a V slot is refilled as
+    //    soon as every wave holds its tile in registers, VRING groups ahead, at the price of a second barrier per group.
+    //  WITH_OBJ (W phase; twice the MFMAs): in-kernel stamps (tools/lab/stamps.py) showed a third of every group spent in
+    //    its HEAD -- the V tile's LDS reads and the bf16 split, which all 8 waves run together right after the barrier
+    //    with the matrix pipe idle (~1000 of 3300 cycles).  So the loop is software-pipelined ACROSS groups: the barrier
+    //    of group g also guarantees V(g + 1), whose reads and split run between the MFMAs of group g into the other
+    //    register set (the group loop is unrolled by two, the sets alternate).  The slot of V(g) is free at that barrier
+    //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
+    constexpr bool PIPE = WITH_OBJ;
+    constexpr bool EARLY = !WITH_OBJ;
+    constexpr int VAHEAD = VRING;                      // groups requested before the loop
+    Frag8 zh[WITH_OBJ ? 4 : 1], zl[WITH_OBJ ? 4 : 1];  // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
+    if (WITH_OBJ) {                                    // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + n31) * KP + 16 * s + 8 * b);
+            zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + n31) * KP + 16 * s + 8 * b);
+        }
+    }
+    if (yrole) { if (g0 < g1) issue_y(); }
+    else {
+#pragma unroll
+        for (int a = 0; a < VAHEAD; ++a) if (g0 + a < g1) issue_v();
+    }
+    if (WITH_OBJ) {
+        if (yrole) dma_wait_le<4>(); else dma_wait_le<32>();      // (an upper bound of the DMAs issued above: the Z loads are older)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
+    }
+    int ycur = 0, vcur = 0;
+#ifdef NMFX_EXP_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_wait = 0, acc_head = 0, acc_early = 0, acc_mfma = 0;
+    const unsigned long long tbeg = __builtin_amdgcn_s_memtime(), rbeg = __builtin_amdgcn_s_memrealtime();
+#endif
+#define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // a wave's V tile of one group: split A operands + accumulator-layout copy, and the product tile Z Y of the same group
+    struct VRegs { Frag8 vh[2], vl[2]; float4 vr[4]; f32x16 d; };
+    // residual of a finished group: d[4 a + c] = (Z Y)[row n31][column 32 hh + 8 a + 4 b + c].  PIPE: evaluated one group
+    // late, right behind the next group's barrier, where it covers the latency of that group's first fragment reads (at
+    // the end of its own group it was a serial tail of ~250 cycles -- MFMA result, 16 dependent adds, an f64 add -- with
+    // the matrix pipe idle in front of the barrier)
+    auto residual = [&](const VRegs& v) {
+        if (ABL & 4) { osum += (double)(v.d[0] + v.d[5] + v.vr[0].x + v.vr[3].y); return; }
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;  // four chains instead of one
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float rx = v.vr[a].x - v.d[4 * a], ry = v.vr[a].y - v.d[4 * a + 1];
+            const float rz = v.vr[a].z - v.d[4 * a + 2], rw = v.vr[a].w - v.d[4 * a + 3];
+            p0 += rx * rx; p1 += ry * ry; p2 += rz * rz; p3 += rw * rw;
+        }
+        osum += (double)((p0 + p1) + (p2 + p3));
+    };
+    auto read_va = [&](const unsigned char* vt, float4 (&va)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
+    };
+    auto read_vr = [&](const unsigned char* vt, VRegs& v) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) v.vr[a] = *reinterpret_cast<const float4*>(vt + vroff[a]);
+    };
+    // one group: `cur` holds V(grp) (PIPE: filled during the previous group), `nxt` receives V(grp + 1) (PIPE)
+    auto group = [&](int grp, VRegs& cur, VRegs& nxt) {
+        NMFX_STAMP(ts0);
+        if (ABL & 1) { }
+        else if (yrole) dma_wait_le<0>();
+        else if (PIPE) {                               // V(grp + 1) must have landed; V(grp + 2), V(grp + 3) may stay in flight
+            const int ahead = g1 - 2 - grp;
+            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        } else {
+            const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
+            if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        }
+        __syncthreads();
+        NMFX_STAMP(ts1);
+        // PIPE: the next requests -- Y(grp + 1) into the other Y buffer, V(grp + VRING) into the slot of V(grp), which every
+        // wave read before this barrier -- go out in pairs BETWEEN the MFMAs of the stages below (dma_step): issued in one
+        // burst at the top of the group they cost 500-800 cycles per loader wave with the matrix pipe idle (stamps)
+        const bool dma_on = PIPE && !(ABL & 1) && (yrole ? grp + 1 < g1 : grp + VRING < g1);
+        if (!PIPE && yrole) { if (grp + 1 < g1) issue_y(); }
+        const unsigned char* ybuf = smem + ycur * YBUF;
+        const unsigned char* vt = vring + vcur * VSLOT;
+        const unsigned char* vtn = vring + (vcur == VRING - 1 ? 0 : vcur + 1) * VSLOT;
+        float4 va[2][2];
+        Frag8 fh[2][2], fl[2][2];                      // [register set][fragment]
+        auto issue = [&](int st, int set) {
+            if ((ABL & 8) && grp > g0 + 1) { pinu(fh[set][0].u); pinu(fh[set][1].u); pinu(fl[set][0].u); pinu(fl[set][1].u); return; }
+            if (st < NA) {                             // Y rows (factors) 32 t + n31, columns of k-step st
+                const unsigned char* ys = ybuf + yrow[st];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fh[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096);
+                    fl[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096 + YT);
+                }
+            } else {                                   // factors 16 s .. + 15 of the wave's 32 columns, transposed
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int s = 2 * (st - NA) + ss;
+                    const unsigned char* t0 = ybuf + tro[0] + s * 2048;
+                    const unsigned char* t1 = ybuf + tro[1] + s * 2048;
+                    const uint2 h0 = lds_read_tr(t0), h1 = lds_read_tr(t1);
+                    const uint2 l0 = lds_read_tr(t0 + YT), l1 = lds_read_tr(t1 + YT);
+                    fh[set][ss].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    fl[set][ss].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+        };
+        if (!PIPE) {
+            read_va(vt, va);
+            issue(0, 0);
+            NMFX_FENCE();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], cur.vh[s], cur.vl[s]);
+        } else {
+            issue(0, 0);
+            NMFX_FENCE();
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pin4(nxt.vr[a]);   // (opaque: keeps the arithmetic below on this side of the barrier)
+            residual(nxt);                             // of the previous group (zeros in front of the first one)
+            asm volatile("" : "+v"(osum));             // (... and on this side of the MFMAs: hipcc otherwise sinks it to the end of the group)
+            NMFX_FENCE();
+        }
+        NMFX_STAMP(ts2);
+        if (EARLY) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!yrole && grp + VRING < g1) issue_v();
+        }
+        NMFX_STAMP(ts3);
+        f32x16& d = cur.d;
+        if (WITH_OBJ) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int set = st & 1;
+            if (st + 1 < NS) issue(st + 1, set ^ 1);
+            if (PIPE) {                                // V(grp + 1): operand-layout reads in stage 0, accumulator-layout reads in stage 1 (unconditional:
+                                                       // behind the last group they fetch a stale slot that nothing uses; a branch here costs a full LDS drain)
+                if (st == 0) read_va(vtn, va);
+                if (st == 1) read_vr(vtn, nxt);
+            }
+            NMFX_FENCE();
+            if (st < NA) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vh[st], fh[set][t], accA[t]);
+                if (PIPE) { NMFX_FENCE(); if (dma_on) dma_step(st); NMFX_FENCE(); }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fh[set][t], accA[t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vh[st], fl[set][t], accA[t]);
+                if (TERMS >= 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fl[set][t], accA[t]);
+                }
+            } else {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int s = WITH_OBJ ? 2 * (st - NA) + ss : 0;
+                    d = MFMA32X(fh[set][ss], zh[s], d);
+                    d = MFMA32X(fl[set][ss], zh[s], d);
+                    if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st); NMFX_FENCE(); }
+                    d = MFMA32X(fh[set][ss], zl[s], d);
+                }
+            }
+            if (PIPE) {                                // the bf16 split of V(grp + 1) rides between the MFMAs of stages 1 and 2
+                if (ABL & 2) {
+                    if (st == 1) { nxt.vh[0].u = make_uint4(__float_as_uint(va[0][0].x), __float_as_uint(va[0][0].y), __float_as_uint(va[0][0].z), __float_as_uint(va[0][0].w));
+                                   nxt.vl[0].u = make_uint4(__float_as_uint(va[0][1].x), __float_as_uint(va[0][1].y), __float_as_uint(va[0][1].z), __float_as_uint(va[0][1].w)); }
+                    if (st == 2) { nxt.vh[1].u = make_uint4(__float_as_uint(va[1][0].x), __float_as_uint(va[1][0].y), __float_as_uint(va[1][0].z), __float_as_uint(va[1][0].w));
+                                   nxt.vl[1].u = make_uint4(__float_as_uint(va[1][1].x), __float_as_uint(va[1][1].y), __float_as_uint(va[1][1].z), __float_as_uint(va[1][1].w)); }
+                } else {
+                if (st == 1) split8(va[0][0], va[0][1], nxt.vh[0], nxt.vl[0]);
+                if (st == 2) split8(va[1][0], va[1][1], nxt.vh[1], nxt.vl[1]);
+                }
+            }
+            NMFX_FENCE();
+            if (st == NA - 1 && do_gram && ((grp - g0) % ng) == (int)blockIdx.x) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned char* ys = ybuf + ylane[s];
+                    Frag8 ah, al;
+                    ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
+                    al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + YT);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        Frag8 bh, bl;
+                        bh.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048);
+                        bl.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048 + YT);
+                        gacc[c] = MFMA_BF16(ah, bh, gacc[c]);
+                        gacc[c] = MFMA_BF16(al, bh, gacc[c]);
+                        gacc[c] = MFMA_BF16(ah, bl, gacc[c]);
+                        if (TERMS >= 4) gacc[c] = MFMA_BF16(al, bl, gacc[c]);
+                    }
+                }
+            }
+        }
+        NMFX_STAMP(ts4);
+#ifdef NMFX_EXP_STAMPS
+        acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_early += ts3 - ts2; acc_mfma += ts4 - ts3;
+#endif
+        ycur ^= 1;
+        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+    };
+    VRegs P, Q;
+    if (PIPE) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Q.vr[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Q.d[r] = 0.f;
+    }
+    if (PIPE && g0 < g1) {                             // V(g0) into registers before the loop
+        if (!yrole) {
+            const int ahead = min(VAHEAD - 1, g1 - 1 - g0);
+            if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        }
+        __syncthreads();
+        float4 va[2][2];
+        read_va(vring, va);
+        read_vr(vring, P);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], P.vh[s], P.vl[s]);
+    }
+    for (int grp = g0; grp < g1; grp += 2) {
+        group(grp, P, Q);
+        if (grp + 1 < g1) group(grp + 1, Q, P);
+    }
+    if (PIPE && g0 < g1) { if ((g1 - g0) & 1) residual(P); else residual(Q); }      // the last group's
+#undef NMFX_FENCE
+#ifdef NMFX_EXP_STAMPS
+    {
+        const int dbg_b = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && dbg_b < 256) {
+            unsigned long long* o = nmfx_dbg_stamps[WITH_OBJ][dbg_b][wave];
+            o[0] = acc_wait; o[1] = acc_head; o[2] = acc_early; o[3] = acc_mfma;
+            o[4] = __builtin_amdgcn_s_memtime() - tbeg; o[5] = __builtin_amdgcn_s_memrealtime() - rbeg;
+        }
+    }
+#endif
+
+    // ---- the two column halves of a row group exchange partial A tiles: wave (rg, hh) finishes factor tile hh ----
+    __syncthreads();                                   // everybody is done with the LDS tiles
+    {
+        float* xch = reinterpret_cast<float*>(smem);   // slot (rg, t): [16 registers][64 lanes]
+        float* mine = xch + (rg * 2 + (1 - hh)) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64] = hh ? accA[0][r] : accA[1][r];
+        __syncthreads();
+        const float* theirs = xch + (rg * 2 + hh) * 1024 + lane;
+        float* out = Apart + ((int64_t)sp * R + r0) * KP + 32 * hh + n31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float own = hh ? accA[1][r] : accA[0][r];
+            out[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * b) * KP] = own + theirs[r * 64];
+        }
+    }
+    if (do_gram) {
+        float* go = gram_part + ((int64_t)blockIdx.x * S + sp) * KP * KP;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                go[(int64_t)(16 * git + 4 * g + r) * KP + 16 * (gj0 + c) + x] = gacc[c][r];
+    }
+    if (WITH_OBJ) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
+        double* red = reinterpret_cast<double*>(smem + 8 * 4096);      // behind the exchange slots
+        if (lane == 0) red[wave] = osum;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 8; ++w) t += red[w];
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * t;
+        }
+    }
+}
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------
 // out = in^T, stored TILE-MAJOR: tile (c / 128, r / 64) of [128][64] floats holds
 // out[c][r] = in[r][c]; tiles of one 128-row block are consecutive (rows_in / 64 of them).
 // ---------------------------------------------------------------------------
@@ -874,12 +1303,40 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
                         const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;                                       // Y double buffer + V rings
-    static bool attr = false;
     auto kern = xyt_bf16_kernel<KP, OBJ, KL, TERMS, WITH_A>;
-    if (!attr) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
                        gram_part, R, ngroups, &E->state->flag, tiled ? 1 : 0, ng);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+template <bool OBJ, int TERMS>
+static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
+                          const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
+                          const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
+    dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+    const size_t shm = 160 * 1024;
+    auto kern = xyt32_bf16_kernel<OBJ, TERMS>;
+#ifdef NMFX_EXP_ABLATE
+    if (OBJ && TERMS == 3) {
+        static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
+        switch (abl) {
+            case 1: kern = xyt32_bf16_kernel<OBJ, TERMS, 1>; break;
+            case 2: kern = xyt32_bf16_kernel<OBJ, TERMS, 2>; break;
+            case 4: kern = xyt32_bf16_kernel<OBJ, TERMS, 4>; break;
+            case 8: kern = xyt32_bf16_kernel<OBJ, TERMS, 8>; break;
+            case 16: kern = xyt32_bf16_kernel<OBJ, TERMS, 16>; break;
+            case 6: kern = xyt32_bf16_kernel<OBJ, TERMS, 6>; break;
+            case 17: kern = xyt32_bf16_kernel<OBJ, TERMS, 17>; break;
+            case 30: kern = xyt32_bf16_kernel<OBJ, TERMS, 30>; break;
+            default: break;
+        }
+    }
+#endif
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
+                       gram_part, R, ngroups, &E->state->flag, ng);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -903,6 +1360,14 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
     }
     if (E->kp == 64) {
         if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
+        // Euclidean products with k padded to 64: the 32-row kernel (NMFX_XYT16=1 keeps the 16-row form, for A/B runs)
+        static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        if (tiled && gram_part && !rows16) {
+#define NMFX_X32(OBJ_, T_) launch_xyt32_t<OBJ_, T_>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
+            if (terms == 3) return obj ? NMFX_X32(true, 3) : NMFX_X32(false, 3);
+            return obj ? NMFX_X32(true, 4) : NMFX_X32(false, 4);
+#undef NMFX_X32
+        }
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
     }
     if (kl) return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
@@ -1054,9 +1519,7 @@ template <int KP>
 static int launch_w_update_bf16(nmfx_engine* E, const float* Wold, float* Wnew, int nxt, const float* hht, int hslabs, float lam) {
     ProfScope ps(E, "w_update");
     constexpr size_t shm = (size_t)(KP * (KP + 16) + 64 * (KP + 4)) * sizeof(float) + (size_t)2 * KP * 66 * sizeof(unsigned short);
-    static bool ok = false;
-    if (!ok) { NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_w_update_bf16_kernel<KP>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); ok = true; }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_w_update_bf16_kernel<KP>), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(mur_w_update_bf16_kernel<KP>, dim3((unsigned)(E->mp / 64)), dim3(512), shm, E->stream, E->A_part,
                        E->bf_wsplit, E->mp, Wold, hht, hslabs, lam, Wnew, E->Whi[nxt], E->Wlo[nxt], E->WThi, E->WTlo,
                        &E->state->flag);
@@ -1071,14 +1534,8 @@ static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int6
     ProfScope ps(E, "h_update");
     const dim3 grid((unsigned)(E->np / 64)), block(512);
     constexpr size_t shm = (size_t)(KP * (KP + 4) + KP * 80 + 64 * (KP + 4)) * sizeof(float);
-    static bool ok = false;
-    if (!ok) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        ok = true;
-    }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, true>), (int)shm); if (rc_) return rc_;
+      rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, false>), (int)shm); if (rc_) return rc_; }
     if (from_slabs)
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
                            E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,

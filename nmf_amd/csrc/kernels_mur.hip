@@ -190,10 +190,7 @@ template <int KP>
 static int launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2) {
     const size_t shm = (size_t)(KP * KP + KP * 64) * sizeof(float);
     auto kern = mur_h_update_kernel<KP>;
-    if (shm > 64 * 1024) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, E->xf32, E->xf64,
                        E->H, E->np, lam, (long long)j, (long long)min_iter, tol1, tol2, E->state,
                        E->obj_hist);

@@ -629,12 +629,8 @@ static int wphase_dispatch(nmfx_engine* E, const float* W, bool with_a, bool wit
     const int ng = (int)(E->np / 64);
 #define NMFX_WLAUNCH(A, O, K)                                                                  \
     do {                                                                                       \
-        static bool big_lds_ok = false;                                                        \
-        if (shm > 64 * 1024 && !big_lds_ok) {                                                  \
-            NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wphase_kernel<KP, A, O, K>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-            big_lds_ok = true;                                                                 \
-        }                                                                                      \
+        int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(wphase_kernel<KP, A, O, K>), (int)shm); \
+        if (rc_) return rc_;                                                                   \
         hipLaunchKernelGGL((wphase_kernel<KP, A, O, K>), grid, block, shm, E->stream, Vsrc, E->np, W, \
                            Hsrc, E->np, E->A_part, E->obj_part, E->mp, ng, &E->state->flag, flag2); \
     } while (0)
@@ -759,12 +755,7 @@ template <int KP>
 static int kl_vaux_dispatch(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2) {
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)(2 * KP * 64 + 8 * 16 * 64) * sizeof(float);
-    static bool big_lds_ok = false;
-    if (shm > 64 * 1024 && !big_lds_ok) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kl_vaux_kernel<KP>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        big_lds_ok = true;
-    }
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kl_vaux_kernel<KP>), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL((kl_vaux_kernel<KP>), grid, block, shm, E->stream, E->V, E->DV, E->S, E->np, Wsrc, Hsrc,
                        E->np, (int)(E->np / 64), &E->state->flag, flag2);
     NMFX_HIP(hipGetLastError());

@@ -156,6 +156,11 @@ int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M,
                     float lam, int round, const double* nrm_global = nullptr);
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
 
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (device, kernel):
+// the attribute belongs to the function ON A DEVICE, so the bookkeeping is keyed by both and guarded by a
+// mutex -- independent handles may launch from different threads and on different devices.
+int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes);
+
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;
     ProfScope(nmfx_engine* e, const char* nm) : E(e), name(nm) {

@@ -1,0 +1,34 @@
+"""Where the cycles of the 32-row product kernel go (build with NMFX_EXTRA_DEFS=-DNMFX_EXP_STAMPS):
+per wave, the shader cycles spent in the segments of the group loop, summed over the groups of the last launch
+of each kind (W phase = with objective, H phase = without), and the clock the chip held.
+
+    NMFX_EXTRA_DEFS=-DNMFX_EXP_STAMPS python -m nmf_amd.build && python tools/lab/stamps.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("NMF_AMD_QUIET", "1")
+import numpy as np  # noqa: E402
+
+from nmf_amd.engine import Engine  # noqa: E402
+from nmf_amd.synth import planted_matrix  # noqa: E402
+
+m, n, k = 16384, 8192, 64
+v = planted_matrix(m, n, k, seed=0, dtype=np.float32)
+rs = np.random.RandomState(0)
+eng = Engine(m, n, k)
+eng.upload_v(v)
+eng.set_factors(np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n)))
+eng.mur_run(0, 0, 0, 10 ** 12, 1e-5, 1e-5, 0, 600)
+eng.synchronize()
+out = np.zeros((2, 256, 8, 6), dtype=np.uint64)
+assert eng.lib.nmfx_debug_stamps(out.ctypes.data_as(C.c_void_p)) == 0
+for kind, name in ((1, "W phase (objective)"), (0, "H phase")):
+    a = out[kind].astype(np.float64)
+    tot, rt = a[..., 4], a[..., 5]
+    print(name, "median block: %.0f cycles, %.1f us, clock %.2f GHz" % (np.median(tot), np.median(rt) / 100.0, np.median(tot / rt) / 10.0))
+    for role, ws in (("V loaders (waves 0-3)", slice(0, 4)), ("Y loaders (waves 4-7)", slice(4, 8))):
+        seg = np.median(a[:, ws, :4].reshape(-1, 4), axis=0)
+        print("   %-22s wait+barrier %6.0f  head (LDS reads + split) %6.0f  early barrier %6.0f  MFMA stages %6.0f  | per group: %s"
+              % (role, *seg, np.round(seg / 32.0, 0) if kind == 0 else np.round(seg / 64.0, 0)))
