@@ -9,7 +9,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnmfx.so")
+LIB_PATH = os.environ.get("NMFX_LIB") or os.path.join(_HERE, "lib", "libnmfx.so")     # NMFX_LIB: an experiment build (A/B runs on one box)
 
 NMFX_OK, NMFX_E_ARG, NMFX_E_HIP, NMFX_E_NOTPD, NMFX_E_STATE, NMFX_E_NOMEM = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1

@@ -724,6 +724,19 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int a = 0; a < 4; ++a) v.vr[a] = *reinterpret_cast<const float4*>(vt + vroff[a]);
     };
+    Frag8 fh[2][2], fl[2][2];                          // Y fragments: [register set][fragment]
+    // PIPE: the LAST stage of a group (residual k-steps 2, 3; its fragments are in register set 1 by then) is carried
+    // over the next group's barrier and runs while that group's first fragment reads are in flight -- with nothing but
+    // those reads behind the barrier the matrix pipe sat idle for their latency, every group.
+    auto carried_stage = [&](f32x16& d, bool dma_on) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            d = MFMA32X(fh[1][ss], zh[WITH_OBJ ? 2 + ss : 0], d);
+            d = MFMA32X(fl[1][ss], zh[WITH_OBJ ? 2 + ss : 0], d);
+            if (ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(0); NMFX_FENCE(); }
+            d = MFMA32X(fh[1][ss], zl[WITH_OBJ ? 2 + ss : 0], d);
+        }
+    };
     // one group: `cur` holds V(grp) (PIPE: filled during the previous group), `nxt` receives V(grp + 1) (PIPE)
     auto group = [&](int grp, VRegs& cur, VRegs& nxt) {
         NMFX_STAMP(ts0);
@@ -747,7 +760,6 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         const unsigned char* vt = vring + vcur * VSLOT;
         const unsigned char* vtn = vring + (vcur == VRING - 1 ? 0 : vcur + 1) * VSLOT;
         float4 va[2][2];
-        Frag8 fh[2][2], fl[2][2];                      // [register set][fragment]
         auto issue = [&](int st, int set) {
             if ((ABL & 8) && grp > g0 + 1) { pinu(fh[set][0].u); pinu(fh[set][1].u); pinu(fl[set][0].u); pinu(fl[set][1].u); return; }
             if (st < NA) {                             // Y rows (factors) 32 t + n31, columns of k-step st
@@ -779,10 +791,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         } else {
             issue(0, 0);
             NMFX_FENCE();
-#pragma unroll
-            for (int a = 0; a < 4; ++a) pin4(nxt.vr[a]);   // (opaque: keeps the arithmetic below on this side of the barrier)
-            residual(nxt);                             // of the previous group (zeros in front of the first one)
-            asm volatile("" : "+v"(osum));             // (... and on this side of the MFMAs: hipcc otherwise sinks it to the end of the group)
+            carried_stage(nxt.d, dma_on);              // of the previous group (zero fragments in front of the first one)
             NMFX_FENCE();
         }
         NMFX_STAMP(ts2);
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             if (st < NA) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vh[st], fh[set][t], accA[t]);
-                if (PIPE) { NMFX_FENCE(); if (dma_on) dma_step(st); NMFX_FENCE(); }
+                if (PIPE) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fh[set][t], accA[t]);
 #pragma unroll
@@ -819,15 +828,21 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
                     for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fl[set][t], accA[t]);
                 }
-            } else {
+            } else if (!(PIPE && st == NS - 1)) {      // (PIPE: the last stage is carried over the barrier)
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
                     const int s = WITH_OBJ ? 2 * (st - NA) + ss : 0;
                     d = MFMA32X(fh[set][ss], zh[s], d);
                     d = MFMA32X(fl[set][ss], zh[s], d);
-                    if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st); NMFX_FENCE(); }
+                    if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
                     d = MFMA32X(fh[set][ss], zl[s], d);
                 }
+            }
+            if (PIPE && st == 0) {                     // residual of the previous group, between the MFMAs of stage 0
+#pragma unroll
+                for (int a = 0; a < 4; ++a) pin4(nxt.vr[a]);   // (opaque: keeps the arithmetic on this side of the barrier ...
+                residual(nxt);
+                asm volatile("" : "+v"(osum));         //  ... and of the later stages: hipcc otherwise sinks it to the end of the group)
             }
             if (PIPE) {                                // the bf16 split of V(grp + 1) rides between the MFMAs of stages 1 and 2
                 if (ABL & 2) {
@@ -874,6 +889,8 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         for (int a = 0; a < 4; ++a) Q.vr[a] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Q.d[r] = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) { fh[1][ss].u = make_uint4(0u, 0u, 0u, 0u); fl[1][ss].u = make_uint4(0u, 0u, 0u, 0u); }
     }
     if (PIPE && g0 < g1) {                             // V(g0) into registers before the loop
         if (!yrole) {
@@ -891,7 +908,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         group(grp, P, Q);
         if (grp + 1 < g1) group(grp + 1, Q, P);
     }
-    if (PIPE && g0 < g1) { if ((g1 - g0) & 1) residual(P); else residual(Q); }      // the last group's
+    if (PIPE && g0 < g1) {                             // the last group's carried stage and residual
+        if ((g1 - g0) & 1) { carried_stage(P.d, false); residual(P); } else { carried_stage(Q.d, false); residual(Q); }
+    }
 #undef NMFX_FENCE
 #ifdef NMFX_EXP_STAMPS
     {

@@ -38,6 +38,7 @@ CASES = [
     ({"NMFX_BF16_TERMS": "4"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),
     ({"NMFX_BF16_TERMS": "4"}, "mur", (384, 256, 40), dict(distance_type="kl", min_iter=15, max_iter=15)),
     ({"NMFX_PRECISION": "f32"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),
+    ({"NMFX_XYT16": "1"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),      # the 16-row form of the k = 64 product kernel
     ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_FUSED": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
