@@ -216,6 +216,13 @@ int nmfx_anls_phase_h(nmfx_handle_t h, double lambda_h, int64_t j);
 int nmfx_profile_enable(nmfx_handle_t h, int on);
 int nmfx_profile_get(nmfx_handle_t h, const char* name, double* total_ms, int64_t* launches);
 int nmfx_profile_reset(nmfx_handle_t h);
+/* Mean duration of ONE product kernel of MUR -- which = "wphase" (V H^T + objective, nmf/mur.py:29 + utils.py:29)
+ * or "hphase" (W^T V, nmf/mur.py:45), distance NMFX_EU / NMFX_KL -- over `reps` back-to-back launches on the
+ * handle's stream between one pair of HIP events (two untimed launches first).  The launches recompute the
+ * products of the current factors; no factor is modified.  This is the live per-launch time `bench.py` divides
+ * the algorithmic bytes by: a HIP event in front of EVERY launch (nmfx_profile_enable) puts a command-processor
+ * barrier there, which the loop of a real factorisation does not have.                                        */
+int nmfx_profile_repeat(nmfx_handle_t h, const char* which, int distance, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "nmfx_profile_enable": (_i32, [_vp, _i32]),
     "nmfx_profile_get": (_i32, [_vp, C.c_char_p, _pd, C.POINTER(_i64)]),
     "nmfx_profile_reset": (_i32, [_vp]),
+    "nmfx_profile_repeat": (_i32, [_vp, C.c_char_p, _i32, _i32, _pd]),
 }
 
 _lib = None

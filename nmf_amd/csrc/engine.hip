@@ -535,6 +535,44 @@ int nmfx_profile_get(nmfx_handle_t E, const char* name, double* total_ms, int64_
     return NMFX_OK;
 }
 
+// `reps` back-to-back launches of ONE product kernel of the current state between a single pair of HIP events:
+// the per-launch time of the dominant kernel without an event (= a command-processor barrier) in front of
+// every launch, which costs the W phase ~10 us that no real iteration pays.
+int nmfx_profile_repeat(nmfx_handle_t E, const char* which, int distance, int reps, double* ms_per_launch) {
+    if (!E || !which || reps <= 0 || !ms_per_launch) return NMFX_E_ARG;
+    int rc = check_ready(E, 0, 0); if (rc) return rc;
+    const std::string w(which);
+    const bool wph = w == "wphase";
+    if (!wph && w != "hphase") { E->err = "profile_repeat: which must be wphase or hphase"; return NMFX_E_ARG; }
+    if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown distance type."; return NMFX_E_ARG; }
+    const bool bf = E->precision == 1 && nmfx_bf16_supported(E);
+    const bool kl = distance == NMFX_KL;
+    if (bf) {
+        if (!E->bf_ready) E->wsel = 0;
+        if ((rc = nmfx_bf16_prepare(E))) return rc;
+        if (kl && (rc = nmfx_bf16_images_h(E, true))) return rc;          // H^T images: the Z operand of the KL H phase
+    }
+    const bool was = E->prof;
+    E->prof = false;
+    hipEvent_t a, b;
+    NMFX_HIP(hipEventCreate(&a)); NMFX_HIP(hipEventCreate(&b));
+    for (int i = -2; i < reps && !rc; ++i) {                               // two untimed launches first
+        if (i == 0) NMFX_HIP(hipEventRecord(a, E->stream));
+        if (bf) rc = wph ? nmfx_bf16_vht(E, true, E->wsel, "wphase", kl, 3) : nmfx_bf16_vtw(E, false, "hphase", kl, 3);
+        else if (kl) { E->err = "profile_repeat: KL only in the split-bf16 mode"; rc = NMFX_E_ARG; }
+        else rc = wph ? nmfx_launch_wphase(E, E->W[E->wsel], true, true) : nmfx_launch_hphase(E, E->W[E->wsel], nmfx_hphase_can_fuse_gram(E));
+    }
+    E->prof = was;
+    if (rc) { hipEventDestroy(a); hipEventDestroy(b); return rc; }
+    NMFX_HIP(hipEventRecord(b, E->stream));
+    NMFX_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    NMFX_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    *ms_per_launch = (double)ms / reps;
+    return NMFX_OK;
+}
+
 int nmfx_profile_reset(nmfx_handle_t E) {
     if (!E) return NMFX_E_ARG;
     drain_profile(E);

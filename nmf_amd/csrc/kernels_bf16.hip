@@ -531,12 +531,13 @@ __global__ __launch_bounds__(512) void xyt_bf16_kernel(
 // CU against 1536 MFMA cycles per SIMD -- the LDS array, not the matrix pipe or HBM, was the W phase's
 // longest queue.  Here a Y fragment feeds 32 rows (half the fragment reads per flop), the MFMA holds
 // the vector issue port for 8 of 32 cycles instead of 8 of 16, and per wave and group there are
-// 32 LDS reads (8 V, 8 Y rows, 16 transposed) instead of 56.
+// 28 LDS reads (4 V, 8 Y rows, 16 transposed) instead of 56.
 //   wave (rg = w & 3, hh = w >> 2): rows 32 rg .. + 31 of the block, columns 32 hh .. + 31 of each group
 //   A-product  A[32 rows][64 factors] += V[32][32 cols] Y^T : 2 k-steps (16 columns) x 2 factor tiles
-//   residual   D^T[32 cols][32 rows]  = Y^T[32 cols][64 factors] Z^T : 4 k-steps (16 factors); the
-//              accumulator layout (lane = row, registers = columns 8 a + 4 b + 0..3) is the layout the
-//              second V read uses, so residual = vr - d needs no data movement
+//   residual   D^T[32 cols][32 rows]  = Y^T[32 cols][64 factors] Z^T : 4 k-steps (16 factors); the rows of
+//              this tile are a PERMUTATION of the columns (chosen through the addresses of the transposed
+//              reads) such that every accumulator register sits on the lane that holds the same element of
+//              V in the A-operand layout: one LDS read of V serves both products, residual = va - d
 //   the two column halves of a row group hold partial A tiles; they are exchanged through LDS once,
 //   after the last group (each wave finishes one factor tile).
 // LDS: Y images as before ([64 factors][128 B] hi, lo; double buffered) with the chunk swizzle yswz32
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     };
 
     // ---- loop-invariant LDS read offsets ----
-    int vaoff[2][2], vroff[4], yrow[2], tro[2], ylane[2];
+    int vaoff[2][2], yrow[2], tro[2], ylane[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -639,15 +640,17 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         yrow[s] = n31 * 128 + 16 * ((4 * hh + 2 * s + b) ^ yswz32(n31));          // + 4096 * (factor tile) + YT * (lo image)
         ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz32(x));                       // + 2048 * (16-factor tile)
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) vroff[a] = n31 * 256 + 16 * ((8 * hh + 2 * a + b) ^ (n31 & 15));
-    {   // transposed reads: lane (G = lane >> 4, q, p) addresses factor row 16 s + 8 (G >> 1) + 4 u + q,
-        // columns 32 hh + 16 (G & 1) + 4 p .. + 3; lane i of the group receives column 16 (G & 1) + i
+    {   // transposed reads: lane (G = lane >> 4, q, p) addresses factor row 16 s + 8 (G >> 1) + 4 u + q, and its piece of 4
+        // columns goes to lanes 4 p .. 4 p + 3 of the group, i.e. to rows m = 16 (G & 1) + 4 p + c of the product tile.  The
+        // pieces are PERMUTED: row m = 8 a + 4 beta + c of the tile is column 16 (a >> 1) + 8 beta + 4 (a & 1) + c of V (piece p
+        // from columns 8 (p & 1) + 4 (p >> 1) of the 16), so that the accumulator register 4 a + c of lane half b holds column
+        // 16 (a >> 1) + 8 b + 4 (a & 1) + c -- exactly the element of the operand-layout V registers va[a >> 1][a & 1].  One
+        // LDS read of the V tile serves both products (tools/lab/swizzle_search.py: still conflict free).
         const int q = (lane >> 2) & 3, pp = lane & 3, G = lane >> 4;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = 8 * (G >> 1) + 4 * u + q;
-            tro[u] = 128 * row + 16 * ((4 * hh + 2 * (G & 1) + (pp >> 1)) ^ yswz32(row)) + 8 * (pp & 1);   // + 2048 * s
+            tro[u] = 128 * row + 16 * ((4 * hh + 2 * (G & 1) + (pp & 1)) ^ yswz32(row)) + 8 * (pp >> 1);   // + 2048 * s
         }
     }
     const unsigned char* vring = smem + VOFF + rg * (VRING * VSLOT);
@@ -697,19 +700,21 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const unsigned long long tbeg = __builtin_amdgcn_s_memtime(), rbeg = __builtin_amdgcn_s_memrealtime();
 #endif
 #define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
-    // a wave's V tile of one group: split A operands + accumulator-layout copy, and the product tile Z Y of the same group
-    struct VRegs { Frag8 vh[2], vl[2]; float4 vr[4]; f32x16 d; };
+    // a wave's V tile of one group: the f32 values (row n31, columns 16 s + 8 b + 4 e ..), their split A operands, and the
+    // product tile Z Y of the same group (register 4 a + c <-> va[a >> 1][a & 1], component c)
+    struct VRegs { Frag8 vh[2], vl[2]; float4 va[2][2]; f32x16 d; };
     // residual of a finished group: d[4 a + c] = (Z Y)[row n31][column 32 hh + 8 a + 4 b + c].  PIPE: evaluated one group
     // late, right behind the next group's barrier, where it covers the latency of that group's first fragment reads (at
     // the end of its own group it was a serial tail of ~250 cycles -- MFMA result, 16 dependent adds, an f64 add -- with
     // the matrix pipe idle in front of the barrier)
     auto residual = [&](const VRegs& v) {
-        if (ABL & 4) { osum += (double)(v.d[0] + v.d[5] + v.vr[0].x + v.vr[3].y); return; }
+        if (ABL & 4) { osum += (double)(v.d[0] + v.d[5] + v.va[0][0].x + v.va[1][1].y); return; }
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;  // four chains instead of one
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float rx = v.vr[a].x - v.d[4 * a], ry = v.vr[a].y - v.d[4 * a + 1];
-            const float rz = v.vr[a].z - v.d[4 * a + 2], rw = v.vr[a].w - v.d[4 * a + 3];
+            const float4 x4 = v.va[a >> 1][a & 1];
+            const float rx = x4.x - v.d[4 * a], ry = x4.y - v.d[4 * a + 1];
+            const float rz = x4.z - v.d[4 * a + 2], rw = x4.w - v.d[4 * a + 3];
             p0 += rx * rx; p1 += ry * ry; p2 += rz * rz; p3 += rw * rw;
         }
         osum += (double)((p0 + p1) + (p2 + p3));
@@ -719,10 +724,6 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 2; ++e) va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
-    };
-    auto read_vr = [&](const unsigned char* vt, VRegs& v) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) v.vr[a] = *reinterpret_cast<const float4*>(vt + vroff[a]);
     };
     Frag8 fh[2][2], fl[2][2];                          // Y fragments: [register set][fragment]
     // PIPE: the LAST stage of a group (residual k-steps 2, 3; its fragments are in register set 1 by then) is carried
@@ -759,7 +760,6 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         const unsigned char* ybuf = smem + ycur * YBUF;
         const unsigned char* vt = vring + vcur * VSLOT;
         const unsigned char* vtn = vring + (vcur == VRING - 1 ? 0 : vcur + 1) * VSLOT;
-        float4 va[2][2];
         auto issue = [&](int st, int set) {
             if ((ABL & 8) && grp > g0 + 1) { pinu(fh[set][0].u); pinu(fh[set][1].u); pinu(fl[set][0].u); pinu(fl[set][1].u); return; }
             if (st < NA) {                             // Y rows (factors) 32 t + n31, columns of k-step st
@@ -783,11 +783,11 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             }
         };
         if (!PIPE) {
-            read_va(vt, va);
+            read_va(vt, cur.va);
             issue(0, 0);
             NMFX_FENCE();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], cur.vh[s], cur.vl[s]);
+            for (int s = 0; s < 2; ++s) split8(cur.va[s][0], cur.va[s][1], cur.vh[s], cur.vl[s]);
         } else {
             issue(0, 0);
             NMFX_FENCE();
@@ -810,11 +810,6 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         for (int st = 0; st < NS; ++st) {
             const int set = st & 1;
             if (st + 1 < NS) issue(st + 1, set ^ 1);
-            if (PIPE) {                                // V(grp + 1): operand-layout reads in stage 0, accumulator-layout reads in stage 1 (unconditional:
-                                                       // behind the last group they fetch a stale slot that nothing uses; a branch here costs a full LDS drain)
-                if (st == 0) read_va(vtn, va);
-                if (st == 1) read_vr(vtn, nxt);
-            }
             NMFX_FENCE();
             if (st < NA) {
 #pragma unroll
@@ -840,19 +835,22 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             }
             if (PIPE && st == 0) {                     // residual of the previous group, between the MFMAs of stage 0
 #pragma unroll
-                for (int a = 0; a < 4; ++a) pin4(nxt.vr[a]);   // (opaque: keeps the arithmetic on this side of the barrier ...
+                for (int a = 0; a < 4; ++a) pin4(nxt.va[a >> 1][a & 1]);   // (opaque: keeps the arithmetic on this side of the barrier ...
                 residual(nxt);
                 asm volatile("" : "+v"(osum));         //  ... and of the later stages: hipcc otherwise sinks it to the end of the group)
+                // V(grp + 1) from its LDS slot into the registers the residual has just released (unconditional: behind the last
+                // group this fetches a stale slot that nothing uses; a branch here costs a full LDS drain)
+                read_va(vtn, nxt.va);
             }
             if (PIPE) {                                // the bf16 split of V(grp + 1) rides between the MFMAs of stages 1 and 2
                 if (ABL & 2) {
-                    if (st == 1) { nxt.vh[0].u = make_uint4(__float_as_uint(va[0][0].x), __float_as_uint(va[0][0].y), __float_as_uint(va[0][0].z), __float_as_uint(va[0][0].w));
-                                   nxt.vl[0].u = make_uint4(__float_as_uint(va[0][1].x), __float_as_uint(va[0][1].y), __float_as_uint(va[0][1].z), __float_as_uint(va[0][1].w)); }
-                    if (st == 2) { nxt.vh[1].u = make_uint4(__float_as_uint(va[1][0].x), __float_as_uint(va[1][0].y), __float_as_uint(va[1][0].z), __float_as_uint(va[1][0].w));
-                                   nxt.vl[1].u = make_uint4(__float_as_uint(va[1][1].x), __float_as_uint(va[1][1].y), __float_as_uint(va[1][1].z), __float_as_uint(va[1][1].w)); }
+                    if (st == 1) { nxt.vh[0].u = make_uint4(__float_as_uint(nxt.va[0][0].x), __float_as_uint(nxt.va[0][0].y), __float_as_uint(nxt.va[0][0].z), __float_as_uint(nxt.va[0][0].w));
+                                   nxt.vl[0].u = make_uint4(__float_as_uint(nxt.va[0][1].x), __float_as_uint(nxt.va[0][1].y), __float_as_uint(nxt.va[0][1].z), __float_as_uint(nxt.va[0][1].w)); }
+                    if (st == 2) { nxt.vh[1].u = make_uint4(__float_as_uint(nxt.va[1][0].x), __float_as_uint(nxt.va[1][0].y), __float_as_uint(nxt.va[1][0].z), __float_as_uint(nxt.va[1][0].w));
+                                   nxt.vl[1].u = make_uint4(__float_as_uint(nxt.va[1][1].x), __float_as_uint(nxt.va[1][1].y), __float_as_uint(nxt.va[1][1].z), __float_as_uint(nxt.va[1][1].w)); }
                 } else {
-                if (st == 1) split8(va[0][0], va[0][1], nxt.vh[0], nxt.vl[0]);
-                if (st == 2) split8(va[1][0], va[1][1], nxt.vh[1], nxt.vl[1]);
+                if (st == 1) split8(nxt.va[0][0], nxt.va[0][1], nxt.vh[0], nxt.vl[0]);
+                if (st == 2) split8(nxt.va[1][0], nxt.va[1][1], nxt.vh[1], nxt.vl[1]);
                 }
             }
             NMFX_FENCE();
@@ -886,7 +884,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     VRegs P, Q;
     if (PIPE) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) Q.vr[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < 4; ++a) Q.va[a >> 1][a & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Q.d[r] = 0.f;
 #pragma unroll
@@ -898,11 +896,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
         }
         __syncthreads();
-        float4 va[2][2];
-        read_va(vring, va);
-        read_vr(vring, P);
+        read_va(vring, P.va);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) split8(va[s][0], va[s][1], P.vh[s], P.vl[s]);
+        for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
     for (int grp = g0; grp < g1; grp += 2) {
         group(grp, P, Q);

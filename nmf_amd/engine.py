@@ -222,6 +222,12 @@ class Engine:
     def profile_reset(self):
         self._ck(self.lib.nmfx_profile_reset(self.h))
 
+    def profile_repeat(self, which, reps=100, dist=0):
+        """ms per launch of the 'wphase' or 'hphase' product kernel over `reps` back-to-back launches."""
+        ms = C.c_double()
+        self._ck(self.lib.nmfx_profile_repeat(self.h, which.encode(), int(dist), int(reps), C.byref(ms)))
+        return ms.value
+
     def profile_get(self, name):
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.lib.nmfx_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
