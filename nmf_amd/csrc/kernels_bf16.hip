@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     {   // G and the B^T tile: slab sums (fixed order)
         const int ng = FROM_SLABS ? gsplit : 1, nb = FROM_SLABS ? bsplit : 1;
         const int nslab = ng > nb ? ng : nb;
-        for (int p0 = 0; p0 < nslab; p0 += SCH) {
+        auto chunk = [&](int p0) {
             float4 tg[SCH][GV], tb[SCH][TV];
 #pragma unroll
             for (int pp = 0; pp < SCH; ++pp) {
@@ -1230,7 +1230,16 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
                     b[u][0] += tb[pp][u].x; b[u][1] += tb[pp][u].y; b[u][2] += tb[pp][u].z; b[u][3] += tb[pp][u].w;
                 }
             }
+        };
+        chunk(0);
+        // the H tile goes to LDS as soon as the first round trip is over (it was requested in front of it): held in registers
+        // across ALL slab chunks it did not fit next to their 32 in-flight float4 and hipcc parked it in scratch (48 B / lane)
+#pragma unroll
+        for (int u = 0; u < TV; ++u) {
+            const int i = tid + NT * u;
+            *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) = ht[u];
         }
+        for (int p0 = SCH; p0 < nslab; p0 += SCH) chunk(p0);
     }
     if (stop) return;
     double obj;
@@ -1249,7 +1258,6 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
 #pragma unroll
     for (int u = 0; u < TV; ++u) {
         const int i = tid + NT * u;
-        *reinterpret_cast<float4*>(hs + (i >> 4) * LDC + 4 * (i & 15)) = ht[u];
         *reinterpret_cast<float4*>(bt + (i / (KP / 4)) * LDG + 4 * (i % (KP / 4))) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
     }
 #pragma unroll
