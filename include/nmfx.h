@@ -46,7 +46,8 @@ enum {
 
 enum { NMFX_F32 = 0, NMFX_F64 = 1 };                 /* host dtype of V          */
 enum { NMFX_EU = 0, NMFX_KL = 1 };                   /* distance_type            */
-enum { NMFX_PROX_NN = 0, NMFX_PROX_L1N = 1, NMFX_PROX_L2N = 2 };  /* reg type   */
+enum { NMFX_PROX_NN = 0, NMFX_PROX_L1N = 1, NMFX_PROX_L2N = 2,      /* reg type   */
+       NMFX_PROX_L1INF = 3, NMFX_PROX_L1INF_T = 4 };                /* ADMM only (nmf/admm.py:158-210) */
 
 /* ---- lifecycle ---------------------------------------------------------- */
 /* m, n: rows/cols of the LOCAL block of V held by this handle (all of V on one
@@ -90,6 +91,8 @@ int nmfx_get_factors(nmfx_handle_t h, double* w, double* hmat);
 /* Other state matrices by name: "dual_w" "dual_h" (AO-ADMM / ADMM),
  * "w_aux" "h_aux" (ADMM).  Shapes as W / H.                                   */
 int nmfx_get_matrix(nmfx_handle_t h, const char* name, double* out);
+/* The inverse: overwrite one of those state matrices (allocates the ADMM state on first use). */
+int nmfx_set_matrix(nmfx_handle_t h, const char* name, const double* in);
 
 /* ---- iteration state ---------------------------------------------------- */
 /* stop_rule: 0 running, 1 / 2 = which branch of convergence_check fired
@@ -192,6 +195,12 @@ int nmfx_get_inner_counts(nmfx_handle_t h, int64_t first, int64_t count, int32_t
  * which = 0 for the W regulariser, 1 for H.  The finish call of AO-ADMM
  * (nmfx_aoadmm_finish) is shared by ADMM.                                     */
 int nmfx_set_l2n_operator(nmfx_handle_t h, int which, const double* p_inverse);
+/* prox 'l1inf' / 'l1inf_transpose' (nmf/admm.py:158-183, :185-210, upper_bound = 1) as one launch on the current
+ * ADMM state: side 0: w = prox(w_aux^T, dual_w^T)^T (admm.py:320), side 1: h = prox(h_aux, dual_h) (admm.py:319);
+ * update_dual != 0 also does dual += x - x_aux (admm.py:321-322).  nmfx_admm_run calls the same kernels; this entry
+ * exists so that the operator can be checked at function level (state through nmfx_set_matrix / nmfx_get_factors).
+ * 'l1inf' sorts vectors of n (side 1) or m (side 0) entries in LDS: at most 32768.                                   */
+int nmfx_prox_apply(nmfx_handle_t h, int side, int prox, double rho, double lambda, int update_dual);
 int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double lambda_w,
                   int prox_h, double lambda_h, int64_t min_iter, double tol1,
                   double tol2, int64_t first, int64_t count);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NMFX_LIB") or os.path.join(_HERE, "lib", "libnmfx.so"
 NMFX_OK, NMFX_E_ARG, NMFX_E_HIP, NMFX_E_NOTPD, NMFX_E_STATE, NMFX_E_NOMEM = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1
 EU, KL = 0, 1
-PROX = {"nn": 0, "l1n": 1, "l2n": 2}
+PROX = {"nn": 0, "l1n": 1, "l2n": 2, "l1inf": 3, "l1inf_transpose": 4}
 
 _i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
 _pd = C.POINTER(C.c_double)
@@ -36,6 +36,8 @@ SIGNATURES = {
     "nmfx_set_factors": (_i32, [_vp, _vp, _vp]),
     "nmfx_get_factors": (_i32, [_vp, _vp, _vp]),
     "nmfx_get_matrix": (_i32, [_vp, C.c_char_p, _vp]),
+    "nmfx_set_matrix": (_i32, [_vp, C.c_char_p, _vp]),
+    "nmfx_prox_apply": (_i32, [_vp, _i32, _i32, _dbl, _dbl, _i32]),
     "nmfx_get_state": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "nmfx_get_objectives": (_i32, [_vp, _i64, _i64, _vp]),
     "nmfx_mur_run": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),

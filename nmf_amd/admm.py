@@ -3,8 +3,9 @@
 Same call signature, defaults and return value as the reference's `admm.admm`
 (nmf/admm.py:233-345); the loop body (admm.py:292-334: two shifted-Gram solves,
 two prox operators, dual updates, objective) runs on the device through libnmfx
-(nmfx_admm_run).  Regularisers 'nn', 'l1n' and 'l2n' are built ('l2n' is the
-reference's default reg_h); 'l1inf*' are not."""
+(nmfx_admm_run).  Regularisers 'nn', 'l1n', 'l2n' ('l2n' is the reference's
+default reg_h) and 'l1inf' / 'l1inf_transpose' (nmf/admm.py:158-210, as written
+there; the iteration they define diverges in the reference too)."""
 from collections import namedtuple
 
 import numpy as np
@@ -20,8 +21,6 @@ Experiment = namedtuple('Experiment', 'method components rho distance_type nndsv
 def _prox_code(kind):
     if kind in L.PROX:
         return L.PROX[kind]
-    if kind in ('l1inf', 'l1inf_transpose'):
-        raise NotImplementedError(f"prox '{kind}' is not built in nmf_amd (out of scope, see DESIGN.md)")
     raise TypeError('Unknown prox_type.')                       # nmf/admm.py:213
 
 
@@ -53,11 +52,18 @@ def admm(v, k, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), 
             eng.set_l2n_operator(0, l2n_operator(k, rho, reg_w[0]))
         if prox_h == L.PROX['l2n']:
             eng.set_l2n_operator(1, l2n_operator(k, rho, reg_h[0]))
+        def will_go(i):
+            # stdout of the reference's 'l1inf_transpose' branch (nmf/admm.py:190), H first (admm.py:319-320)
+            if reg_h[1] == 'l1inf_transpose':
+                utils.say('will go {}'.format(v.shape[1]))
+            if reg_w[1] == 'l1inf_transpose':
+                utils.say('will go {}'.format(v.shape[0]))
+
         i, history = drive(
             eng,
             lambda first, count: eng.admm_run(dist, rho, prox_w, reg_w[0], prox_h, reg_h[0], min_iter,
                                               tol1, tol2, first, count),
             lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
-            max_iter, tol1, tol2)
+            max_iter, tol1, tol2, before_line=will_go)
         w, h = eng.get_factors()
     return Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)

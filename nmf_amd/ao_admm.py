@@ -10,8 +10,11 @@ is evaluated on the device too.
 Regularisers: 'nn' and 'l1n' are built.  'l2n' raises ValueError exactly like
 the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it
 is also the reference's DEFAULT reg_h, so callers must pass reg_h explicitly);
-'l1inf' / 'l1inf_transpose' are not built (index bugs in the
-reference, out of scope)."""
+'l1inf' / 'l1inf_transpose' raise numpy.linalg.LinAlgError like the reference:
+its ao_admm copy of the operator (nmf/ao_admm.py:143-195) divides by a zero
+count in the first sub-problem and the Cholesky factorisation of the next one
+fails ("leading minor not positive definite"; probed for all four placements).
+The working copy of the operator is ADMM's (nmf_amd.admm)."""
 from collections import namedtuple
 
 import numpy as np
@@ -31,7 +34,7 @@ def _prox_code(kind):
         raise ValueError('setting an array element with a sequence. The requested array has an '
                          'inhomogeneous shape (reference nmf/ao_admm.py:128 on numpy >= 1.24)')
     if kind in ('l1inf', 'l1inf_transpose'):
-        raise NotImplementedError(f"prox '{kind}' is not built in nmf_amd (out of scope, see DESIGN.md)")
+        raise np.linalg.LinAlgError('1-th leading minor of the array is not positive definite')   # scipy cholesky, ao_admm.py:55
     raise TypeError('Unknown prox_type.')                       # nmf/ao_admm.py:198
 
 

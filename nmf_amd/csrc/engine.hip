@@ -359,6 +359,21 @@ int nmfx_get_matrix(nmfx_handle_t E, const char* name, double* out) {
                  : get_padded(E, src, out, E->k, E->n, E->kp, E->np);
 }
 
+int nmfx_set_matrix(nmfx_handle_t E, const char* name, const double* in) {
+    if (!E || !name || !in) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = nmfx_admm_state_alloc(E))) return rc;
+    const std::string s(name);
+    float* dst = nullptr; bool wlike = false;
+    if (s == "dual_w") { dst = E->dualW; wlike = true; }
+    else if (s == "dual_h") { dst = E->dualH; }
+    else if (s == "w_aux") { dst = E->auxW; wlike = true; }
+    else if (s == "h_aux") { dst = E->auxH; }
+    else { E->err = "set_matrix: unknown name"; return NMFX_E_ARG; }
+    return wlike ? put_padded(E, dst, in, E->m, E->k, E->mp, E->kp) : put_padded(E, dst, in, E->k, E->n, E->kp, E->np);
+}
+
 int nmfx_get_state(nmfx_handle_t E, int* stop_rule, int64_t* stop_i, int64_t* n_obj) {
     if (!E) return NMFX_E_ARG;
     DevState hs; int rc;

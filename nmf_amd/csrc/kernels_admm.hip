@@ -30,6 +30,8 @@ static int admm_alloc(nmfx_engine* E) {
     return NMFX_OK;
 }
 
+int nmfx_admm_state_alloc(nmfx_engine* E) { return admm_alloc(E); }
+
 static bool admm_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_bf16_supported(E); }
 
 // objective partials of (W, H) (admm.py:324); split-bf16: one pass of the product kernel with
@@ -71,6 +73,9 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
       if (prox_h == NMFX_PROX_L2N) {
           if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
           if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
+      } else if (prox_h == NMFX_PROX_L1INF || prox_h == NMFX_PROX_L1INF_T) {   // couples whole rows / columns: its own launch
+          if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+          if ((rc = nmfx_launch_prox_l1inf(E, true, prox_h == NMFX_PROX_L1INF_T, rho, lam_h, 1.0, true))) return rc;
       } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc; }
     // ---- w_aux (from the NEW h_aux) and the W half ----
     if (bf) {
@@ -93,6 +98,9 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
       if (prox_w == NMFX_PROX_L2N) {
           if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
           if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
+      } else if (prox_w == NMFX_PROX_L1INF || prox_w == NMFX_PROX_L1INF_T) {
+          if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+          if ((rc = nmfx_launch_prox_l1inf(E, false, prox_w == NMFX_PROX_L1INF_T, rho, lam_w, 1.0, true))) return rc;
       } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc; }
     // ---- objective of (w, h) (admm.py:324) ----
     return admm_objective(E);
@@ -113,6 +121,9 @@ static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     if (prox_h == NMFX_PROX_L2N) {
         if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
         if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
+    } else if (prox_h == NMFX_PROX_L1INF || prox_h == NMFX_PROX_L1INF_T) {
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+        if ((rc = nmfx_launch_prox_l1inf(E, true, prox_h == NMFX_PROX_L1INF_T, rho, lam_h, 1.0, true))) return rc;
     } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc;
     if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->auxH, E->S))) return rc;
@@ -122,6 +133,9 @@ static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     if (prox_w == NMFX_PROX_L2N) {
         if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
         if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
+    } else if (prox_w == NMFX_PROX_L1INF || prox_w == NMFX_PROX_L1INF_T) {
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+        if ((rc = nmfx_launch_prox_l1inf(E, false, prox_w == NMFX_PROX_L1INF_T, rho, lam_w, 1.0, true))) return rc;
     } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc;
     if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->auxH))) return rc;
     return nmfx_launch_wphase(E, W, false, true, true);
@@ -141,6 +155,19 @@ extern "C" int nmfx_set_l2n_operator(nmfx_handle_t E, int which, const double* p
     return NMFX_OK;
 }
 
+// Function-level entry (tests, and callers that drive their own ADMM loop): X = prox(X_aux, dual) on one side of the
+// current ADMM state; update_dual != 0 also performs dual += X - X_aux (admm.py:321-322).
+extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, double lambda, int update_dual) {
+    if (!E || (side != 0 && side != 1)) { if (E) E->err = "prox_apply: side must be 0 (W) or 1 (H)"; return NMFX_E_ARG; }
+    if (prox != NMFX_PROX_L1INF && prox != NMFX_PROX_L1INF_T) { E->err = "prox_apply: only the l1inf operators have a launch of their own"; return NMFX_E_ARG; }
+    if (!(rho != 0.0)) { E->err = "prox_apply: rho must not be zero"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = admm_alloc(E))) return rc;
+    E->wsel = 0; E->w_in_place = true;
+    return nmfx_launch_prox_l1inf(E, side == 1, prox == NMFX_PROX_L1INF_T, rho, lambda, 1.0, update_dual != 0);
+}
+
 extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
                              double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
                              int64_t count) {
@@ -148,7 +175,7 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
     E->himg_both = false;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
-    auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N; };
+    auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N && p != NMFX_PROX_L1INF && p != NMFX_PROX_L1INF_T; };
     if (bad(prox_w) || bad(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || !(rho > 0.0)) { E->err = "bad range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));

@@ -148,6 +148,7 @@ int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
 
 // AO-ADMM / ADMM building blocks (kernels_aoadmm.hip)
 int nmfx_aoadmm_alloc(nmfx_engine* E);
+int nmfx_admm_state_alloc(nmfx_engine* E);       // + the aux matrices of ADMM (kernels_admm.hip)
 int nmfx_kl_state_alloc(nmfx_engine* E);
 int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,
                         double tol1, double tol2, double fixed_rho);
@@ -160,6 +161,9 @@ int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, co
 // the attribute belongs to the function ON A DEVICE, so the bookkeeping is keyed by both and guarded by a
 // mutex -- independent handles may launch from different threads and on different devices.
 int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes);
+
+// prox 'l1inf' / 'l1inf_transpose' of ADMM (kernels_prox.hip): X = prox(X_aux, dual) on the W or the H side
+int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual);
 
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;

@@ -101,6 +101,18 @@ class Engine:
         self._ck(self.lib.nmfx_get_matrix(self.h, name.encode(), _ptr(out)))
         return out
 
+    def set_matrix(self, name, a):
+        wlike = name in ("dual_w", "w_aux")
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != ((self.m, self.k) if wlike else (self.k, self.n)):
+            raise ValueError("matrix shape does not match the engine")
+        self._ck(self.lib.nmfx_set_matrix(self.h, name.encode(), _ptr(a)))
+
+    def prox_apply(self, side, kind, rho, lam, update_dual=False):
+        """x = prox(x_aux, dual) for side 'w' | 'h' with the l1inf operators of nmf/admm.py:158-210."""
+        self._ck(self.lib.nmfx_prox_apply(self.h, {"w": 0, "h": 1}[side], L.PROX[kind], float(rho), float(lam),
+                                          1 if update_dual else 0))
+
     # -- state -------------------------------------------------------------
     def state(self):
         rule, stop_i, n_obj = C.c_int(), C.c_int64(), C.c_int64()

@@ -55,3 +55,15 @@ def test_unknown_method_and_distance_raise_like_reference():
         NMF(v, 3).factorize(method="nope")
     with pytest.raises(KeyError):                                   # nmf/utils.py:31
         NMF(v, 3).factorize(method="mur", distance_type="xx")
+
+
+def test_ao_admm_l1inf_raises_like_reference():
+    """nmf/ao_admm.py:143-195: the ao_admm copy of the operator breaks the next Cholesky factorisation (scipy
+    LinAlgError) for every placement; raised before any device work."""
+    from nmf_amd.ao_admm import ao_admm
+    v = np.random.RandomState(0).rand(16, 12)
+    for kind in ("l1inf", "l1inf_transpose"):
+        with pytest.raises(np.linalg.LinAlgError):
+            ao_admm(v, 3, reg_w=(0.1, "nn"), reg_h=(0.1, kind), nndsvd_init=(False, "zero"))
+        with pytest.raises(np.linalg.LinAlgError):
+            ao_admm(v, 3, reg_w=(0.1, kind), reg_h=(0.1, "nn"), nndsvd_init=(False, "zero"))
