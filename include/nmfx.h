@@ -101,6 +101,10 @@ int nmfx_set_matrix(nmfx_handle_t h, const char* name, const double* in);
  * objective of the initial factors, nmf/mur.py:115).                           */
 int nmfx_get_state(nmfx_handle_t h, int* stop_rule, int64_t* stop_i, int64_t* n_obj);
 int nmfx_get_objectives(nmfx_handle_t h, int64_t first, int64_t count, double* out);
+/* NNLS diagnostics of ANLS since the last nmfx_set_factors: passive variables dropped because their pivot vanished
+ * (a dead or collinear component at lambda = 0; their x stays 0 like in scipy's nnls / nmf/fcnnls.py) and solves that
+ * ran into the iteration cap (8 k + 64 exchanges; the reference's FCNNLS prints 'Not converged.' in that case).      */
+int nmfx_get_diagnostics(nmfx_handle_t h, int64_t* nnls_evicted, int64_t* nnls_capped);
 
 /* ---- MUR (replaces the loop body nmf/mur.py:119-131) -------------------- */
 /* Queue `count` outer iterations starting at iteration `first` (= number of
@@ -206,6 +210,9 @@ int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double 
                   double tol2, int64_t first, int64_t count);
 
 /* ---- ANLS (replaces nmf/anls.py:111-122) -------------------------------- */
+/* distance_type of ANLS (nmf/anls.py:108,118): NMFX_EU (default) or NMFX_KL.  It only selects the objective that is
+ * recorded and tested by the stop rule; the iterates are the least-squares ones either way, as in the reference.   */
+int nmfx_anls_set_distance(nmfx_handle_t h, int distance);
 int nmfx_anls_run(nmfx_handle_t h, double lambda_w, double lambda_h,
                   int64_t min_iter, double tol1, double tol2,
                   int64_t first, int64_t count);

@@ -66,7 +66,9 @@ SIGNATURES = {
     "nmfx_get_inner_counts": (_i32, [_vp, _i64, _i64, _vp]),
     "nmfx_set_l2n_operator": (_i32, [_vp, _i32, _vp]),
     "nmfx_admm_run": (_i32, [_vp, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_anls_set_distance": (_i32, [_vp, _i32]),
     "nmfx_anls_run": (_i32, [_vp, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_get_diagnostics": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "nmfx_profile_enable": (_i32, [_vp, _i32]),
     "nmfx_profile_get": (_i32, [_vp, C.c_char_p, _pd, C.POINTER(_i64)]),
     "nmfx_profile_reset": (_i32, [_vp]),

@@ -9,6 +9,7 @@ strictly convex problems in the reference (scipy's Lawson-Hanson vs
 nmf/fcnnls.py); here it is recorded in the experiment tuple (and therefore in
 the save-file name) and otherwise has no effect.  `distance_type` only selects
 the reported objective, exactly as in the reference."""
+import logging
 from collections import namedtuple
 
 from . import _lib as L
@@ -26,17 +27,22 @@ def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, 
                             lambda_h, use_fcnnls)
     if distance_type not in ('eu', 'kl'):
         raise KeyError('Distance type unknown: use "kl" or "eu"')   # nmf/utils.py:31 via anls.py:108
-    if distance_type == 'kl':
-        raise NotImplementedError("anls with distance_type='kl' (KL objective of least-squares "
-                                  "iterates) is not built in nmf_amd")
+    dist = L.EU if distance_type == 'eu' else L.KL
     init = utils.initial_factors(x, k, nndsvd_init, uniform=True, defer_device=True)
     with Engine.for_data(x, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
+        eng.anls_set_distance(dist)
         i, history = drive(
             eng,
             lambda first, count: eng.anls_run(lambda_w, lambda_h, min_iter, tol1, tol2, first, count),
             lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
             max_iter, tol1, tol2)
         w, h = eng.get_factors()
+        evicted, capped = eng.diagnostics()
+    if capped:                    # (the reference's FCNNLS prints 'Not converged.' there, nmf/fcnnls.py:118)
+        logging.warning('%d NNLS solves reached the iteration cap', capped)
+    if evicted:
+        logging.info('%d passive NNLS variables had a vanished pivot (dead or collinear component) and stay at zero', evicted)
+    anls.last_diagnostics = {'nnls_evicted': evicted, 'nnls_capped': capped}
     return Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)

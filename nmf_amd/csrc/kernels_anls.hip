@@ -31,13 +31,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // rounding of every solve and the exchange rule cycles until the iteration cap (seen on 0.03 % of
 // the right-hand sides at 16384 x 8192 -- they set the run time of the whole launch).
 #define NMFX_NNLS_TOL 1e-6f
+// A passive pivot that has shrunk to this fraction of the variable's own diagonal entry is treated as zero: the
+// variable is dropped from the passive set for the rest of the solve and keeps x = 0.  That is what happens to a
+// dead component (a zero column of the fixed factor: G_pp = 0) or to the second of two collinear ones at
+// lambda = 0 -- the Gram matrix is then singular on the passive set, the unguarded 1 / pivot made the whole
+// right-hand side NaN and the solve silently returned zeros.  Lawson-Hanson and FCNNLS leave such a variable
+// at zero as well (its dual is zero, it is never selected).  (NaN pivots fail the comparison and are dropped too.)
+#define NMFX_NNLS_PIVOT_EPS 1e-6f
 
 template <int KP>
 __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
 {
-    if (*flag) return;
+    if (st->flag) return;
     constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
     constexpr int NW = KP <= 64 ? 4 : 2;                // waves (problems) per block
     constexpr int LDM = KP + 1;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
     float* M = lds + (size_t)wave * (KP * LDM + KP);     // [KP][KP+1] augmented rows
     float* xs = M + KP * LDM;                            // [KP] broadcast copy of x
 
-    int idx[NV]; bool valid[NV], inF[NV];
+    int idx[NV]; bool valid[NV], inF[NV], dead[NV];
     float r[NV], x[NV], y[NV];
     // WARM START: the passive set starts as the support of the previous solution (X on entry: the
     // factor of the last outer iteration, or the initial factor).  Block principal pivoting reaches the
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         idx[t] = lane + 64 * t;
         valid[t] = idx[t] < k;
         r[t] = valid[t] ? R[(int64_t)idx[t] * sj + c * sc] : 0.f;
-        x[t] = 0.f; y[t] = -r[t];
+        x[t] = 0.f; y[t] = -r[t]; dead[t] = false;
         inF[t] = valid[t] && X[(int64_t)idx[t] * sj + c * sc] > 0.f;
     }
     float toly;
@@ -69,8 +76,8 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         for (int t = 0; t < NV; ++t) ar = fmaxf(ar, fabsf(r[t]));
         toly = NMFX_NNLS_TOL * wave_max(ar);
     }
-    int best = k + 1, spare = 3;
-    for (int iter = 0; iter < 8 * KP + 64; ++iter) {
+    int best = k + 1, spare = 3, iter = 0;
+    for (; iter < 8 * KP + 64; ++iter) {
         unsigned long long Im[NV];
         if (iter > 0) {                                  // (iteration 0 solves for the warm-start set first)
         float ax = 0.f;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         int n_inf = 0;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            const bool bad = valid[t] && (inF[t] ? (x[t] < -tolx) : (y[t] < -toly));
+            const bool bad = valid[t] && !dead[t] && (inF[t] ? (x[t] < -tolx) : (y[t] < -toly));
             Im[t] = __ballot(bad);
             n_inf += __popcll(Im[t]);
         }
@@ -133,6 +140,12 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
                 left &= left - 1;
                 const int p = b + 64 * tp;
                 const float* prow = M + p * LDM;
+                if (!(prow[p] > NMFX_NNLS_PIVOT_EPS * (G[(int64_t)p * KP + p] + diag_add))) {   // vanished pivot: drop the variable
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) if (idx[t] == p) { inF[t] = false; dead[t] = true; }
+                    if (lane == 0) atomicAdd(&st->nnls_evicted, 1);
+                    continue;
+                }
                 const float inv = 1.f / prow[p];
                 const int c0 = (p + 1) & ~3;                 // columns <= p of the pivot row are already zero
 #pragma unroll
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
             y[t] = acc;
         }
     }
+    if (iter == 8 * KP + 64 && lane == 0) atomicAdd(&st->nnls_capped, 1);
 #pragma unroll
     for (int t = 0; t < NV; ++t)
         if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.f) ? x[t] : 0.f;
@@ -188,9 +202,9 @@ __device__ unsigned long long nnls_dbg[8];     // [sum of iterations, max, probl
 template <int KP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void nnls_bpp_reg_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
 {
-    if (*flag) return;
+    if (st->flag) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
     if (c >= nprob) return;                              // whole wave leaves together
@@ -198,6 +212,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     float g[KP];
 #pragma unroll
     for (int cc = 0; cc < KP; ++cc) g[cc] = owner ? G[(int64_t)lane * KP + cc] + (cc == lane ? diag_add : 0.f) : 0.f;
+    float gd = 0.f;                                      // this variable's own diagonal entry (pivot guard)
+#pragma unroll
+    for (int cc = 0; cc < KP; ++cc) gd = (cc == lane) ? g[cc] : gd;
+    bool dead = false;
     const float r = valid ? R[(int64_t)lane * sj + c * sc] : 0.f;
     bool inF = valid && X[(int64_t)(owner ? lane : 0) * sj + c * sc] > 0.f;      // warm start: previous support
     float x = 0.f, y = -r;
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (; iter < 8 * KP + 64; ++iter) {
         if (iter > 0) {
             const float tolx = NMFX_NNLS_TOL * wave_max(fabsf(x));
-            const bool bad = valid && (inF ? (x < -tolx) : (y < -toly));
+            const bool bad = valid && !dead && (inF ? (x < -tolx) : (y < -toly));
             unsigned long long Im = __ballot(bad);
             const int n_inf = __popcll(Im);
             if (n_inf == 0) break;
@@ -236,7 +254,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             float f = 0.f;
 #pragma unroll
             for (int cc = 0; cc < KP; ++cc) f = (cc == p) ? m[cc] : f;
-            const float inv = 1.f / __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(f)));
+            const float piv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(f)));
+            if (!(piv > NMFX_NNLS_PIVOT_EPS * __int_as_float(__builtin_amdgcn_ds_bpermute(4 * p, __float_as_int(gd))))) {
+                if (lane == p) { inF = false; dead = true; atomicAdd(&st->nnls_evicted, 1); }      // vanished pivot: drop the variable
+                continue;
+            }
+            const float inv = 1.f / piv;
             const bool me = lane == p;
 #pragma unroll
             for (int c0 = 0; c0 < KP; c0 += 16) {
@@ -260,6 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             acc = fmaf(g[cc], __int_as_float(__builtin_amdgcn_ds_bpermute(4 * cc, __float_as_int(x))), acc);
         y = (valid && !inF) ? acc : 0.f;
     }
+    if (iter == 8 * KP + 64 && lane == 0) atomicAdd(&st->nnls_capped, 1);
     if (owner) X[(int64_t)lane * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
 #ifdef NMFX_NNLS_STATS
     const int nfinal = __popcll(__ballot(valid && x > 0.f));
@@ -280,9 +304,9 @@ extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build wit
 // waves exchanged through LDS.  Same algorithm as nnls_bpp_reg_kernel.
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) void nnls_bpp_reg128_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, const int* __restrict__ flag)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
 {
-    if (*flag) return;
+    if (st->flag) return;
     constexpr int KP = 128;
     __shared__ __attribute__((aligned(16))) float prow_s[2][KP + 4];   // pivot row, [KP] = its right-hand side
     __shared__ __attribute__((aligned(16))) float xs[KP];
@@ -294,6 +318,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float* grow = G + (int64_t)tid * KP;
     const float r = valid ? R[(int64_t)tid * sj + c * sc] : 0.f;
     bool inF = valid && X[(int64_t)tid * sj + c * sc] > 0.f;        // warm start: previous support
+    bool dead = false;
     float x = 0.f, y = -r;
     int ph = 0;                                                      // parity of the small exchange buffers
     auto block_max = [&](float v) {
@@ -312,12 +337,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         ph ^= 1;
     };
     const float toly = NMFX_NNLS_TOL * block_max(fabsf(r));
-    int best = k + 1, spare = 3, pbuf = 0;
-    for (int iter = 0; iter < 8 * KP + 64; ++iter) {
+    int best = k + 1, spare = 3, pbuf = 0, iter = 0;
+    for (; iter < 8 * KP + 64; ++iter) {
         if (iter > 0) {
             const float tolx = NMFX_NNLS_TOL * block_max(fabsf(x));
             unsigned long long Im[2];
-            block_masks(valid && (inF ? (x < -tolx) : (y < -toly)), Im);
+            block_masks(valid && !dead && (inF ? (x < -tolx) : (y < -toly)), Im);
             const int n_inf = __popcll(Im[0]) + __popcll(Im[1]);
             if (n_inf == 0) break;
             bool full = true;
@@ -355,6 +380,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 float f = 0.f;
 #pragma unroll
                 for (int cc = 0; cc < KP; ++cc) f = (cc == p) ? m[cc] : f;
+                if (!(pw[p] > NMFX_NNLS_PIVOT_EPS * (G[(int64_t)p * KP + p] + diag_add))) {       // vanished pivot: drop the variable
+                    if (tid == p) { inF = false; dead = true; atomicAdd(&st->nnls_evicted, 1); }
+                    pbuf ^= 1;
+                    continue;
+                }
                 const float inv = 1.f / pw[p];
                 const bool me = tid == p;
 #pragma unroll
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         acc = fmaf(diag_add, x, acc);                    // (G + diag) x; x = 0 for the active variables anyway
         y = (valid && !inF) ? acc : 0.f;
     }
+    if (iter == 8 * KP + 64 && tid == 0) atomicAdd(&st->nnls_capped, 1);
     X[(int64_t)tid * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
 }
 
@@ -394,7 +425,7 @@ template <int KP>
 static int launch_nnls_reg(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
                            int64_t sc, int64_t nprob) {
     hipLaunchKernelGGL((nnls_bpp_reg_kernel<KP>), dim3((unsigned)((nprob + 3) / 4)), dim3(256), 0, E->stream, G, diag_add,
-                       R, X, sj, sc, nprob, E->k, &E->state->flag);
+                       R, X, sj, sc, nprob, E->k, E->state);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -407,7 +438,7 @@ static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const flo
     auto kern = nnls_bpp_kernel<KP>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)((nprob + NW - 1) / NW)), dim3(64 * NW), shm, E->stream, G, diag_add,
-                       R, X, sj, sc, nprob, E->k, &E->state->flag);
+                       R, X, sj, sc, nprob, E->k, E->state);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -426,7 +457,7 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
         default:
             if (lds_only) return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
             hipLaunchKernelGGL(nnls_bpp_reg128_kernel, dim3((unsigned)nprob), dim3(128), 0, E->stream, G, diag_add, R, X, sj,
-                               sc, nprob, E->k, &E->state->flag);
+                               sc, nprob, E->k, E->state);
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
     }
@@ -440,6 +471,9 @@ static bool anls_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_b
 // objective partials of (W, H) (anls.py:118)
 static int anls_objective(nmfx_engine* E) {
     int rc;
+    // distance_type = 'kl' (anls.py:108,118 + utils.py:21-26): the KL objective of the least-squares iterates,
+    // by the exact-f32 objective pass in either arithmetic mode
+    if (E->anls_dist == NMFX_KL) return nmfx_launch_wphase(E, E->W[0], false, true, true);
     if (!anls_bf16(E)) return nmfx_launch_wphase(E, E->W[0], false, true);
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
@@ -531,6 +565,12 @@ extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
     if (E) E->himg_both = false;
     int rc = anls_ready(E, j, lambda_h); if (rc) return rc;
     return anls_h(E, lambda_h);
+}
+
+extern "C" int nmfx_anls_set_distance(nmfx_handle_t E, int distance) {
+    if (!E || (distance != NMFX_EU && distance != NMFX_KL)) { if (E) E->err = "Unknown distance type."; return NMFX_E_ARG; }
+    E->anls_dist = distance;
+    return NMFX_OK;
 }
 
 extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, int64_t min_iter, double tol1,

@@ -31,6 +31,10 @@ struct DevState {          // lives in device memory, written by kernels
     // added to the iteration index a launch carries: lets a captured hipGraph of two outer
     // iterations (indices 0 and 1 baked into its kernel arguments) be replayed for any pair
     long long j_base;
+    // NNLS diagnostics (ANLS): passive variables dropped because their pivot vanished (a dead or collinear
+    // component at lambda = 0: its x stays 0, as in Lawson-Hanson / FCNNLS), solves that hit the iteration cap
+    int nnls_evicted;
+    int nnls_capped;
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };
@@ -90,6 +94,7 @@ struct nmfx_engine {
     // split configuration
     int wsplit = 1, hsplit = 1, gsplit = 1;
     bool have_v = false, have_f = false;
+    int anls_dist = NMFX_EU;       // objective ANLS reports (anls.py:108,118): the iterates are least-squares either way
     int wsel = 0;                  // W buffer holding the current iterate
     bool w_in_place = false;       // solver updates W[0] in place (all but MUR, which ping-pongs)
     // profiling

@@ -214,6 +214,15 @@ class Engine:
                                         float(lam_h), int(min_iter), float(tol1), float(tol2),
                                         int(first), int(count)))
 
+    def anls_set_distance(self, dist):
+        self._ck(self.lib.nmfx_anls_set_distance(self.h, int(dist)))
+
+    def diagnostics(self):
+        """(NNLS variables dropped for a vanished pivot, NNLS solves that hit the iteration cap)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_get_diagnostics(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def anls_run(self, lam_w, lam_h, min_iter, tol1, tol2, first, count):
         self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
                                         float(tol2), int(first), int(count)))

@@ -40,6 +40,9 @@ OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 
 
+ONLY = set()       # --only name[,name...]: regenerate these fixtures only ("functions" = functions.npz)
+
+
 def quiet(fn, *a, **kw):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -98,6 +101,8 @@ def run_solver(method, v, k, seed, kwargs):
 
 
 def solver_case(name, method, vspec, k, seed, kwargs, snaps=(1, 2, 10)):
+    if ONLY and name not in ONLY:
+        return
     v = make_v(vspec)
     v_in = v.copy()
     init = kwargs.get("nndsvd_init", {"mur": (False, "zero")}.get(method, (True, "zero")))
@@ -136,6 +141,12 @@ def solver_case(name, method, vspec, k, seed, kwargs, snaps=(1, 2, 10)):
 
 
 def function_vectors():
+    if ONLY and "functions" not in ONLY:
+        return
+    _function_vectors()
+
+
+def _function_vectors():
     rs = np.random.RandomState(7)
     out = {}
     # distance (utils.py:18-33) incl. zeros in v and in wh
@@ -222,6 +233,13 @@ def function_vectors():
     out["ls_h_out"], out["ls_dual_out"] = hh, dd
     # ADMM aux_update (admm.py:216-230)
     out["aux_eu"] = ref_admm.aux_update(h, du, w, y, None, 1.7, "eu")
+    # cssls (fcnnls.py:14-52): the unconstrained solve, and passive sets with repeated and unique columns
+    ct_c, ct_a = c.T @ c, c.T @ a
+    out["cssls_full"] = ref_fcnnls.cssls(ct_c, ct_a)
+    p_set = np.random.RandomState(77).rand(5, 8) > 0.35
+    p_set[:, 1] = p_set[:, 0]; p_set[:, 5] = p_set[:, 0]; p_set[:, 6] = True
+    out["cssls_pset"] = p_set
+    out["cssls_k"] = ref_fcnnls.cssls(ct_c, ct_a, p_set=p_set)
     np.savez_compressed(os.path.join(OUT, "functions.npz"), **out)
     print("functions.npz", len(out), "arrays")
 
@@ -288,6 +306,8 @@ def main():
     N = dict(kind="planted", rank=4, seed=17, m=64, n=48)
     solver_case("anls_nnls", "anls", N, 4, 18, dict(min_iter=6, max_iter=6), snaps=(1, 2))
     solver_case("anls_fcnnls", "anls", N, 4, 18, dict(min_iter=6, max_iter=6, use_fcnnls=True), snaps=(1, 2))
+    # distance_type='kl': the least-squares iterates with the KL objective reported (anls.py:108,118)
+    solver_case("anls_kl", "anls", N, 4, 18, dict(distance_type="kl", min_iter=6, max_iter=6), snaps=(1, 2))
     solver_case("anls_lambda_random", "anls", dict(kind="uniform", seed=19, m=50, n=40), 5, 19,
                 dict(min_iter=6, max_iter=6, lambda_w=0.1, lambda_h=0.2, nndsvd_init=(False, "zero")),
                 snaps=(1, 2))
@@ -295,4 +315,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--only" in sys.argv:
+        ONLY.update(sys.argv[sys.argv.index("--only") + 1].split(","))
     main()

@@ -412,6 +412,21 @@ def nnls_columns(a, b):
     return out
 
 
+def passive_set_solve(gram, rhs, passive=None):
+    """nmf/fcnnls.py:14-52 (`cssls`): solve gram @ k = rhs for the variables of the passive set of every column (all
+    variables when `passive` is None or all True), zeros elsewhere.  The reference groups columns with equal passive
+    sets and solves each group with one np.linalg.solve; column by column gives the same numbers up to the BLAS's
+    grouping of right-hand sides (pinned by tests/golden/functions.npz: cssls_*)."""
+    out = np.zeros_like(rhs, dtype=np.float64)
+    if passive is None or np.all(passive):
+        return np.linalg.solve(gram, rhs)
+    for j in range(rhs.shape[1]):
+        idx = np.nonzero(passive[:, j])[0]
+        if idx.size:
+            out[idx, j] = np.linalg.solve(gram[np.ix_(idx, idx)], rhs[idx, j])
+    return out
+
+
 def anls_w_step(v, h, lam):
     """nmf/anls.py:18-31: rows of W from the stacked system [h.T; sqrt(2 lam) I]."""
     a = np.concatenate((h.T, math.sqrt(2 * lam) * np.eye(h.shape[0])))

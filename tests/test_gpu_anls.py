@@ -8,7 +8,7 @@ from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["anls_nnls", "anls_fcnnls", "anls_lambda_random"])
+@pytest.mark.parametrize("name", ["anls_nnls", "anls_fcnnls", "anls_lambda_random", "anls_kl"])
 def test_anls_matches_reference(name):
     from nmf_amd.anls import anls
     z, meta, v, res = run_fixture(name, anls)
@@ -57,3 +57,57 @@ def test_anls_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
     assert err < 1e-4, err
     assert res.i == ref.i
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+
+
+@pytest.mark.parametrize("k", [6, 40, 100])
+@pytest.mark.parametrize("case", ["dead", "collinear"])
+def test_anls_rank_deficient_passive_set_at_lambda_zero(k, case):
+    """lambda_w = lambda_h = 0 with a singular Gram matrix on the warm-started passive set: a component
+    whose row of H is zero while its column of W is still positive (dead), or two identical rows of H (collinear).
+    The unguarded 1 / pivot turned the whole right-hand side into NaN and the solve silently returned zeros; scipy's
+    Lawson-Hanson (the oracle) keeps such a variable at zero.  All three NNLS kernel shapes (k padded to 16, 64, 128).
+    dead: the component stays dead in the reference, so the runs are comparable.  collinear: the NNLS minimiser is not
+    unique (only the sum of the two twin variables is determined), the solvers split it differently and the iterates
+    part ways -- asserted instead: everything finite and non-negative, the first W step reproduces the oracle's product
+    W H0, and H is a KKT point for the returned W."""
+    from nmf_amd.engine import Engine
+    from oracle import nmf_ref as R
+    (m, n), iters = {6: (200, 150), 40: (300, 260), 100: (500, 700)}[k], 3
+    v = R.planted_matrix(m, n, k, seed=k, dtype=np.float32)
+    rs = np.random.RandomState(k)
+    w0, h0 = rs.rand(m, k), rs.rand(k, n)
+    if case == "dead":
+        h0[2] = 0.0
+    else:
+        h0[3] = h0[1]
+    with Engine(m, n, k) as eng:
+        eng.upload_v(v)
+        eng.set_factors(w0, h0)
+        eng.anls_set_distance(0)
+        eng.anls_run(0.0, 0.0, 10 ** 9, 1e-3, 1e-3, 0, iters)
+        eng.aoadmm_finish(10 ** 9, 1e-3, 1e-3, iters)
+        w, h = eng.get_factors()
+        _, _, n_obj = eng.state()
+        obj = eng.objectives(0, n_obj)
+        evicted, capped = eng.diagnostics()
+    assert np.isfinite(w).all() and np.isfinite(h).all() and (w >= 0).all() and (h >= 0).all()
+    assert evicted > 0 and capped == 0
+    assert np.isfinite(obj).all() and obj[-1] < obj[0]
+    vd = v.astype(np.float64)
+    if case == "dead":
+        ref = R.anls(vd, k, lambda_w=0, lambda_h=0, min_iter=iters, max_iter=iters, w0=w0, h0=h0)
+        assert wh_error(w, h, ref.w, ref.h, v) < WH_TOL
+        np.testing.assert_allclose(obj, ref.obj_history, rtol=1e-3)
+        assert not w[:, 2].any() and not h[2].any()          # the component stays dead, as in the reference
+    else:
+        y = (w.T @ w) @ h - w.T @ vd                         # duals of the H sub-problem for the returned W
+        scale = np.abs(w.T @ vd).max()
+        assert y[h == 0].min() > -5e-4 * scale and np.abs(y[h > 0]).max() < 5e-4 * scale
+        with Engine(m, n, k) as eng:                         # one W step alone: W1 H0 is unique although W1 is not
+            eng.upload_v(v)
+            eng.set_factors(w0, h0)
+            eng.anls_phase_objective(0)
+            eng.anls_phase_w(0.0, 10 ** 9, 1e-3, 1e-3, 0)
+            w1, _ = eng.get_factors()
+        w1_ref = R.anls_w_step(vd, h0, 0)
+        assert np.linalg.norm(w1 @ h0 - w1_ref @ h0) / np.linalg.norm(vd) < WH_TOL

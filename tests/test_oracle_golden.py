@@ -90,6 +90,11 @@ def test_function_vectors():
     assert close(w, f["nndsvd_random_w"]) and close(h, f["nndsvd_random_h"])
     # NNLS: reference FCNNLS result == per-column Lawson-Hanson to rounding
     assert close(R.nnls_columns(f["fc_c"], f["fc_a"]), f["fc_k"], 1e-9)
+    # cssls (fcnnls.py:14-52): full solve and grouped passive sets
+    ct_c, ct_a = f["fc_c"].T @ f["fc_c"], f["fc_c"].T @ f["fc_a"]
+    assert close(R.passive_set_solve(ct_c, ct_a), f["cssls_full"], 1e-10)
+    assert close(R.passive_set_solve(ct_c, ct_a, f["cssls_pset"]), f["cssls_k"], 1e-10)
+    assert np.all(f["cssls_k"][~f["cssls_pset"]] == 0)
     v, w, h = f["step_v"], f["step_w"], f["step_h"]
     for kind in ("eu", "kl"):
         for lam, tag in ((0.0, "0p0"), (0.3, "0p3")):
