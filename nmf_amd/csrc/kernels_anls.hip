@@ -302,7 +302,7 @@ extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build wit
 // k = 128: two waves per right-hand side (thread = variable), rows in registers, the pivot row
 // handed over through a double-buffered LDS row (one barrier per pivot), the masks of the two
 // waves exchanged through LDS.  Same algorithm as nnls_bpp_reg_kernel.
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) void nnls_bpp_reg128_kernel(
+__device__ __forceinline__ void nnls_bpp_reg128_body(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
     int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
 {
@@ -421,6 +421,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     X[(int64_t)tid * sj + c * sc] = (valid && x > 0.f) ? x : 0.f;
 }
 
+// Two register budgets for the same body: 256 registers (two waves per SIMD; hipcc parks ~40 dwords of the row in
+// scratch) or 512 (one wave per SIMD, no scratch).  NMFX_NNLS128_OCC=1 selects the second; measured in tools/anls_perf.py.
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) void nnls_bpp_reg128_kernel(
+    const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
+{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st); }
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void nnls_bpp_reg128_wide_kernel(
+    const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
+{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st); }
+
 template <int KP>
 static int launch_nnls_reg(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
                            int64_t sc, int64_t nprob) {
@@ -456,8 +467,9 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
                                  : launch_nnls_reg<64>(E, G, diag_add, R, X, sj, sc, nprob);
         default:
             if (lds_only) return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
-            hipLaunchKernelGGL(nnls_bpp_reg128_kernel, dim3((unsigned)nprob), dim3(128), 0, E->stream, G, diag_add, R, X, sj,
-                               sc, nprob, E->k, E->state);
+            { static const bool wide = getenv("NMFX_NNLS128_OCC") && atoi(getenv("NMFX_NNLS128_OCC")) == 1;
+              hipLaunchKernelGGL(wide ? nnls_bpp_reg128_wide_kernel : nnls_bpp_reg128_kernel, dim3((unsigned)nprob), dim3(128), 0,
+                                 E->stream, G, diag_add, R, X, sj, sc, nprob, E->k, E->state); }
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
     }
