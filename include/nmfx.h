@@ -133,7 +133,8 @@ int nmfx_mur_finish_a(nmfx_handle_t h, int distance, int64_t j);
 int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
 
 /* Exchange buffers: f32 part = [W^T V (kp x n_pad) | W^T W (kp x kp)] (+ KL:
- * column sums of W), f64 part = [objective partial, 4 inner-loop norm sums (sharded AO-ADMM), 3 spare].  Sizes in
+ * column sums of W), f64 part = [objective partial, 4 inner-loop norm sums (sharded AO-ADMM, round by round), 3 spare,
+ * 64 x 4 norm sums of the speculative rounds (nmfx_aoadmm_phase_w_fused)].  Sizes in
  * elements.  The caller may supply its own device allocations (e.g. torch
  * tensors, so that torch.distributed can all-reduce them in place).           */
 int nmfx_exchange_sizes(nmfx_handle_t h, int64_t* n_f32, int64_t* n_f64);
@@ -184,6 +185,14 @@ int nmfx_aoadmm_phase_h_solve(nmfx_handle_t h, int prox_h, double lambda_h, int 
 int nmfx_aoadmm_phase_w_products(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_aoadmm_phase_w_round(nmfx_handle_t h, int prox_w, double lambda_w, int round);
 int nmfx_aoadmm_phase_w_close(nmfx_handle_t h, int admm_iter, int64_t j);
+/* The W sub-problem with ONE exchange: nmfx_aoadmm_phase_w_fused runs all admm_iter (<= 64) rounds speculatively on
+ * this rank's rows and leaves its four norm sums of every round in the f64 exchange buffer [8 + 4 round + c];
+ * after the caller's all-reduce of those 4 admm_iter numbers nmfx_aoadmm_phase_w_repair derives the round at which
+ * `terminate` (ao_admm.py:33-43) fires -- the same on every rank -- reruns that many rounds from the saved start if it
+ * is before the last one, records the inner count and leaves the objective partials of the new pair.  Replaces
+ * { phase_w_round . all-reduce } x admm_iter . phase_w_close: 3 collectives per outer iteration instead of 2 + admm_iter. */
+int nmfx_aoadmm_phase_w_fused(nmfx_handle_t h, int prox_w, double lambda_w, int admm_iter);
+int nmfx_aoadmm_phase_w_repair(nmfx_handle_t h, int prox_w, double lambda_w, int admm_iter, int64_t j);
 /* f64 exchange buffer [0] = this rank's objective partial of the current factor pair.        */
 int nmfx_objective_partial(nmfx_handle_t h);
 /* Record the objective / convergence test of the last queued iteration.       */
@@ -208,6 +217,17 @@ int nmfx_prox_apply(nmfx_handle_t h, int side, int prox, double rho, double lamb
 int nmfx_admm_run(nmfx_handle_t h, int distance, double rho, int prox_w, double lambda_w,
                   int prox_h, double lambda_h, int64_t min_iter, double tol1,
                   double tol2, int64_t first, int64_t count);
+/* Row-sharded form.  Per outer iteration j:  phase_products . all-reduce(f32, f64) . phase_update
+ * phase_products leaves this rank's [w_aux^T V | w_aux^T w_aux] (KL loss: w_aux^T (v_aux + dual_v)) and the objective
+ * partial of the current pair in the exchange buffers (j = 0: also the start state of admm.py:27-28, 289);
+ * phase_update records obj[j] / evaluates the stop rule, solves h_aux from the all-reduced sums (replicated work,
+ * admm.py:295), solves this rank's rows of w_aux (admm.py:297), applies both prox operators and dual updates
+ * (admm.py:319-322).  ADMM has no inner loop: this is the only exchange.  After the last iteration:
+ * nmfx_objective_partial . all-reduce(f64) . nmfx_mur_finish_b.  The row-coupled prox 'l1inf' on the W side and
+ * 'l1inf_transpose' on the W side (column 1 of dual_w^T = global row 1) are not available sharded.                   */
+int nmfx_admm_phase_products(nmfx_handle_t h, int distance, double rho, int prox_w, int prox_h, int64_t j);
+int nmfx_admm_phase_update(nmfx_handle_t h, int distance, double rho, int prox_w, double lambda_w,
+                           int prox_h, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 
 /* ---- ANLS (replaces nmf/anls.py:111-122) -------------------------------- */
 /* distance_type of ANLS (nmf/anls.py:108,118): NMFX_EU (default) or NMFX_KL.  It only selects the objective that is

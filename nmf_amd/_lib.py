@@ -52,6 +52,8 @@ SIGNATURES = {
     "nmfx_aoadmm_phase_w_products": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
     "nmfx_aoadmm_phase_w_round": (_i32, [_vp, _i32, _dbl, _i32]),
     "nmfx_aoadmm_phase_w_close": (_i32, [_vp, _i32, _i64]),
+    "nmfx_aoadmm_phase_w_fused": (_i32, [_vp, _i32, _dbl, _i32]),
+    "nmfx_aoadmm_phase_w_repair": (_i32, [_vp, _i32, _dbl, _i32, _i64]),
     "nmfx_objective_partial": (_i32, [_vp]),
     "nmfx_anls_phase_objective": (_i32, [_vp, _i64]),
     "nmfx_anls_phase_w": (_i32, [_vp, _dbl, _i64, _dbl, _dbl, _i64]),
@@ -66,6 +68,8 @@ SIGNATURES = {
     "nmfx_get_inner_counts": (_i32, [_vp, _i64, _i64, _vp]),
     "nmfx_set_l2n_operator": (_i32, [_vp, _i32, _vp]),
     "nmfx_admm_run": (_i32, [_vp, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_admm_phase_products": (_i32, [_vp, _i32, _dbl, _i32, _i32, _i64]),
+    "nmfx_admm_phase_update": (_i32, [_vp, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i64, _dbl, _dbl, _i64]),
     "nmfx_anls_set_distance": (_i32, [_vp, _i32]),
     "nmfx_anls_run": (_i32, [_vp, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_get_diagnostics": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -153,7 +153,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));
     TRY(dev_alloc(E, &E->obj_part, std::max<int64_t>(rb * ws, cb * hs) + 64));
     TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp));
-    TRY(dev_alloc(E, &E->xf64, 8));
+    TRY(dev_alloc(E, &E->xf64, 8 + 4 * NMFX_MAX_FUSED_ROUNDS));
     TRY(dev_alloc(E, &E->state, 1));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
     TRY(nmfx_ensure_obj_capacity(E, 4096));
@@ -421,7 +421,7 @@ int nmfx_get_inner_counts(nmfx_handle_t E, int64_t first, int64_t count, int32_t
 int nmfx_exchange_sizes(nmfx_handle_t E, int64_t* n_f32, int64_t* n_f64) {
     if (!E) return NMFX_E_ARG;
     if (n_f32) *n_f32 = (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp;
-    if (n_f64) *n_f64 = 8;
+    if (n_f64) *n_f64 = 8 + 4 * NMFX_MAX_FUSED_ROUNDS;
     return NMFX_OK;
 }
 

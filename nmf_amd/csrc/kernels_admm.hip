@@ -45,13 +45,11 @@ static int admm_objective(nmfx_engine* E) {
     return nmfx_bf16_objective(E, 1, "objective");
 }
 
-static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
-                             int64_t min_iter, double tol1, double tol2, int64_t j) {
+// first half of an iteration: this rank's [w_aux^T V | w_aux^T w_aux | objective partial] into the exchange buffers
+// (row-sharded runs all-reduce them here)
+static int admm_eu_products(nmfx_engine* E) {
     int rc;
-    float* W = E->W[0];
-    const int64_t kk = (int64_t)E->kp * E->kp;
     const bool bf = admm_bf16(E);
-    // ---- h_aux and the H half ----
     if (bf) {       // w_aux^T V and w_aux^T w_aux on the split-bf16 kernel (kp = 64: the Gram is its by-product)
         const int64_t nobj = E->obj_count;             // the objective pass that ended the previous iteration
         if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;
@@ -68,6 +66,16 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     if ((rc = nmfx_launch_hphase(E, E->auxW, fuse_g))) return rc;
     if ((rc = nmfx_launch_pack(E))) return rc;
     }
+    return NMFX_OK;
+}
+
+static int admm_eu_update(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                          int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const bool bf = admm_bf16(E);
+    // ---- h_aux and the H half ----
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
     { ProfScope ps(E, "inner_h");
       if (prox_h == NMFX_PROX_L2N) {
@@ -106,17 +114,28 @@ static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     return admm_objective(E);
 }
 
-// KL loss (admm.py:303-315): the Gram right-hand sides multiply S = v_aux + dual_v, and
-// v_aux / dual_v are refreshed from w_aux @ h_aux at the end of the iteration.
-static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+static int admm_eu_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
                              int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
-    float* W = E->W[0];
-    const int64_t kk = (int64_t)E->kp * E->kp;
+    if ((rc = admm_eu_products(E))) return rc;
+    return admm_eu_update(E, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j);
+}
+
+// KL loss (admm.py:303-315): the Gram right-hand sides multiply S = v_aux + dual_v, and
+// v_aux / dual_v are refreshed from w_aux @ h_aux at the end of the iteration.
+static int admm_kl_products(nmfx_engine* E) {
+    int rc;
     const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
     if (!fuse_g && (rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_hphase(E, E->auxW, fuse_g, E->S))) return rc;
-    if ((rc = nmfx_launch_pack(E))) return rc;
+    return nmfx_launch_pack(E);
+}
+
+static int admm_kl_update(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                          int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
     if (prox_h == NMFX_PROX_L2N) {
         if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
@@ -139,6 +158,13 @@ static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc;
     if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->auxH))) return rc;
     return nmfx_launch_wphase(E, W, false, true, true);
+}
+
+static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                             int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    if ((rc = admm_kl_products(E))) return rc;
+    return admm_kl_update(E, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j);
 }
 
 extern "C" int nmfx_set_l2n_operator(nmfx_handle_t E, int which, const double* p) {
@@ -168,16 +194,18 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
     return nmfx_launch_prox_l1inf(E, side == 1, prox == NMFX_PROX_L1INF_T, rho, lambda, 1.0, update_dual != 0);
 }
 
-extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
-                             double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
-                             int64_t count) {
+// argument checks, allocations and (for the first iteration) the start state w_aux = w, h_aux = h (admm.py:27-28)
+// with the objective partials of the initial pair (admm.py:289)
+static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count) {
     if (!E) return NMFX_E_ARG;
     E->himg_both = false;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
     auto bad = [](int p) { return p != NMFX_PROX_NN && p != NMFX_PROX_L1N && p != NMFX_PROX_L2N && p != NMFX_PROX_L1INF && p != NMFX_PROX_L1INF_T; };
     if (bad(prox_w) || bad(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
-    if (first < 0 || count < 0 || !(rho > 0.0)) { E->err = "bad range or rho"; return NMFX_E_ARG; }
+    // rho = 0 is a plain Gram solve in the reference (np.linalg.solve, admm.py:230); negative values make the shifted
+    // system indefinite -- the elimination then reports "not positive definite" like any singular system
+    if (first < 0 || count < 0 || !(rho >= 0.0)) { E->err = "negative iteration range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
     if ((rc = admm_alloc(E))) return rc;
@@ -188,7 +216,6 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
     E->wsel = 0;
     E->w_in_place = true;
     if (first == 0 && count > 0) {
-        // w_aux = w, h_aux = h (admm.py:27-28); obj[0] (admm.py:289)
         NMFX_HIP(hipMemcpyAsync(E->auxW, E->W[0], (size_t)E->mp * E->kp * 4, hipMemcpyDeviceToDevice, E->stream));
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
         if (distance == NMFX_EU) rc = admm_objective(E);
@@ -196,6 +223,30 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
         if (rc) return rc;
     }
     if (distance == NMFX_EU && admm_bf16(E) && (rc = nmfx_bf16_prepare(E))) return rc;
+    return NMFX_OK;
+}
+
+// ---- row-sharded form: phase_products -> [all-reduce f32 + f64] -> phase_update (the H half is replicated work on the
+// all-reduced sums, the W half is local to the rank's rows; ADMM has no inner loop, so this is the only exchange) ----
+extern "C" int nmfx_admm_phase_products(nmfx_handle_t E, int distance, double rho, int prox_w, int prox_h, int64_t j) {
+    int rc = admm_begin(E, distance, rho, prox_w, prox_h, j, 1); if (rc) return rc;
+    return distance == NMFX_EU ? admm_eu_products(E) : admm_kl_products(E);
+}
+
+extern "C" int nmfx_admm_phase_update(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
+                                      double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
+    if (!E->auxH || j < 0) { E->err = "admm_phase_update: call nmfx_admm_phase_products first"; return NMFX_E_STATE; }
+    NMFX_HIP(hipSetDevice(E->device));
+    return distance == NMFX_EU ? admm_eu_update(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)
+                               : admm_kl_update(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
+}
+
+extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
+                             double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
+                             int64_t count) {
+    int rc = admm_begin(E, distance, rho, prox_w, prox_h, first, count); if (rc) return rc;
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)

@@ -760,7 +760,8 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     const float* __restrict__ Asum, int asplit, int64_t astride,     // right-hand side = sum of asplit slabs (slab order)
     float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
-    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot)
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot,
+    const double* __restrict__ decide_tab)             // row-sharded runs: the ALL-REDUCED norm sums [admm_iter][4]
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -774,7 +775,8 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     int rounds = admm_iter;
     if (repair) {
         int fired;
-        rounds = fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
+        rounds = decide_tab ? fused_decide(decide_tab, 1, admm_iter, sh, &fired)
+                            : fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
         if (blockIdx.x == 0 && tid == 0) { st->inner_count = rounds; st->inner_stop = 0; *slot = rounds | (fired << 16); }
         if (rounds >= admm_iter) return;
     }
@@ -1081,7 +1083,8 @@ static int ao_fused_rows_rb(const nmfx_engine* E) {
 }
 
 template <int KP, int RB>
-static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
+                               const double* decide_tab) {
     const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP, RB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
@@ -1089,16 +1092,41 @@ static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, i
     const bool slabs = E->ao_a_slabs > 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / RB)), dim3(RB * 4), shm, E->stream, slabs ? E->A_part : E->auxW,
                        slabs ? E->ao_a_slabs : 1, (int64_t)E->mp * E->kp, W, E->dualW, E->bkX, E->bkU,
-                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
+                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot, decide_tab);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 template <int KP>
-static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
+                             const double* decide_tab = nullptr) {
     if constexpr (KP >= 64) {
-        if (ao_fused_rows_rb(E) == 128) return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, repair, slot);
+        if (ao_fused_rows_rb(E) == 128) return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
     }
-    return launch_fused_rows_rb<KP, 64>(E, W, prox, lam, admm_iter, repair, slot);
+    return launch_fused_rows_rb<KP, 64>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+}
+static int fused_rows_any(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
+                          const double* decide_tab = nullptr) {
+    switch (E->kp) {
+        case 16: return launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+        case 32: return launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+        case 64: return launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+        default: return launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+    }
+}
+
+// this rank's norm sums of every speculative round, nrm_rounds[round][block][4] -> out[round][4] (fixed order)
+__global__ __launch_bounds__(256) void nrm_table_kernel(const double* __restrict__ nrm_rounds, int nblk, int admm_iter,
+                                                        double* __restrict__ out, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // wave = component
+    for (int r = 0; r < admm_iter; ++r) {
+        double s = 0.0;
+        for (int b = lane; b < nblk; b += 64) s += nrm_rounds[((int64_t)r * nblk + b) * 4 + wave];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) out[r * 4 + wave] = s;
+    }
 }
 
 static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, float lam, int admm_iter, int32_t* slot) {
@@ -1113,12 +1141,7 @@ static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, fl
                 default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, repair, slot); break;
             }
         } else {
-            switch (E->kp) {
-                case 16: rc = launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair, slot); break;
-                case 32: rc = launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair, slot); break;
-                case 64: rc = launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair, slot); break;
-                default: rc = launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair, slot); break;
-            }
+            rc = fused_rows_any(E, W, prox, lam, admm_iter, repair, slot);
         }
         if (rc) return rc;
     }
@@ -1297,6 +1320,36 @@ extern "C" int nmfx_aoadmm_phase_w_round(nmfx_handle_t E, int prox_w, double lam
 extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
     int rc = ao_sharded_ready(E, j); if (rc) return rc;
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
+    return ao_new_pair_objective(E);
+}
+
+// Row-sharded W sub-problem with ONE exchange instead of one per round: all admm_iter rounds run speculatively on
+// this rank's rows (ao_fused_rows_kernel) and the four norm sums of every round go to the f64 exchange buffer
+// [8 + 4 round + component]; after the caller's all-reduce of that table nmfx_aoadmm_phase_w_repair finds the round at
+// which the reference's `terminate` (ao_admm.py:33-43, norms over ALL rows of W) would have stopped and, if that is
+// before the last one, reruns exactly that many rounds from the saved start -- what the single-GPU path does with
+// its block partials.  admm_iter <= NMFX_MAX_FUSED_ROUNDS (64).
+extern "C" int nmfx_aoadmm_phase_w_fused(nmfx_handle_t E, int prox_w, double lambda_w, int admm_iter) {
+    if (!E) return NMFX_E_ARG;
+    if (prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (admm_iter < 1 || admm_iter > NMFX_MAX_FUSED_ROUNDS) { E->err = "phase_w_fused: admm_iter out of range"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = ao_fused_alloc(E, admm_iter))) return rc;
+    ProfScope ps(E, "inner_w");
+    if ((rc = fused_rows_any(E, E->W[0], prox_w, (float)lambda_w, admm_iter, 0, nullptr))) return rc;
+    const int nblk = (int)(E->mp / ao_fused_rows_rb(E));
+    hipLaunchKernelGGL(nrm_table_kernel, dim3(1), dim3(256), 0, E->stream, E->nrm_rounds, nblk, admm_iter, E->xf64 + 8,
+                       &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_aoadmm_phase_w_repair(nmfx_handle_t E, int prox_w, double lambda_w, int admm_iter, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    if (admm_iter < 1 || admm_iter > NMFX_MAX_FUSED_ROUNDS) { E->err = "phase_w_repair: admm_iter out of range"; return NMFX_E_ARG; }
+    { ProfScope ps(E, "inner_w");
+      if ((rc = fused_rows_any(E, E->W[0], prox_w, (float)lambda_w, admm_iter, 1, E->inner_hist + j * 2 + 1, E->xf64 + 8))) return rc; }
     return ao_new_pair_objective(E);
 }
 

@@ -15,6 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // and the factor rank is padded to KP in {16, 32, 64, 128}.  Zero padding is a
 // fixed point of every update rule implemented here ("padding").
 #define NMFX_TILE 64
+#define NMFX_MAX_FUSED_ROUNDS 64     // rows of the norm table in the f64 exchange buffer (sharded fused W sub-problem)
 
 struct DevState {          // lives in device memory, written by kernels
     int flag;              // 0 running, 1/2 = convergence_check branch (utils.py:8-11)

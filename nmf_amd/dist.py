@@ -4,7 +4,9 @@ Rank p holds the rows [r0, r1) of V and of W; H (k x n) and H H^T are
 replicated.  The W update is row-local (nmf/mur.py:29: row i of W depends only
 on row i of V).  The H update (nmf/mur.py:45) needs W^T V = sum_p W_p^T V_p and
 W^T W = sum_p W_p^T W_p: ONE sum-all-reduce per outer iteration of the packed
-f32 buffer [W^T V | W^T W] (k*n + k*k elements) plus the f64 objective partial.
+f32 buffer [W^T V | W^T W] (k*n + k*k elements), followed on the same stream by
+the 64-byte f64 all-reduce of the objective partial (torch cannot coalesce two
+dtypes into one RCCL group).
 Every rank then applies the identical H update, so no broadcast is needed and
 the device-side stop flag agrees on all ranks.
 
@@ -35,25 +37,42 @@ class TorchComm:
     share ONE GPU in tests where RCCL refuses duplicate devices."""
 
     def __init__(self, group=None, stage_through_host=False):
+        import inspect
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.stage = stage_through_host
-        self._coalesce = hasattr(dist, "_coalescing_manager")
+        # One RCCL group launch for several reductions of one dtype (ncclGroupStart / End) through torch's coalescing
+        # manager.  It is a private API: its presence and keywords are probed ONCE here -- identically on every rank,
+        # they run the same torch -- and the mode then stays fixed for the run.  (Falling back in the middle of a call
+        # could reduce a tensor twice, or desynchronise the collective sequence between ranks.)
+        mgr = getattr(dist, "_coalescing_manager", None)
+        self._coalesce = False
+        if mgr is not None and not stage_through_host and dist.get_backend(group) == "nccl":
+            try:
+                params = inspect.signature(mgr).parameters
+                self._coalesce = all(name in params for name in ("group", "device", "async_ops"))
+            except (TypeError, ValueError):
+                self._coalesce = False
 
     def all_reduce(self, *tensors):
-        # RCCL: put the f32 and the f64 reduction into ONE group launch (ncclGroupStart/End)
-        # -- one host call and one kernel instead of two per outer iteration.
-        if len(tensors) > 1 and not self.stage and all(t.is_cuda for t in tensors) and self._coalesce:
-            try:
-                with self.dist._coalescing_manager(group=self.group, device=tensors[0].device, async_ops=False):
-                    for t in tensors:
-                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-                return
-            except Exception:      # noqa: BLE001  (private torch API: fall back for good)
-                self._coalesce = False
+        # torch coalesces tensors of ONE dtype only (allreduce_coalesced: "Tensors must have identical type"): the f32
+        # products and the f64 objective partial therefore travel as two collectives, back to back on the stream.
+        # (Round 1 wrapped the mixed call in try/except and never noticed that it always fell back.)
+        if self._coalesce and len(tensors) > 1 and all(t.is_cuda for t in tensors):
+            by_type = {}
+            for t in tensors:
+                by_type.setdefault(t.dtype, []).append(t)
+            for group in by_type.values():
+                if len(group) > 1:
+                    with self.dist._coalescing_manager(group=self.group, device=group[0].device, async_ops=False):
+                        for t in group:
+                            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                else:
+                    self.dist.all_reduce(group[0], op=self.dist.ReduceOp.SUM, group=self.group)
+            return
         for t in tensors:
             if self.stage and t.is_cuda:
                 import torch
@@ -119,6 +138,24 @@ class DeviceShard:
     def ao_w_close(self, admm_iter, j):
         self.eng.aoadmm_phase_w_close(admm_iter, j)
 
+    def ao_w_fused(self, prox_w, lam_w, admm_iter):
+        self.eng.aoadmm_phase_w_fused(prox_w, lam_w, admm_iter)
+
+    def ao_w_repair(self, prox_w, lam_w, admm_iter, j):
+        self.eng.aoadmm_phase_w_repair(prox_w, lam_w, admm_iter, j)
+
+    def admm_products(self, dist_code, rho, prox_w, prox_h, j):
+        self.eng.admm_phase_products(dist_code, rho, prox_w, prox_h, j)
+
+    def admm_update(self, dist_code, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j):
+        self.eng.admm_phase_update(dist_code, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j)
+
+    def set_l2n_operator(self, which, p):
+        self.eng.set_l2n_operator(which, p)
+
+    def anls_set_distance(self, dist_code):
+        self.eng.anls_set_distance(dist_code)
+
     def objective_partial(self):
         self.eng.objective_partial()
 
@@ -147,9 +184,14 @@ class DeviceShard:
         self.eng.close()
 
 
+def _mur_buffers(shard):
+    x32, x64 = shard.buffers()
+    return x32, x64[:8]            # (the tail of the f64 buffer is the norm table of sharded AO-ADMM)
+
+
 def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
     """Queue `count` sharded outer iterations (no host sync)."""
-    bufs = shard.buffers()
+    bufs = _mur_buffers(shard)
     for j in range(first, first + count):
         shard.phase_a(dist_code, lambda_w, j)
         comm.all_reduce(*bufs)
@@ -174,7 +216,7 @@ class GraphedIterations:
         self.shard, self.torch = shard, torch
         self.args = (dist_code, lambda_w, lambda_h, min_iter, tol1, tol2)
         self.graph = torch.cuda.CUDAGraph()
-        bufs = shard.buffers()
+        bufs = _mur_buffers(shard)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
@@ -266,7 +308,7 @@ class Runner:
 
 def finish(shard, comm, dist_code, min_iter, tol1, tol2, done):
     shard.finish_a(dist_code, done)
-    comm.all_reduce(shard.buffers()[1])
+    comm.all_reduce(_mur_buffers(shard)[1])
     shard.finish_b(min_iter, tol1, tol2, done)
 
 
@@ -331,68 +373,280 @@ def _sharded_loop(shard, comm, queue, finish_run, *, max_iter, tol1, tol2, batch
 
 
 def _prox_code(kind):
-    from . import _lib as L
-    if kind in ('nn', 'l1n'):
-        return L.PROX[kind]
-    if kind in ('l2n', 'l1inf', 'l1inf_transpose'):
-        raise NotImplementedError(f"prox '{kind}' is not available in the row-sharded AO-ADMM")
-    raise TypeError('Unknown prox_type.')                       # nmf/ao_admm.py:198
+    from .ao_admm import _prox_code as single        # same codes and the reference's errors ('l2n': ValueError, 'l1inf*': LinAlgError)
+    return single(kind)
+
+
+MAX_FUSED_ROUNDS = 64         # rows of the norm table in the engine's f64 exchange buffer
 
 
 def aoadmm_sharded(shard, comm, *, reg_w=(0, 'nn'), reg_h=(0, 'nn'), min_iter=10, max_iter=100000,
-                   admm_iter=10, tol1=1e-3, tol2=1e-3, batch=4, experiment=None):
+                   admm_iter=10, tol1=1e-3, tol2=1e-3, batch=4, experiment=None, fused=None):
     """AO-ADMM, Euclidean loss (nmf/ao_admm.py:259-301), over a row-sharded V.
 
     H sub-problem (ao_admm.py:263): [W^T V | W^T W | objective] is all-reduced once, the Cholesky
     solve / prox / dual rounds are then replicated work.  W sub-problem (ao_admm.py:265): rank-local
-    rows, except that `terminate` (ao_admm.py:33-43) takes norms over the whole factor: the four
-    sums of squares of every round are all-reduced (32 bytes), so all ranks stop at the same
-    round, as the reference would.  Returns Results with THIS rank's rows of w."""
+    rows, except that `terminate` (ao_admm.py:33-43) takes norms over the whole factor: all rounds run
+    speculatively, the [admm_iter x 4] table of their sums of squares is all-reduced ONCE and every rank
+    derives the same stopping round from it and repairs its rows if that round is not the last
+    (nmfx_aoadmm_phase_w_fused / _repair; 3 collectives per outer iteration).  Returns Results with THIS
+    rank's rows of w."""
     prox_h, prox_w = _prox_code(reg_h[1]), _prox_code(reg_w[1])     # H's regulariser is met first
     x32, x64 = shard.buffers()
     norms = x64[1:5]
+    # ONE exchange for the whole W sub-problem where the shard can run its rounds speculatively (the HIP engine, for
+    # 2 <= admm_iter <= 64): the [admm_iter x 4] table of norm sums.  `fused=False` keeps one exchange per round.
+    if fused is None:
+        fused = hasattr(shard, "ao_w_fused") and 2 <= admm_iter <= MAX_FUSED_ROUNDS
+    table = x64[8:8 + 4 * admm_iter] if fused else None
 
     def queue(first, count):
         for j in range(first, first + count):
             shard.ao_h_products(j)
-            comm.all_reduce(x32, x64)
+            comm.all_reduce(x32, x64[:8])
             shard.ao_h_solve(prox_h, reg_h[0], admm_iter, min_iter, tol1, tol2, j)
             shard.ao_w_products(min_iter, tol1, tol2, j)
-            for rnd in range(admm_iter):
-                shard.ao_w_round(prox_w, reg_w[0], rnd)
-                comm.all_reduce(norms)
-            shard.ao_w_close(admm_iter, j)
+            if fused:
+                shard.ao_w_fused(prox_w, reg_w[0], admm_iter)
+                comm.all_reduce(table)
+                shard.ao_w_repair(prox_w, reg_w[0], admm_iter, j)
+            else:
+                for rnd in range(admm_iter):
+                    shard.ao_w_round(prox_w, reg_w[0], rnd)
+                    comm.all_reduce(norms)
+                shard.ao_w_close(admm_iter, j)
 
     def finish_run(done):
         shard.objective_partial()
-        comm.all_reduce(x64)
+        comm.all_reduce(x64[:8])
         shard.finish_b(min_iter, tol1, tol2, done)
 
     return _sharded_loop(shard, comm, queue, finish_run, max_iter=max_iter, tol1=tol1, tol2=tol2,
                          batch=batch, experiment=experiment)
 
 
-def anls_sharded(shard, comm, *, lambda_w=0, lambda_h=0, min_iter=10, max_iter=1000, tol1=1e-3, tol2=1e-3,
-                 batch=4, experiment=None):
+def admm_sharded(shard, comm, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'nn'), min_iter=10,
+                 max_iter=100000, tol1=1e-3, tol2=1e-3, batch=8, experiment=None):
+    """ADMM (nmf/admm.py:292-334), Euclidean or KL loss, over a row-sharded V: h_aux solves the shifted Gram system of
+    sum_p w_aux_p^T w_aux_p with the right-hand side sum_p w_aux_p^T V_p (KL: V replaced by v_aux + dual_v, whose rows
+    are rank-local) -- ONE all-reduce per outer iteration, then replicated work; w_aux, both prox operators and the
+    dual updates are row-local.  reg_h may be any of 'nn', 'l1n', 'l2n', 'l1inf', 'l1inf_transpose' (replicated);
+    reg_w 'nn', 'l1n', 'l2n' (the l1inf operators couple all rows of W).  Returns Results with THIS rank's rows of w."""
+    from . import _lib as L
+    from .admm import l2n_operator
+    if distance_type not in ('eu', 'kl'):
+        raise KeyError('Distance type unknown: use "kl" or "eu"')
+    for kind in (reg_h[1], reg_w[1]):
+        if kind not in L.PROX:
+            raise TypeError('Unknown prox_type.')               # nmf/admm.py:213
+    if reg_w[1] in ('l1inf', 'l1inf_transpose'):
+        raise NotImplementedError(f"prox '{reg_w[1]}' on W couples all rows and is not available row-sharded")
+    code = 0 if distance_type == 'eu' else 1
+    prox_h, prox_w = L.PROX[reg_h[1]], L.PROX[reg_w[1]]
+    k = shard.get_factors()[1].shape[0]
+    if reg_w[1] == 'l2n':
+        shard.set_l2n_operator(0, l2n_operator(k, rho, reg_w[0]))
+    if reg_h[1] == 'l2n':
+        shard.set_l2n_operator(1, l2n_operator(k, rho, reg_h[0]))
+    x32, x64 = shard.buffers()
+
+    def queue(first, count):
+        for j in range(first, first + count):
+            shard.admm_products(code, rho, prox_w, prox_h, j)
+            comm.all_reduce(x32, x64[:8])
+            shard.admm_update(code, rho, prox_w, reg_w[0], prox_h, reg_h[0], min_iter, tol1, tol2, j)
+
+    def finish_run(done):
+        shard.objective_partial()
+        comm.all_reduce(x64[:8])
+        shard.finish_b(min_iter, tol1, tol2, done)
+
+    return _sharded_loop(shard, comm, queue, finish_run, max_iter=max_iter, tol1=tol1, tol2=tol2,
+                         batch=batch, experiment=experiment)
+
+
+def anls_sharded(shard, comm, *, distance_type='eu', lambda_w=0, lambda_h=0, min_iter=10, max_iter=1000, tol1=1e-3,
+                 tol2=1e-3, batch=4, experiment=None):
     """ANLS (nmf/anls.py:112-126) over a row-sharded V: the rows of W are independent NNLS
     problems (anls.py:18-31, rank-local), the columns of H need sum_p W_p^T W_p and
     sum_p W_p^T V_p (anls.py:34-47; replicated solve after one all-reduce).  The objective
     partial is all-reduced separately because the stop rule is evaluated BEFORE the updates of
     the iteration are queued.  Returns Results with THIS rank's rows of w."""
+    if distance_type not in ('eu', 'kl'):
+        raise KeyError('Distance type unknown: use "kl" or "eu"')
+    if hasattr(shard, "anls_set_distance"):
+        shard.anls_set_distance(0 if distance_type == 'eu' else 1)
+    elif distance_type != 'eu':
+        raise NotImplementedError("this shard type reports the Euclidean objective only")
     x32, x64 = shard.buffers()
 
     def queue(first, count):
         for j in range(first, first + count):
             shard.anls_objective(j)
-            comm.all_reduce(x64)
+            comm.all_reduce(x64[:8])
             shard.anls_w(lambda_w, min_iter, tol1, tol2, j)
             comm.all_reduce(x32)
             shard.anls_h(lambda_h, j)
 
     def finish_run(done):
         shard.objective_partial()
-        comm.all_reduce(x64)
+        comm.all_reduce(x64[:8])
         shard.finish_b(min_iter, tol1, tol2, done)
 
     return _sharded_loop(shard, comm, queue, finish_run, max_iter=max_iter, tol1=tol1, tol2=tol2,
                          batch=batch, experiment=experiment)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's call surface for a matrix sharded over the GPUs of one node
+# ---------------------------------------------------------------------------------------------------------------------
+_SOLVERS = {'mur': mur_sharded, 'ao_admm': aoadmm_sharded, 'admm': admm_sharded, 'anls': anls_sharded}
+
+
+def _defaults(method):
+    """Keyword defaults and the Experiment tuple of the single-GPU solver with the same name (= the reference's)."""
+    import inspect
+    from importlib import import_module
+    mod = import_module('.' + method, __package__)
+    sig = inspect.signature(getattr(mod, method))
+    kw = {name: p.default for name, p in sig.parameters.items()
+          if p.kind is p.KEYWORD_ONLY and name not in ('device', 'engine', 'save_dir')}
+    return mod, kw
+
+
+def _experiment(mod, method, k, kw):
+    if method == 'mur':
+        return mod.Experiment('mur', k, kw['distance_type'], kw['nndsvd_init'], kw['max_iter'], kw['tol1'], kw['tol2'],
+                              kw['lambda_w'], kw['lambda_h'])
+    if method == 'anls':
+        return mod.Experiment('anls', k, kw['distance_type'], kw['nndsvd_init'], kw['max_iter'], kw['tol1'], kw['tol2'],
+                              kw['lambda_w'], kw['lambda_h'], kw['use_fcnnls'])
+    if method == 'admm':
+        return mod.Experiment('admm', k, kw['rho'], kw['distance_type'], kw['nndsvd_init'], kw['min_iter'], kw['max_iter'],
+                              kw['tol1'], kw['tol2'], kw['reg_w'][0], kw['reg_w'][1], kw['reg_h'][0], kw['reg_h'][1])
+    return mod.Experiment('ao_admm', k, kw['distance_type'], kw['nndsvd_init'], kw['min_iter'], kw['max_iter'],
+                          kw['admm_iter'], kw['tol1'], kw['tol2'], kw['reg_w'][0], kw['reg_w'][1], kw['reg_h'][0],
+                          kw['reg_h'][1])
+
+
+def init_process_group(backend=None):
+    """Join the torch.distributed job this process was started in (torchrun / torch.distributed.run sets RANK,
+    WORLD_SIZE, LOCAL_RANK, MASTER_*): "nccl" (= RCCL over xGMI) with one GPU per rank by default.  Call it -- or
+    `factorize`, which calls it -- BEFORE anything touches a GPU.  Returns (rank, world, local_rank)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist.get_rank(), dist.get_world_size(), local
+
+
+def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, shard_factory=None, **method_params):
+    """`NMF(data, k).factorize(method=...)` of the reference (nmf/nmf.py:48) for a matrix whose rows are sharded over
+    the GPUs of one node -- north_star's "V too large for one GPU".  SPMD: every rank of a torch.distributed job calls
+    it with the same arguments,
+
+        torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 my_script.py
+            np.random.seed(0)                                  # the SAME seed on every rank (reference: global numpy RNG)
+            res = nmf_amd.dist.factorize(np.load('v.npy', mmap_mode='r'), 64, method='mur', distance_type='eu')
+
+    `data`: the full m x n array on every rank (a read-only np.memmap is enough: rank p only reads its rows
+    [m p / P, m (p + 1) / P), plus all of it on rank 0 when an NNDSVD start is asked for).  Keyword arguments and
+    their defaults are those of the reference's solver function of that name (nmf/mur.py:52, nmf/anls.py:50,
+    nmf/admm.py:233, nmf/ao_admm.py:201).  Returns the reference's Results(w, h, i, obj_history, experiment): with
+    gather=True `w` is the full m x k factor on rank 0 (its own row block on the other ranks), h / i / obj_history are
+    identical everywhere.  Exchange per outer iteration: one RCCL all-reduce of [W^T V | W^T W] (+ objective) -- MUR,
+    ADMM, ANLS -- or three (AO-ADMM: + the H products' objective, the norm table of the W sub-problem).
+
+    Not available sharded (NotImplementedError): AO-ADMM with the KL loss, prox 'l1inf*' on W.  The in-place lift of
+    negative data (nmf/mur.py:99-101) is applied to a private copy of the rank's rows when `data` is not writeable."""
+    import torch
+    import torch.distributed as tdist
+    if method not in _SOLVERS:
+        raise Exception('Method not known. Choose one from: mur anls admm ao_admm')      # nmf/nmf.py:76
+    rank, world, local = init_process_group(backend)
+    mod, kw = _defaults(method)
+    unknown = set(method_params) - set(kw)
+    if unknown:
+        raise TypeError(f"{method}() got an unexpected keyword argument '{sorted(unknown)[0]}'")
+    kw.update(method_params)
+    if method == 'ao_admm' and kw['distance_type'] == 'kl':
+        raise NotImplementedError('AO-ADMM with the KL loss is not available row-sharded (its H sub-problem exchanges '
+                                  'a k x n product in every inner round)')
+    experiment = _experiment(mod, method, k, kw)
+    m, n = data.shape
+    if world > m:
+        raise ValueError('more ranks than rows')
+    r0, r1 = row_range(m, rank, world)
+    on_gpu = tdist.get_backend() == "nccl"
+    dev = torch.device(f"cuda:{local if device is None else device}") if on_gpu else torch.device("cpu")
+    comm = TorchComm(stage_through_host=(shard_factory is None and not on_gpu))
+    v_local = data[r0:r1]
+    if method == 'mur':                                       # nmf/mur.py:99-101, with the minimum over ALL ranks' rows
+        low = torch.tensor([float(np.min(v_local))], dtype=torch.float64, device=dev)
+        tdist.all_reduce(low, op=tdist.ReduceOp.MIN)
+        if float(low) < 0:
+            if not (isinstance(v_local, np.ndarray) and v_local.flags.writeable):
+                v_local = np.array(v_local)
+            v_local += abs(float(low))
+            logging.info('Data elevated by {}.'.format(abs(float(low))))
+    # initial factors, in the reference's RNG order; NNDSVD from rank 0's view of the whole matrix
+    nndsvd_init = kw['nndsvd_init']
+    if nndsvd_init[0]:
+        if rank == 0:
+            full = np.asarray(data)
+            if method == 'mur' and float(low) < 0:             # (the lifted matrix, as the reference's nndsvd would see it)
+                full = full + abs(float(low))
+            if utils.nndsvd_on_device(full, k) and shard_factory is None:
+                from .engine import Engine
+                with Engine(m, n, k, device=dev.index or 0) as tmp:
+                    tmp.upload_v(full)
+                    w0, h0 = utils.nndsvd_device(tmp, full, k, variant=nndsvd_init[1])
+            else:
+                w0, h0 = utils.nndsvd(np.asarray(full, dtype=np.float64), k, variant=nndsvd_init[1])
+            w0, h0 = np.ascontiguousarray(w0), np.ascontiguousarray(h0)
+        else:
+            w0, h0 = np.empty((m, k)), np.empty((k, n))
+        for a in (w0, h0):
+            t = torch.from_numpy(a).to(dev)
+            tdist.broadcast(t, src=0)
+            a[...] = t.cpu().numpy()
+    else:
+        w0, h0 = utils.initial_factors(_Shape(m, n), k, nndsvd_init, uniform=(method == 'anls'))
+    make = shard_factory or (lambda v, kk, w, h: DeviceShard(v, kk, w, h, dev.index or 0))
+    shard = make(v_local, k, w0[r0:r1], h0)
+    run_kw = {key: val for key, val in kw.items()
+              if key not in ('nndsvd_init', 'use_fcnnls') and not (method == 'ao_admm' and key == 'distance_type')}
+    try:
+        res = _SOLVERS[method](shard, comm, experiment=experiment, **run_kw)
+        w = res.w
+        if gather and world > 1:
+            rows = max(row_range(m, p, world)[1] - row_range(m, p, world)[0] for p in range(world))
+            mine = torch.zeros(rows, k, dtype=torch.float64, device=dev)
+            mine[:r1 - r0] = torch.from_numpy(np.ascontiguousarray(res.w)).to(dev)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            tdist.all_gather(parts, mine)
+            if rank == 0:
+                w = np.concatenate([parts[p][:row_range(m, p, world)[1] - row_range(m, p, world)[0]].cpu().numpy()
+                                    for p in range(world)])
+    finally:
+        if hasattr(shard, "close"):
+            shard.close()
+    return Results(w, res.h, res.i, res.obj_history, experiment)
+
+
+class _Shape:
+    """Just enough of an array for utils.initial_factors' random branch (it only reads .shape)."""
+
+    def __init__(self, m, n):
+        self.shape = (m, n)

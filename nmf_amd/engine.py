@@ -164,6 +164,19 @@ class Engine:
     def aoadmm_phase_w_close(self, admm_iter, j):
         self._ck(self.lib.nmfx_aoadmm_phase_w_close(self.h, int(admm_iter), int(j)))
 
+    def aoadmm_phase_w_fused(self, prox_w, lam_w, admm_iter):
+        self._ck(self.lib.nmfx_aoadmm_phase_w_fused(self.h, prox_w, float(lam_w), int(admm_iter)))
+
+    def aoadmm_phase_w_repair(self, prox_w, lam_w, admm_iter, j):
+        self._ck(self.lib.nmfx_aoadmm_phase_w_repair(self.h, prox_w, float(lam_w), int(admm_iter), int(j)))
+
+    def admm_phase_products(self, dist, rho, prox_w, prox_h, j):
+        self._ck(self.lib.nmfx_admm_phase_products(self.h, dist, float(rho), prox_w, prox_h, int(j)))
+
+    def admm_phase_update(self, dist, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_admm_phase_update(self.h, dist, float(rho), prox_w, float(lam_w), prox_h, float(lam_h),
+                                                 int(min_iter), float(tol1), float(tol2), int(j)))
+
     def objective_partial(self):
         self._ck(self.lib.nmfx_objective_partial(self.h))
 

@@ -17,7 +17,7 @@ class HostShard:
         self.k = k
         n = self.v.shape[1]
         self.x32 = torch.zeros(k * n + k * k + k, dtype=torch.float64)   # f64 here: compare tightly
-        self.x64 = torch.zeros(8, dtype=torch.float64)
+        self.x64 = torch.zeros(8 + 4 * 64, dtype=torch.float64)     # [8 + 4 r + c]: norm table of the fused W sub-problem
         self.obj = []
         self.flag, self.stop_i = 0, -1
         self.w_new = None
@@ -167,15 +167,109 @@ class HostShard:
         if not self.flag:
             self.inner[(j, 1)] = self._w_ran
 
+    # the W sub-problem with ONE exchange (nmfx_aoadmm_phase_w_fused / _repair): all rounds speculatively, the norm
+    # sums of every round into x64[8 + 4 r + c]; after the all-reduce the stopping round is derived and the rows are
+    # recomputed from the saved start for exactly that many rounds
+    def _w_rounds(self, prox_w, lam_w, rounds, table=None):
+        import scipy.linalg as sla
+        wt, dt = self._w_start
+        for rnd in range(rounds):
+            aux = sla.cho_solve((self._chol_w, True), self._b_w + self._rho_w * (wt + dt))
+            new = self._prox(prox_w, aux, dt, self._rho_w, lam_w)
+            dual = dt + new - aux
+            if table is not None:
+                table[rnd] = [np.sum((new - aux) ** 2), np.sum(new ** 2), np.sum((new - wt) ** 2), np.sum(dual ** 2)]
+            wt, dt = new, dual
+        return wt, dt
+
+    def ao_w_fused(self, prox_w, lam_w, admm_iter):
+        if self.flag:
+            return
+        self._w_start = (self.w.T.copy(), self.dual_w.T.copy())
+        table = np.zeros((admm_iter, 4))
+        wt, dt = self._w_rounds(prox_w, lam_w, admm_iter, table)
+        self.w, self.dual_w = wt.T.copy(), dt.T.copy()
+        self.x64[8:8 + 4 * admm_iter] = torch.from_numpy(table.ravel())
+
+    def ao_w_repair(self, prox_w, lam_w, admm_iter, j):
+        if self.flag:
+            return
+        table = self.x64[8:8 + 4 * admm_iter].numpy().reshape(admm_iter, 4)
+        rounds = admm_iter
+        for rnd in range(admm_iter):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = np.sqrt(table[rnd, 0]) / np.sqrt(table[rnd, 1])
+                s = np.sqrt(table[rnd, 2]) / np.sqrt(table[rnd, 3])
+            if r < 1e-2 and s < 1e-2:
+                rounds = rnd + 1
+                break
+        if rounds < admm_iter:
+            wt, dt = self._w_rounds(prox_w, lam_w, rounds)
+            self.w, self.dual_w = wt.T.copy(), dt.T.copy()
+        self.inner[(j, 1)] = rounds
+
+    # ---- ADMM (nmf/admm.py:292-334) in the sharded protocol ----
+    def set_l2n_operator(self, which, p):
+        if not hasattr(self, "l2n"):
+            self.l2n = {}
+        self.l2n[which] = np.asarray(p, dtype=np.float64)
+
+    def admm_products(self, kind, rho, prox_w, prox_h, j):
+        if not hasattr(self, "w_aux"):
+            self.w_aux, self.h_aux = self.w.copy(), self.h.copy()
+            self.dual_w, self.dual_h = np.zeros_like(self.w), np.zeros_like(self.h)
+            self.v_aux, self.dual_v = np.zeros_like(self.v), np.zeros_like(self.v)
+        self.obj_kind = kind
+        if self.flag:
+            return
+        k, n = self.k, self.v.shape[1]
+        self.x64[:8] = 0
+        self.x64[0] = self._local_objective(kind)
+        x = self.x32.numpy()
+        x[:] = 0
+        data = self.v if kind == 0 else self.v_aux + self.dual_v
+        x[:k * n] = (self.w_aux.T @ data).ravel()
+        x[k * n:k * n + k * k] = (self.w_aux.T @ self.w_aux).ravel()
+
+    def _admm_prox(self, code, aux, dual, rho, lam, which):
+        kind = {0: "nn", 1: "l1n", 2: "l2n", 3: "l1inf", 4: "l1inf_transpose"}[code]
+        if kind == "l2n":
+            out = self.l2n[which] @ (aux - dual)
+            return np.where(out < 0, 0, out)
+        return R.prox(kind, aux, dual, rho=rho, lam=lam)
+
+    def admm_update(self, kind, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j):
+        if self.flag or self._record(min_iter, tol1, tol2, j):
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        b = x[:k * n].reshape(k, n)
+        g = x[k * n:k * n + k * k].reshape(k, k)
+        self.h_aux = np.linalg.solve(g + rho * np.eye(k), b + rho * (self.h + self.dual_h))
+        data = self.v if kind == 0 else self.v_aux + self.dual_v
+        a = self.h_aux @ self.h_aux.T + rho * np.eye(k)
+        self.w_aux = np.linalg.solve(a, self.h_aux @ data.T + rho * (self.w.T + self.dual_w.T)).T
+        self.h = self._admm_prox(prox_h, self.h_aux, self.dual_h, rho, lam_h, 1)
+        self.w = self._admm_prox(prox_w, self.w_aux.T, self.dual_w.T, rho, lam_w, 0).T
+        if kind == 1:
+            v_bar = self.w_aux @ self.h_aux - self.dual_v
+            self.v_aux = 0.5 * ((v_bar - 1) + np.sqrt((v_bar - 1) ** 2 + 4 * self.v))
+            self.dual_v = self.dual_v + self.v_aux - self.w_aux @ self.h_aux
+        self.dual_h = self.dual_h + self.h - self.h_aux
+        self.dual_w = self.dual_w + self.w - self.w_aux
+
     def objective_partial(self):
         if not self.flag:
-            self.x64[0] = self._local_objective(0)
+            self.x64[0] = self._local_objective(getattr(self, "obj_kind", 0))
 
     # ---- ANLS (nmf/anls.py:18-47, 112-126) in the sharded protocol ----
+    def anls_set_distance(self, kind):
+        self.obj_kind = kind
+
     def anls_objective(self, j):
         if not self.flag:
             self.x64.zero_()
-            self.x64[0] = self._local_objective(0)
+            self.x64[0] = self._local_objective(getattr(self, "obj_kind", 0))
 
     def anls_w(self, lam_w, min_iter, tol1, tol2, j):
         if self.flag or self._record(min_iter, tol1, tol2, j):

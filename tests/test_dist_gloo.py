@@ -153,3 +153,101 @@ def test_sharded_aoadmm_anls_equal_single_process_oracle(case, tmp_path):
     np.testing.assert_allclose(w, ref.w, rtol=1e-6, atol=1e-9)
     if case.get("uniform"):
         assert any(t[0] < 10 or t[1] < 10 for t in ref.trace["inner"]), "case must exercise the early exit"
+
+
+# ---- the round-by-round exchange of the W sub-problem, ADMM, and the SPMD entry point -------------------------------
+def _generic_worker(rank, world, port, case, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    from host_shard import HostShard
+    from nmf_amd import dist as nd
+    v, w0, h0 = _solver_inputs(case)
+    if case.get("api"):
+        # nmf_amd.dist.factorize: the reference's call surface, SPMD; the numpy stand-in replaces the HIP engine
+        np.random.seed(case["seed"])
+        res = nd.factorize(v, case["k"], method=case["solver"], backend="gloo", shard_factory=HostShard, **case["kw"])
+        w_local = None
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        r0, r1 = nd.row_range(case["m"], rank, world)
+        shard = HostShard(v[r0:r1], case["k"], w0[r0:r1], h0)
+        run = {"ao_admm": nd.aoadmm_sharded, "admm": nd.admm_sharded}[case["solver"]]
+        res = run(shard, nd.TorchComm(), batch=case["batch"], **case["kw"], **case.get("extra", {}))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
+             exp=json.dumps([str(x) for x in (res.experiment or [])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import json  # noqa: E402
+
+GENERIC_CASES = [
+    dict(solver="ao_admm", m=96, n=70, k=5, seed=12, batch=2, svd=True, uniform=True, extra=dict(fused=False),
+         kw=dict(reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=2, max_iter=60, admm_iter=10, tol1=1e-3, tol2=1e-2)),
+    dict(solver="admm", m=110, n=80, k=5, seed=21, batch=4, svd=True,
+         kw=dict(rho=2, distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.3, "l2n"), min_iter=8, max_iter=8)),
+    dict(solver="admm", m=90, n=66, k=4, seed=22, batch=3, svd=True,
+         kw=dict(rho=1, distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=6, max_iter=6)),
+    dict(solver="admm", m=90, n=66, k=4, seed=23, batch=3, svd=True,       # the row-coupled prox on the replicated side
+         kw=dict(rho=1, distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.05, "l1inf"), min_iter=3, max_iter=3)),
+]
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES, ids=["ao_admm_round_by_round", "admm_eu_l1n_l2n", "admm_kl", "admm_l1inf_h"])
+def test_sharded_admm_and_unfused_aoadmm_equal_single_process_oracle(case, tmp_path):
+    world = 2
+    mp.spawn(_generic_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    from oracle import nmf_ref as R
+    v, w0, h0 = _solver_inputs(case)
+    ref = {"ao_admm": R.ao_admm, "admm": R.admm}[case["solver"]](v, case["k"], w0=w0, h0=h0, **case["kw"])
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    w = np.concatenate([p["w"] for p in parts])
+    for p in parts:
+        assert int(p["i"]) == ref.i
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=1e-8)
+        np.testing.assert_allclose(p["h"], ref.h, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(w, ref.w, rtol=1e-6, atol=1e-9)
+
+
+API_CASES = [
+    dict(api=True, solver="mur", m=101, n=63, k=4, seed=31, kw=dict(distance_type="eu", min_iter=9, max_iter=9, lambda_w=0.02)),
+    dict(api=True, solver="mur", m=64, n=48, k=3, seed=32, kw=dict(min_iter=7, max_iter=7)),                 # default distance: 'kl'
+    dict(api=True, solver="ao_admm", m=90, n=70, k=4, seed=33,
+         kw=dict(reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)),                           # default NNDSVD start
+    dict(api=True, solver="admm", m=90, n=70, k=4, seed=34, kw=dict(reg_h=(0.2, "l2n"), min_iter=5, max_iter=5)),
+    dict(api=True, solver="anls", m=50, n=40, k=3, seed=35, kw=dict(distance_type="kl", min_iter=3, max_iter=3, lambda_h=0.05)),
+]
+
+
+@pytest.mark.parametrize("case", API_CASES, ids=["mur_eu", "mur_default_kl", "ao_admm", "admm", "anls_kl"])
+def test_factorize_api_over_two_ranks_matches_the_single_process_reference_semantics(case, tmp_path):
+    """nmf_amd.dist.factorize: reference keyword names / defaults per method, the global numpy RNG consumed in the
+    reference's order on every rank, NNDSVD from rank 0 broadcast, rank 0 returns the gathered m x k factor."""
+    world = 2
+    mp.spawn(_generic_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    from oracle import nmf_ref as R
+    v, _, _ = _solver_inputs(case)
+    np.random.seed(case["seed"])
+    ref = R.SOLVERS[case["solver"]](v.copy(), case["k"], **case["kw"])
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert parts[0]["w"].shape == (case["m"], case["k"])                 # gathered on rank 0
+    assert parts[1]["w"].shape == (case["m"] - case["m"] // 2, case["k"])  # its own rows elsewhere
+    np.testing.assert_allclose(parts[0]["w"], ref.w, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(parts[0]["w"][case["m"] // 2:], parts[1]["w"], rtol=0, atol=0)
+    for p in parts:
+        assert int(p["i"]) == ref.i
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=1e-8)
+        np.testing.assert_allclose(p["h"], ref.h, rtol=1e-6, atol=1e-9)
+    exp = json.loads(str(parts[0]["exp"]))
+    assert exp[0] == case["solver"] and exp[1] == str(case["k"])
+
+
+def test_factorize_rejects_what_the_reference_rejects():
+    from nmf_amd import dist as nd
+    v = np.random.RandomState(0).rand(12, 9)
+    with pytest.raises(Exception, match="Method not known"):
+        nd.factorize(v, 3, method="nope")

@@ -135,6 +135,19 @@ def test_graphed_loop_equals_eager_loop(tmp_path):
 # ---- AO-ADMM and ANLS over row shards (device engine) ------------------------
 def _solver_case(solver):
     from oracle import nmf_ref as R
+    if solver in ("ao_admm_early", "ao_admm_unfused"):     # uniform data: the inner loops stop early -> the REPAIR launch runs
+        m, n, k = 192, 128, 5
+        v = np.random.RandomState(12).rand(m, n).astype(np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        kw = dict(reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=2, max_iter=60, admm_iter=10, tol1=1e-3, tol2=1e-2)
+        return m, n, k, v, w0, h0, kw
+    if solver.startswith("admm"):
+        m, n, k = 520, 300, (40 if solver.endswith("bf16") else 12)
+        kw = dict(rho=1.0, distance_type="kl" if solver == "admm_kl" else "eu", reg_w=(0.05, "l1n"),
+                  reg_h=(0.05, "l1n") if solver == "admm_kl" else (0.2, "l2n"), min_iter=6, max_iter=6)
+        v = R.planted_matrix(m, n, k, seed=33, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
     if solver.startswith("ao_admm"):
         m, n, k = 520, 300, (40 if solver.endswith("bf16") else 12)    # k = 40: split-bf16 products, lazy objective
         kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=8, max_iter=8, admm_iter=10)
@@ -162,7 +175,12 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
     r0, r1 = nd.row_range(m, rank, world)
     shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
     comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
-    res = (nd.aoadmm_sharded if solver.startswith("ao_admm") else nd.anls_sharded)(shard, comm, batch=3, **kw)
+    if solver.startswith("ao_admm"):
+        res = nd.aoadmm_sharded(shard, comm, batch=16, fused=(False if solver == "ao_admm_unfused" else None), **kw)
+    elif solver.startswith("admm"):
+        res = nd.admm_sharded(shard, comm, batch=3, **kw)
+    else:
+        res = nd.anls_sharded(shard, comm, batch=3, **kw)
     inner = (shard.eng.inner_counts(0, res.i + 1) & 0xFFFF) if solver.startswith("ao_admm") else np.zeros(0)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
              inner=inner)
@@ -171,22 +189,66 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "anls"])
+@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "admm", "admm_bf16", "admm_kl", "anls"])
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
     mp.spawn(_solver_gpu_worker, args=(world, _free_port(), backend, solver, str(tmp_path)), nprocs=world, join=True)
     m, n, k, v, w0, h0, kw = _solver_case(solver)
-    ref = (R.ao_admm if solver.startswith("ao_admm") else R.anls)(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
+    oracle = R.ao_admm if solver.startswith("ao_admm") else R.admm if solver.startswith("admm") else R.anls
+    ref = oracle(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     w = np.concatenate([p["w"] for p in parts])
     h = parts[0]["h"]
     err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
     assert err < 1e-4, err
+    if solver == "ao_admm_early":
+        assert any(t[1] < 10 for t in ref.trace["inner"]), "case must exercise the repair launch of the W sub-problem"
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-4)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-3 if solver == "admm_kl" else 5e-4)
         np.testing.assert_array_equal(p["h"], h)
         if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
+
+
+def _api_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from nmf_amd import dist as nd
+    from oracle import nmf_ref as R
+    v = R.planted_matrix(600, 260, 12, seed=41, dtype=np.float32)
+    out = {}
+    np.random.seed(7)
+    res = nd.factorize(v, 12, method="mur", backend="gloo", distance_type="eu", min_iter=10, max_iter=10)
+    out["mur_w"], out["mur_h"], out["mur_obj"] = res.w, res.h, np.asarray(res.obj_history)
+    res = nd.factorize(v, 12, method="ao_admm", backend="gloo", reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)
+    out["ao_w"], out["ao_h"], out["ao_obj"] = res.w, res.h, np.asarray(res.obj_history)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
+    """nmf_amd.dist.factorize end to end on the device engine: reference keywords / defaults, seeds, NNDSVD from
+    rank 0, gathered W on rank 0 (two ranks share the GPU: exchange staged through the host over gloo)."""
+    import torch.multiprocessing as mp
+    from oracle import nmf_ref as R
+    mp.spawn(_api_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    v = R.planted_matrix(600, 260, 12, seed=41, dtype=np.float32)
+    z = np.load(tmp_path / "rank0.npz")
+    np.random.seed(7)
+    ref = R.mur(v.astype(np.float64), 12, distance_type="eu", min_iter=10, max_iter=10)
+    assert z["mur_w"].shape == (600, 12)
+    assert np.linalg.norm(z["mur_w"] @ z["mur_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+    np.testing.assert_allclose(z["mur_obj"], ref.obj_history, rtol=2e-4)
+    ref = R.ao_admm(v.astype(np.float64), 12, reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)
+    assert np.linalg.norm(z["ao_w"] @ z["ao_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+    np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=5e-4)
