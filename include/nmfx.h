@@ -64,13 +64,19 @@ int nmfx_device_count(void);
 int nmfx_set_stream(nmfx_handle_t h, void* hip_stream);
 int nmfx_reset_stream(nmfx_handle_t h);
 int nmfx_synchronize(nmfx_handle_t h);
-/* Arithmetic of the two V-sized products of MUR-Euclidean: 0 = f32-input MFMA (exact
- * f32 FMA chains), 1 = split bf16 (each f32 operand as bf16 hi + bf16 lo, four bf16
- * MFMA terms, f32 accumulation; available when k pads to 64, otherwise mode 0 is
- * used).  nmfx_get_precision returns the mode in effect.  Environment override at
- * create time: NMFX_PRECISION=f32|bf16.                                         */
+/* Arithmetic of the V-sized products: 0 = f32-input MFMA (exact
+ * f32 FMA chains), 1 = split bf16 (each f32 operand as bf16 hi + bf16 lo, three or four
+ * bf16 MFMA terms per product -- kernels_bf16.hip, top -- f32 accumulation; available when
+ * k pads to 64 or 128, otherwise mode 0 is used; every solver's Euclidean products and
+ * MUR-KL's quotient products).  nmfx_get_precision returns the mode in effect.
+ * Environment override at create time: NMFX_PRECISION=f32|bf16.                 */
 int nmfx_set_precision(nmfx_handle_t h, int mode);
 int nmfx_get_precision(nmfx_handle_t h);
+/* What nmfx_create decided on its own, in words ("" if nothing): today the fall back to the exact-f32 kernels when the
+ * two extra V-sized buffers of the split-bf16 path do not fit into the free device memory.  (In split-bf16 mode the
+ * row-major copy of a V of 4 GiB or more is freed once the tile-major copies exist -- NMFX_DROP_V=0/1 overrides -- and
+ * rebuilt when a kernel needs it.)                                                                                  */
+const char* nmfx_get_note(nmfx_handle_t h);
 
 /* ---- data --------------------------------------------------------------- */
 /* Copy rows [row0, row0+rows) of the local V from host memory (row stride `ld`

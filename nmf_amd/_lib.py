@@ -31,6 +31,7 @@ SIGNATURES = {
     "nmfx_synchronize": (_i32, [_vp]),
     "nmfx_set_precision": (_i32, [_vp, _i32]),
     "nmfx_get_precision": (_i32, [_vp]),
+    "nmfx_get_note": (C.c_char_p, [_vp]),
     "nmfx_upload_v": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64]),
     "nmfx_upload_v_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64]),
     "nmfx_set_factors": (_i32, [_vp, _vp, _vp]),

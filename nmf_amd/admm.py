@@ -45,6 +45,10 @@ def admm(v, k, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), 
     init = utils.initial_factors(v, k, nndsvd_init, defer_device=True)
     prox_h = _prox_code(reg_h[1])
     prox_w = _prox_code(reg_w[1])
+    if rho == 0 and (reg_h[1] != 'nn' or reg_w[1] != 'nn'):
+        # rho = 0 is a plain Gram solve in the reference (admm.py:230); every prox but 'nn' divides by rho (admm.py:135,
+        # 150, 161) in the first iteration
+        raise ZeroDivisionError('division by zero')
     with Engine.for_data(v, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, v, k, nndsvd_init, init)
         eng.set_factors(w0, h0)

@@ -32,6 +32,28 @@ int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes) {
     return NMFX_OK;
 }
 
+// The HIP runtime loads a translation unit's code object onto a device lazily, at the first launch of one of its
+// kernels.  So that two host threads never make those first launches at the same time, every handle passes through here
+// before its own first launch: once per device, under a lock, one kernel of every translation unit is touched
+// (hipFuncGetAttributes) and a launch is made and waited for.  (Precaution.  The failure that two concurrent creates did
+// show -- "unknown error" on the second thread's first launch -- came from the unguarded attribute / occupancy queries of
+// nmfx_phase_occupancy, which are serialised now.)
+__global__ void nmfx_startup_kernel(int* p) { if (p) *p = 0; }
+static int preload_once(nmfx_engine* E) {
+    static std::mutex mu;
+    static std::map<int, bool> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[E->device]) return NMFX_OK;
+    if (nmfx_preload_bf16() || nmfx_preload_products() || nmfx_preload_mur() || nmfx_preload_kl() || nmfx_preload_aoadmm() ||
+        nmfx_preload_anls() || nmfx_preload_svd() || nmfx_preload_prox()) {
+        E->err = "loading the kernels onto the device failed"; return NMFX_E_HIP; }
+    hipLaunchKernelGGL(nmfx_startup_kernel, dim3(1), dim3(1), 0, 0, (int*)nullptr);
+    NMFX_HIP(hipGetLastError());
+    NMFX_HIP(hipDeviceSynchronize());
+    done[E->device] = true;
+    return NMFX_OK;
+}
+
 static int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 __global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t lds, int64_t n, float* __restrict__ dst,
@@ -122,6 +144,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
 #define TRY(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { E->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(NMFX_E_HIP); } } while (0)
     TRYHIP(hipSetDevice(device));
+    TRY(preload_once(E));
     TRYHIP(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
     E->stream = E->own_stream;
     // split configuration: enough workgroups to fill 256 CUs twice over
@@ -156,14 +179,26 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->xf64, 8 + 4 * NMFX_MAX_FUSED_ROUNDS));
     TRY(dev_alloc(E, &E->state, 1));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
+    TRYHIP(hipGetLastError());
     TRY(nmfx_ensure_obj_capacity(E, 4096));
     TRYHIP(hipStreamSynchronize(E->stream));
-    {   // the split-bf16 path keeps two more V-sized buffers (tile-major V and V^T): fall back to the
-        // exact-f32 kernels (one copy of V) when they would not fit next to everything else
+    {   // Memory plan of the split-bf16 path: tile-major V and V^T next to the row-major V while they are built (three
+        // V-sized buffers), two afterwards when the row-major one is dropped.  It is dropped for V >= 4 GiB (or
+        // NMFX_DROP_V=1 / 0) and rebuilt on demand (nmfx_need_v).  If even the three-copy peak does not fit, the engine
+        // runs the exact-f32 kernels (one copy) and SAYS so: nmfx_get_note().
+        const double vbytes = (double)mp * (double)np * 4.0;
+        const char* dv = getenv("NMFX_DROP_V");
+        E->drop_v = dv ? atoi(dv) != 0 : vbytes >= 4.0 * 1024 * 1024 * 1024;
         size_t free_b = 0, total_b = 0;
-        if (E->precision == 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const double need = 2.0 * (double)mp * (double)np * 4.0 + 64.0 * (double)(mp + np) * kp + (256u << 20);
-            if ((double)free_b < need) E->precision = 0;
+        if (E->precision == 1 && nmfx_bf16_supported(E) && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double need = 2.0 * vbytes + 64.0 * (double)(mp + np) * kp + (256u << 20);
+            if ((double)free_b < need) {
+                E->precision = 0;
+                char buf[256];
+                snprintf(buf, sizeof buf, "split-bf16 products need %.1f GiB more device memory than the %.1f GiB that are free: "
+                         "running the exact-f32 kernels (about half the speed)", need / 1073741824.0, (double)free_b / 1073741824.0);
+                E->note = buf;
+            }
         }
     }
 #undef TRY
@@ -211,6 +246,8 @@ int nmfx_set_precision(nmfx_handle_t E, int mode) {
     return NMFX_OK;
 }
 
+const char* nmfx_get_note(nmfx_handle_t E) { return E ? E->note.c_str() : ""; }
+
 int nmfx_get_precision(nmfx_handle_t E) {
     if (!E) return NMFX_E_ARG;
     return (E->precision == 1 && nmfx_bf16_supported(E)) ? 1 : 0;
@@ -229,6 +266,7 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
         E->err = "upload_v: bad row range or leading dimension"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     if (rows == 0) return NMFX_OK;
+    if (E->have_v) { int rc_ = nmfx_need_v(E); if (rc_) return rc_; }       // (rows of a V whose row-major copy was dropped)
     float* dst = E->V + row0 * E->np;
     if (dtype == NMFX_F32) {
         NMFX_HIP(hipMemcpy2DAsync(dst, (size_t)E->np * 4, host, (size_t)ld * 4, (size_t)E->n * 4,
@@ -263,6 +301,7 @@ int nmfx_upload_v_device(nmfx_handle_t E, const void* dev, int dtype, int64_t ld
         E->err = "upload_v_device: bad row range or leading dimension"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     if (rows == 0) return NMFX_OK;
+    if (E->have_v) { int rc_ = nmfx_need_v(E); if (rc_) return rc_; }
     float* dst = E->V + row0 * E->np;
     if (dtype == NMFX_F32) {
         NMFX_HIP(hipMemcpy2DAsync(dst, (size_t)E->np * 4, dev, (size_t)ld * 4, (size_t)E->n * 4,

@@ -605,3 +605,6 @@ extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, 
         if ((rc = anls_iteration(E, lambda_w, lambda_h, min_iter, tol1, tol2, j))) return rc;
     return NMFX_OK;
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_anls() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(nnls_bpp_reg128_kernel)) == hipSuccess ? 0 : -1; }

@@ -1368,3 +1368,6 @@ extern "C" int nmfx_aoadmm_finish(nmfx_handle_t E, int64_t min_iter, double tol1
     if ((rc = ao_final_objective(E))) return rc;
     return nmfx_finish_b(E, min_iter, tol1, tol2, done);
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_aoadmm() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(nrm_table_kernel)) == hipSuccess ? 0 : -1; }

@@ -985,6 +985,26 @@ __global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ i
         dst[i] = *reinterpret_cast<const float4*>(src + (int64_t)(i >> 4) * ld + 4 * (i & 15));
 }
 
+// the inverse of retile_kernel: row-major out from the tile-major copy
+__global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out)
+{
+    const int64_t rb = blockIdx.y, cb = blockIdx.x;
+    float* dst = out + rb * 128 * ld + cb * 64;
+    const float4* src = reinterpret_cast<const float4*>(in + (rb * (ld >> 6) + cb) * 8192);
+    for (int i = threadIdx.x; i < 128 * 16; i += 256)
+        *reinterpret_cast<float4*>(dst + (int64_t)(i >> 4) * ld + 4 * (i & 15)) = src[i];
+}
+
+int nmfx_need_v(nmfx_engine* E) {
+    if (E->V) return NMFX_OK;
+    if (!E->Vtile) { E->err = "no copy of V on the device"; return NMFX_E_STATE; }
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->V), (size_t)E->mp * E->np * sizeof(float)));
+    hipLaunchKernelGGL(untile_kernel, dim3((unsigned)(E->np / 64), (unsigned)(E->mp / 128)), dim3(256), 0, E->stream,
+                       E->Vtile, E->np, E->V);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // bf16 hi/lo images of M [rows][cols] (row-major, ld) and of its transpose [cols][rows]
 __global__ __launch_bounds__(256) void split_images_kernel(
     const float* __restrict__ M, int64_t rows, int64_t cols, int64_t ld,
@@ -1404,6 +1424,7 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     if (E->bf_ready) return NMFX_OK;
     int rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if ((rc = nmfx_need_v(E))) return rc;              // (a second prepare after new factors / new rows of V)
     if ((rc = lazy_alloc(E, &E->Vt, mp * np))) return rc;
     if ((rc = lazy_alloc(E, &E->Vtile, mp * np))) return rc;
     for (int b = 0; b < 2; ++b) {
@@ -1433,6 +1454,11 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
                        E->V, np, E->Vt, mp);
     hipLaunchKernelGGL(retile_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 128)), dim3(256), 0, E->stream,
                        E->V, np, E->Vtile);
+    if (E->drop_v) {               // two copies of V instead of three from here on (nmfx_need_v rebuilds the row-major one)
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+        NMFX_HIP(hipFree(E->V));
+        E->V = nullptr;
+    }
     E->bf_ready = true;
     if ((rc = nmfx_bf16_images_w(E, E->W[E->wsel], E->wsel))) return rc;
     return nmfx_bf16_images_h(E, false);
@@ -1618,3 +1644,6 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
     if (E->kp != 64) return mur_eu_phase_b_bf16_k128(E, lambda_h, min_iter, tol1, tol2, j);
     return launch_h_update_bf16<64>(E, E->fused_pack, (float)lambda_h, j, min_iter, tol1, tol2);
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_bf16() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(transpose_tiled_kernel)) == hipSuccess ? 0 : -1; }

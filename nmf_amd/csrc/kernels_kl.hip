@@ -245,6 +245,7 @@ static int launch_hphase_kl(nmfx_engine* E, const float* W) {
     const size_t panel = (size_t)KP * (16 * NE + 4) * sizeof(float);
     const size_t red = (size_t)(KP / 16) * NE * 64 * sizeof(f32x4);
     const size_t shm = std::max(std::max(panel, red), (size_t)4 * KP * sizeof(float));
+    { int rc_ = nmfx_need_v(E); if (rc_) return rc_; }
     hipLaunchKernelGGL((hphase_kl_kernel<KP, NE>), grid, block, shm, E->stream, E->V, E->np, W, E->H,
                        E->B_part, E->G_part, E->np, E->mp, &E->state->flag);
     NMFX_HIP(hipGetLastError());
@@ -368,3 +369,6 @@ int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j) {
     if ((rc = nmfx_launch_wphase(E, E->W[j & 1], false, true, true))) return rc;
     return nmfx_launch_obj_reduce(E);
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_kl() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(row_sums_kernel)) == hipSuccess ? 0 : -1; }

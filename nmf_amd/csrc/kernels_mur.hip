@@ -301,3 +301,6 @@ int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, in
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_mur() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(obj_reduce_kernel)) == hipSuccess ? 0 : -1; }

@@ -17,6 +17,8 @@
 // to four different output tiles (hphase); both operands use the same
 // permutation, so every global/LDS access is a full dwordx4.
 #include "nmfx_internal.h"
+#include <mutex>
+#include <utility>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -666,19 +668,34 @@ static void occupancy_of(int* wocc, int* hocc) {
 }
 
 void nmfx_phase_occupancy(int kp, int* wocc, int* hocc) {
-    switch (kp) {
-        case 16: occupancy_of<16>(wocc, hocc); break;
-        case 32: occupancy_of<32>(wocc, hocc); break;
-        case 64: occupancy_of<64>(wocc, hocc); break;
-        default: occupancy_of<128>(wocc, hocc); break;
+    // (called by nmfx_create of every handle, possibly from several threads: the attribute + occupancy queries are
+    // serialised, answered once per device and padded rank, and must not leave a stale error for the next
+    // hipGetLastError of the calling thread -- two concurrent creates with kp = 128 did exactly that)
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::pair<int, int>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = cache.find(std::make_pair(dev, kp));
+    if (it == cache.end()) {
+        int a = 2, b = 2;
+        switch (kp) {
+            case 16: occupancy_of<16>(&a, &b); break;
+            case 32: occupancy_of<32>(&a, &b); break;
+            case 64: occupancy_of<64>(&a, &b); break;
+            default: occupancy_of<128>(&a, &b); break;
+        }
+        (void)hipGetLastError();
+        it = cache.emplace(std::make_pair(dev, kp), std::make_pair(a, b)).first;
     }
+    *wocc = it->second.first; *hocc = it->second.second;
 }
 
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl, const float* Hsrc,
                        const float* Vsrc, const int* flag2) {
     ProfScope ps(E, with_a ? (with_obj ? "wphase" : "wphase_noobj") : "objective");
     if (!Hsrc) Hsrc = E->H;
-    if (!Vsrc) Vsrc = E->V;
+    if (!Vsrc) { int rc_ = nmfx_need_v(E); if (rc_) return rc_; Vsrc = E->V; }
     switch (E->kp) {
         case 16: return wphase_dispatch<16>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
         case 32: return wphase_dispatch<32>(E, W, with_a, with_obj, kl, Hsrc, Vsrc, flag2);
@@ -707,7 +724,7 @@ static int hphase_dispatch(nmfx_engine* E, const float* W, bool with_g, const fl
 // see nmfx_hphase_can_fuse_gram).
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc, const int* flag2) {
     ProfScope ps(E, "hphase");
-    if (!Vsrc) Vsrc = E->V;
+    if (!Vsrc) { int rc_ = nmfx_need_v(E); if (rc_) return rc_; Vsrc = E->V; }
     switch (E->kp) {
         case 16: return hphase_dispatch<16>(E, W, with_g, Vsrc, flag2);
         case 32: return hphase_dispatch<32>(E, W, with_g, Vsrc, flag2);
@@ -756,6 +773,7 @@ static int kl_vaux_dispatch(nmfx_engine* E, const float* Wsrc, const float* Hsrc
     dim3 grid((unsigned)(E->mp / 64), (unsigned)E->wsplit), block(256);
     const size_t shm = (size_t)(2 * KP * 64 + 8 * 16 * 64) * sizeof(float);
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kl_vaux_kernel<KP>), (int)shm); if (rc_) return rc_; }
+    { int rc_ = nmfx_need_v(E); if (rc_) return rc_; }
     hipLaunchKernelGGL((kl_vaux_kernel<KP>), grid, block, shm, E->stream, E->V, E->DV, E->S, E->np, Wsrc, Hsrc,
                        E->np, (int)(E->np / 64), &E->state->flag, flag2);
     NMFX_HIP(hipGetLastError());
@@ -772,3 +790,6 @@ int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, co
         default: return kl_vaux_dispatch<128>(E, Wsrc, Hsrc, flag2);
     }
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_products() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gram_nt_kernel<16>)) == hipSuccess ? 0 : -1; }

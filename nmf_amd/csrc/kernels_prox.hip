@@ -240,3 +240,6 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_prox() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(dual_update_kernel)) == hipSuccess ? 0 : -1; }

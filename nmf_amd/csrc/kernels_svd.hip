@@ -292,6 +292,7 @@ int launch_apply(SvdWork& w, bool trans, const double* B, double* C)
     while ((int64_t)splits * out_rows * L > w.part_count && splits > 1) --splits;
     const size_t shm = (size_t)KC * LDA * 4 + (size_t)KC * LP * 8;
     dim3 grid((unsigned)blocks, (unsigned)splits);
+    { int rc_ = nmfx_need_v(E); if (rc_) return rc_; }
     if (trans) hipLaunchKernelGGL((svd_apply_kernel<NT, true>), grid, dim3(256), shm, E->stream, E->V, E->np, clen, B, w.part, out_rows);
     else hipLaunchKernelGGL((svd_apply_kernel<NT, false>), grid, dim3(256), shm, E->stream, E->V, E->np, clen, B, w.part, out_rows);
     NMFX_HIP(hipGetLastError());
@@ -573,3 +574,6 @@ extern "C" int nmfx_topk_svd(nmfx_handle_t E, int k, int block, double tol, int 
         default: return topk_svd<12>(E, k, tol, max_sweeps, seed, u, s, vt, sweeps, resid);
     }
 }
+
+// (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
+int nmfx_preload_svd() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(svd_sum_kernel)) == hipSuccess ? 0 : -1; }

@@ -80,6 +80,8 @@ struct nmfx_engine {
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     bool himg_both = false;        // Hhi/Hlo AND HThi/HTlo are the images of the current H (AO-ADMM skips a rebuild)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
+    bool drop_v = false;           // split-bf16 mode: free the row-major V once Vtile / Vt exist (rebuilt on demand, nmfx_need_v)
+    std::string note;              // what nmfx_create decided on its own (precision fallback, dropped V): nmfx_get_note
     float* Vtile = nullptr;        // V, tile-major: [mp/128][np/64] tiles of [128][64] (bf16-path W phase)
     float* Vt = nullptr;           // V^T, tile-major: [np/128][mp/64] tiles of [128][64] (bf16-path H phase)
     float* Bt_part = nullptr;      // [bt_split][np][kp]
@@ -105,8 +107,10 @@ struct nmfx_engine {
     std::string err;
 };
 
+#define NMFX_STR2(x) #x
+#define NMFX_STR(x) NMFX_STR2(x)
 #define NMFX_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-    E->err = std::string(#expr) + ": " + hipGetErrorString(e_); return NMFX_E_HIP; } } while (0)
+    E->err = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" NMFX_STR(__LINE__) ")"; return NMFX_E_HIP; } } while (0)
 
 // ---- launch helpers implemented in the kernel translation units ---------
 // A_part[sp] = V(rows, cols of split sp) * H^T ; optionally the residual
@@ -163,6 +167,10 @@ int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M,
                     float lam, int round, const double* nrm_global = nullptr);
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
 
+// Row-major V for the kernels that read it (exact-f32 products, KL auxiliaries, the SVD): in split-bf16 mode it may
+// have been freed after the tile-major copies were built (drop_v) and is then rebuilt from Vtile.
+int nmfx_need_v(nmfx_engine* E);
+
 // Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (device, kernel):
 // the attribute belongs to the function ON A DEVICE, so the bookkeeping is keyed by both and guarded by a
 // mutex -- independent handles may launch from different threads and on different devices.
@@ -170,6 +178,15 @@ int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes);
 
 // prox 'l1inf' / 'l1inf_transpose' of ADMM (kernels_prox.hip): X = prox(X_aux, dual) on the W or the H side
 int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual);
+
+int nmfx_preload_bf16();
+int nmfx_preload_products();
+int nmfx_preload_mur();
+int nmfx_preload_kl();
+int nmfx_preload_aoadmm();
+int nmfx_preload_anls();
+int nmfx_preload_svd();
+int nmfx_preload_prox();
 
 struct ProfScope {
     nmfx_engine* E; hipEvent_t a = nullptr, b = nullptr; const char* name;

@@ -1,5 +1,6 @@
 """Thin object wrapper over the C handle (include/nmfx.h)."""
 import ctypes as C
+import logging
 
 import numpy as np
 
@@ -20,6 +21,9 @@ class Engine:
         h = C.c_void_p()
         L.check(self.lib.nmfx_create(C.byref(h), int(device), self.m, self.n, self.k))
         self.h = h
+        note = self.lib.nmfx_get_note(h)
+        if note:                                  # e.g. the fall back to the exact-f32 kernels for lack of memory
+            logging.warning('nmf_amd: %s', note.decode())
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
@@ -49,7 +53,8 @@ class Engine:
         self._ck(self.lib.nmfx_set_stream(self.h, C.c_void_p(stream_ptr)))
 
     def set_precision(self, mode):
-        """'f32' (exact f32 MFMA) or 'bf16' (split-bf16 products, MUR-eu with k padded to 64)."""
+        """'f32' (exact f32 MFMA) or 'bf16' (split-bf16 products: every solver's Euclidean products and MUR-KL's
+        quotient products when k pads to 64 or 128)."""
         self._ck(self.lib.nmfx_set_precision(self.h, {"f32": 0, "bf16": 1}[mode]))
 
     def precision(self):

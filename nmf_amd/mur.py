@@ -32,12 +32,15 @@ def mur(x, k, *, distance_type='kl', min_iter=100, max_iter=100000, tol1=1e-5, t
 
     # negative data is lifted IN PLACE on the caller's array (nmf/mur.py:99-101)
     lowest = np.min(x)
-    if lowest < 0:
+    lifted = lowest < 0
+    if lifted:
         x += abs(lowest)
         logging.info('Data elevated by {}.'.format(abs(lowest)))
 
     init = utils.initial_factors(x, k, nndsvd_init, defer_device=True)
     with Engine.for_data(x, k, device=device, engine=engine) as eng:
+        if lifted and engine is not None:
+            eng.upload_v(x)             # a resident engine still holds the data as it was before the lift
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         logging.info('Entering Main Loop.')

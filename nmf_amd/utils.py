@@ -76,12 +76,23 @@ def nndsvd(x, rank=None, variant='zero'):
 def nndsvd_device(eng, x, rank, variant='zero'):
     """NNDSVD whose singular triplets come from the device (Engine.topk_svd on the uploaded V,
     f64 subspace iteration) instead of a full LAPACK SVD on the host: the only part of
-    nmf/utils.py:36-93 whose cost grows like m n min(m, n).  Raises if the iteration hits its
-    sweep cap (clustered singular values around the rank-th one)."""
-    u, s, vt, sweeps, resid = eng.topk_svd(rank)
+    nmf/utils.py:36-93 whose cost grows like m n min(m, n).
+
+    NMFX_NNDSVD=device: the device or an error (sweep cap 4000).  Otherwise ("auto"): a few hundred sweeps are
+    allowed -- the filtered iteration needs 4 to 14 on matrices with any gap behind the rank-th singular value -- and
+    when they do not converge (rank beyond the numerical rank: sigma_k sits in the noise bulk) the start is computed by
+    the host's LAPACK SVD like the reference does, with a warning about the minutes that takes on a large matrix."""
+    forced = os.environ.get("NMFX_NNDSVD", "auto") == "device"
+    u, s, vt, sweeps, resid = eng.topk_svd(rank, max_sweeps=0 if forced else 300)
     if not resid <= 1e-9:
-        raise RuntimeError(f'device SVD did not converge ({sweeps} sweeps, residual {resid:.2e}); '
-                           'set NMFX_NNDSVD=host to use LAPACK on the host')
+        if forced:
+            raise RuntimeError(f'device SVD did not converge ({sweeps} sweeps, residual {resid:.2e}); '
+                               'set NMFX_NNDSVD=host to use LAPACK on the host')
+        import logging
+        logging.warning('device SVD did not converge in %d sweeps (residual %.1e: rank %d lies beyond the numerical rank); '
+                        'falling back to the full LAPACK SVD on the host like the reference -- slow for a %dx%d matrix',
+                        sweeps, resid, rank, x.shape[0], x.shape[1])
+        return nndsvd(np.asarray(x), rank, variant=variant)
     return _nndsvd_from_triplets(x, u, s, vt, rank, variant)
 
 

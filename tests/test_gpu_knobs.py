@@ -39,6 +39,8 @@ CASES = [
     ({"NMFX_BF16_TERMS": "4"}, "mur", (384, 256, 40), dict(distance_type="kl", min_iter=15, max_iter=15)),
     ({"NMFX_PRECISION": "f32"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),
     ({"NMFX_XYT16": "1"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),      # the 16-row form of the k = 64 product kernel
+    ({"NMFX_DROP_V": "1"}, "anls", (320, 256, 40), dict(distance_type="kl", min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),   # row-major V dropped, the KL objective pass brings it back
+    ({"NMFX_NNLS128_OCC": "1"}, "anls", (260, 400, 100), dict(min_iter=3, max_iter=3, lambda_w=0.05, lambda_h=0.02, nndsvd_init=NNDSVD)),
     ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_FUSED": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
@@ -55,3 +57,43 @@ def test_alternative_paths_keep_parity(env, method, shape, kwargs):
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert got["i"] == got["ref_i"]
     assert got["err"] < 1e-4, got
+
+
+def test_two_handles_from_two_threads_and_dropped_row_major_v(monkeypatch):
+    """Independent handles are thread safe (include/nmfx.h): two factorisations with different padded ranks run
+    concurrently from two threads -- the per-device bookkeeping of the kernels' LDS limits is shared state -- and give
+    what they give alone.  One of them also runs with the row-major V dropped after the tile-major copies were built
+    (NMFX_DROP_V=1 at create time) and later needs it back (device SVD for an NNDSVD start)."""
+    import threading
+    from nmf_amd.engine import Engine
+    from nmf_amd import utils as U
+    from oracle import nmf_ref as R
+    out, errs = {}, []
+
+    def work(tag, m, n, k, seed):
+        try:
+            v = R.planted_matrix(m, n, k, seed=seed, dtype=np.float32)
+            rs = np.random.RandomState(seed)
+            w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+            with Engine(m, n, k) as eng:
+                eng.upload_v(v)
+                eng.set_factors(w0, h0)
+                eng.mur_run(0, 0.0, 0.0, 10 ** 9, 1e-5, 1e-5, 0, 12)
+                eng.mur_finish(0, 10 ** 9, 1e-5, 1e-5, 12)
+                w, h = eng.get_factors()
+                s = eng.topk_svd(4)[1] if tag == "b" else None        # needs the row-major V again
+            ref = R.mur(v.astype(np.float64), k, distance_type="eu", min_iter=12, max_iter=12, w0=w0, h0=h0)
+            out[tag] = (float(np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))), s,
+                        np.linalg.svd(v.astype(np.float64), compute_uv=False)[:4])
+        except Exception as e:  # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    monkeypatch.setenv("NMFX_DROP_V", "1")
+    ts = [threading.Thread(target=work, args=("a", 384, 256, 40, 1)), threading.Thread(target=work, args=("b", 256, 384, 100, 2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert out["a"][0] < 1e-4 and out["b"][0] < 1e-4, out
+    np.testing.assert_allclose(out["b"][1], out["b"][2], rtol=1e-9)

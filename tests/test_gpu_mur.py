@@ -181,3 +181,19 @@ def test_grid_keeps_v_resident_and_matches_separate_calls(tmp_path):
     np.random.seed(9); fresh = admm(v.copy(), 6, distance_type="kl", **kw)
     np.testing.assert_array_equal(again.w, fresh.w)
     np.testing.assert_array_equal(twice.w, fresh.w)
+
+
+def test_signed_data_with_a_resident_engine_is_lifted_on_the_device_too():
+    """mur(x, k, engine=eng) with negative data: the in-place lift of nmf/mur.py:99-101 happens on the host
+    array; the resident engine must see the lifted matrix as well."""
+    from nmf_amd.engine import Engine
+    from nmf_amd.mur import mur
+    rs = np.random.RandomState(3)
+    x = rs.rand(96, 80) - 0.2
+    with Engine(96, 80, 5) as eng:
+        eng.upload_v(x)
+        np.random.seed(4)
+        res = mur(x.copy(), 5, distance_type="eu", min_iter=8, max_iter=8, engine=eng)
+    np.random.seed(4)
+    ref = R.mur(x.copy(), 5, distance_type="eu", min_iter=8, max_iter=8)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=OBJ_RTOL)
