@@ -29,7 +29,7 @@ def test_aoadmm_converges_at_reference_iteration():
     from nmf_amd.ao_admm import ao_admm
     z, meta, v, res = run_fixture("aoadmm_eu_converge", ao_admm)
     assert int(z["stop_rule"]) == 2
-    assert abs(res.i - int(z["i"])) <= 1, (res.i, int(z["i"]))
+    assert res.i == int(z["i"]), (res.i, int(z["i"]))      # (the firing decrease clears tol2 by 34x the objective's rounding error)
     assert wh_error(res.w, res.h, z["w"], z["h"], v) < WH_TOL
 
 

@@ -148,7 +148,20 @@ def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
     ref = R.mur(v.astype(np.float64), 36, **kw)
     assert ref.trace["stop_rule"] == 2 and ref.i < 599
     assert out["f32"].i == ref.i
+    # this tol2 sits 2e-6 from the firing decrease (0.004998 against 5e-3): at the edge of what an f32-grade objective
+    # resolves, so the split-bf16 mode may fire one iteration off here ...
     assert abs(out["bf16"].i - ref.i) <= 1, (out["bf16"].i, ref.i)
+    # ... and must hit the reference's iteration exactly where the rule has a margin (tol2 between two consecutive
+    # decreases, 1e-5 from either)
+    dec = -np.diff(ref.obj_history)
+    j = len(dec) - 3
+    kw["tol2"] = float(0.5 * (dec[j] + dec[j + 1]))
+    np.random.seed(3)
+    ref2 = R.mur(v.astype(np.float64), 36, **kw)
+    for precision in ("f32", "bf16"):
+        monkeypatch.setenv("NMFX_PRECISION", precision)
+        np.random.seed(3)
+        assert mur(v.copy(), 36, **kw).i == ref2.i < ref.i
 
 
 def test_grid_keeps_v_resident_and_matches_separate_calls(tmp_path):
