@@ -564,7 +564,12 @@ extern "C" int nmfx_debug_stamps(unsigned long long* out) {
 #pragma clang fp contract(fast)
 // ABL (experiments only, NMFX_EXP_ABLATE builds; results are then WRONG): bit 0 no DMA in the loop, bit 1 no bf16 split,
 // bit 2 no residual arithmetic, bit 3 no fragment reads after the first group, bit 4 no MFMAs
-template <bool WITH_OBJ, int TERMS, int ABL = 0>
+// KL = true (MUR with the KL divergence, nmf/mur.py:24-27, 40-43; W phase: X = V, Y = H, Z = W; H phase: X = V^T, Y = W^T,
+// Z = H^T): A_part = (X / (Z Y + 1e-9)) Y^T.  The product Z Y comes first (the residual product's transposed reads), the
+// quotient is formed in registers -- accumulator register 4 a + c sits on the lane that holds the same element of X in the
+// operand layout (see above), so it is split to bf16 where it stands and used as the A operand of the second product -- and
+// with WITH_OBJ the objective term x log(x / zy) [inf, nan -> 0] - x + zy (nmf/utils.py:21-26) comes from the same registers.
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -576,7 +581,8 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     if (*flag) return;
     constexpr int KP = 64;
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = 2 * YBUF, VRING = 4, VSLOT = 8192;
-    constexpr int NA = 2, ND = WITH_OBJ ? 2 : 0, NS = NA + ND;
+    constexpr bool WITH_D = WITH_OBJ || KL;            // the product Z Y is formed
+    constexpr int NA = 2, ND = (WITH_OBJ && !KL) ? 2 : 0, NS = NA + ND;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
-    const bool do_gram = (int)blockIdx.x < ng;         // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
+    const bool do_gram = !KL && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
@@ -673,11 +679,11 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //    of group g also guarantees V(g + 1), whose reads and split run between the MFMAs of group g into the other
     //    register set (the group loop is unrolled by two, the sets alternate).  The slot of V(g) is free at that barrier
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
-    constexpr bool PIPE = WITH_OBJ;
-    constexpr bool EARLY = !WITH_OBJ;
+    constexpr bool PIPE = WITH_OBJ && !KL;
+    constexpr bool EARLY = !PIPE;
     constexpr int VAHEAD = VRING;                      // groups requested before the loop
-    Frag8 zh[WITH_OBJ ? 4 : 1], zl[WITH_OBJ ? 4 : 1];  // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
-    if (WITH_OBJ) {                                    // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
+    Frag8 zh[WITH_D ? 4 : 1], zl[WITH_D ? 4 : 1];      // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
+    if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + n31) * KP + 16 * s + 8 * b);
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int a = 0; a < VAHEAD; ++a) if (g0 + a < g1) issue_v();
     }
-    if (WITH_OBJ) {
+    if (WITH_D) {
         if (yrole) dma_wait_le<4>(); else dma_wait_le<32>();      // (an upper bound of the DMAs issued above: the Z loads are older)
 #pragma unroll
         for (int s = 0; s < 4; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
@@ -732,10 +738,10 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     auto carried_stage = [&](f32x16& d, bool dma_on) {
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            d = MFMA32X(fh[1][ss], zh[WITH_OBJ ? 2 + ss : 0], d);
-            d = MFMA32X(fl[1][ss], zh[WITH_OBJ ? 2 + ss : 0], d);
+            d = MFMA32X(fh[1][ss], zh[WITH_D ? 2 + ss : 0], d);
+            d = MFMA32X(fl[1][ss], zh[WITH_D ? 2 + ss : 0], d);
             if (ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(0); NMFX_FENCE(); }
-            d = MFMA32X(fh[1][ss], zl[WITH_OBJ ? 2 + ss : 0], d);
+            d = MFMA32X(fh[1][ss], zl[WITH_D ? 2 + ss : 0], d);
         }
     };
     // one group: `cur` holds V(grp) (PIPE: filled during the previous group), `nxt` receives V(grp + 1) (PIPE)
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             } else if (!(PIPE && st == NS - 1)) {      // (PIPE: the last stage is carried over the barrier)
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
-                    const int s = WITH_OBJ ? 2 * (st - NA) + ss : 0;
+                    const int s = WITH_D ? 2 * (st - NA) + ss : 0;
                     d = MFMA32X(fh[set][ss], zh[s], d);
                     d = MFMA32X(fl[set][ss], zh[s], d);
                     if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
@@ -881,6 +887,118 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         ycur ^= 1;
         vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
     };
+    // ---- KL: product, quotient, product; one register set, the slot of V refilled as soon as it is in registers ----
+    auto group_kl = [&](int grp, VRegs& cur) {
+        if (yrole) dma_wait_le<0>();
+        else {
+            const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
+            if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        }
+        __syncthreads();
+        if (yrole) { if (grp + 1 < g1) issue_y(); }
+        const unsigned char* ybuf = smem + ycur * YBUF;
+        const unsigned char* vt = vring + vcur * VSLOT;
+        auto issue_d = [&](int half, int set) {        // factors 16 s .. + 15 (s = 2 half, 2 half + 1) of the wave's 32 columns, transposed
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int s = 2 * half + ss;
+                const unsigned char* t0 = ybuf + tro[0] + s * 2048;
+                const unsigned char* t1 = ybuf + tro[1] + s * 2048;
+                const uint2 h0 = lds_read_tr(t0), h1 = lds_read_tr(t1);
+                const uint2 l0 = lds_read_tr(t0 + YT), l1 = lds_read_tr(t1 + YT);
+                fh[set][ss].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                fl[set][ss].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        };
+        auto issue_a = [&](int ks, int set) {          // Y rows (factors) 32 t + n31, columns of k-step ks
+            const unsigned char* ys = ybuf + yrow[ks];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fh[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096);
+                fl[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096 + YT);
+            }
+        };
+        auto d_stage = [&](int half, int set, f32x16& d) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int s = WITH_D ? 2 * half + ss : 0;
+                d = MFMA32_BF16(fh[set][ss], zh[s], d);
+                d = MFMA32_BF16(fl[set][ss], zh[s], d);
+                d = MFMA32_BF16(fh[set][ss], zl[s], d);
+                if (TERMS >= 4) d = MFMA32_BF16(fl[set][ss], zl[s], d);
+            }
+        };
+        read_va(vt, cur.va);
+        issue_d(0, 0);
+        NMFX_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the V tile is in registers: its slot can be refilled
+        __syncthreads();
+        if (!yrole && grp + VRING < g1) issue_v();
+        f32x16& d = cur.d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        issue_d(1, 1);
+        NMFX_FENCE();
+        d_stage(0, 0, d);
+        NMFX_FENCE();
+        issue_a(0, 0);
+        NMFX_FENCE();
+        d_stage(1, 1, d);
+        NMFX_FENCE();
+        {   // quotient x / (zy + 1e-9) where the accumulator stands (v_rcp_f32, 1 ulp, instead of an IEEE division)
+            float4 qa[2][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 x4 = cur.va[a >> 1][a & 1];
+                qa[a >> 1][a & 1] = make_float4(x4.x * __builtin_amdgcn_rcpf(d[4 * a] + 1e-9f), x4.y * __builtin_amdgcn_rcpf(d[4 * a + 1] + 1e-9f),
+                                                x4.z * __builtin_amdgcn_rcpf(d[4 * a + 2] + 1e-9f), x4.w * __builtin_amdgcn_rcpf(d[4 * a + 3] + 1e-9f));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) split8(qa[s2][0], qa[s2][1], cur.vh[s2], cur.vl[s2]);
+        }
+        NMFX_FENCE();
+        // The objective terms x log(x / zy) [inf, nan -> 0] - x + zy (utils.py:23-26) of the same registers ride between the
+        // MFMAs of the second product, half of them per k-step: in the serial section above (matrix pipe idle: the second
+        // product waits for the quotient) they cost the W phase a third of its time.  v_rcp_f32 / v_log_f32 instead of an
+        // IEEE division and logf: 0 * log(0 / p), x * log(x / 0) and 0 / 0 still come out as nan / inf / nan and are zeroed
+        // exactly like utils.py:24 does.
+        auto kl_terms = [&](int half) {
+            float k0 = 0.f, k1 = 0.f;
+#pragma unroll
+            for (int a = 2 * half; a < 2 * half + 2; ++a) {
+                const float4 x4 = cur.va[a >> 1][a & 1];
+                const float vv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float pv = d[4 * a + c];
+                    float t = vv[c] * (__builtin_amdgcn_logf(vv[c] * __builtin_amdgcn_rcpf(pv)) * 0.69314718055994531f);
+                    t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                    if (c & 1) k1 += (t - vv[c]) + pv; else k0 += (t - vv[c]) + pv;
+                }
+            }
+            osum += (double)(k0 + k1);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int set = ks & 1;
+            if (ks == 0) issue_a(1, 1);
+            NMFX_FENCE();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vh[ks], fh[set][t], accA[t]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vl[ks], fh[set][t], accA[t]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vh[ks], fl[set][t], accA[t]);
+            if (TERMS >= 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vl[ks], fl[set][t], accA[t]);
+            }
+            if (WITH_OBJ) { kl_terms(ks); asm volatile("" : "+v"(osum)); }
+            NMFX_FENCE();
+        }
+        ycur ^= 1;
+        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+    };
     VRegs P, Q;
     if (PIPE) {
 #pragma unroll
@@ -900,9 +1018,13 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
-    for (int grp = g0; grp < g1; grp += 2) {
-        group(grp, P, Q);
-        if (grp + 1 < g1) group(grp + 1, Q, P);
+    if (KL) {
+        for (int grp = g0; grp < g1; ++grp) group_kl(grp, P);
+    } else {
+        for (int grp = g0; grp < g1; grp += 2) {
+            group(grp, P, Q);
+            if (grp + 1 < g1) group(grp + 1, Q, P);
+        }
     }
     if (PIPE && g0 < g1) {                             // the last group's carried stage and residual
         if ((g1 - g0) & 1) { carried_stage(P.d, false); residual(P); } else { carried_stage(Q.d, false); residual(Q); }
@@ -952,7 +1074,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < 8; ++w) t += red[w];
-            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * t;
+            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (KL ? 1.0 : 0.5) * t;
         }
     }
 }
@@ -1354,15 +1476,15 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
     return NMFX_OK;
 }
 
-template <bool OBJ, int TERMS>
+template <bool OBJ, int TERMS, bool KL = false>
 static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
                           const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                           const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
-    auto kern = xyt32_bf16_kernel<OBJ, TERMS>;
+    auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL>;
 #ifdef NMFX_EXP_ABLATE
-    if (OBJ && TERMS == 3) {
+    if (OBJ && TERMS == 3 && !KL) {
         static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
         switch (abl) {
             case 1: kern = xyt32_bf16_kernel<OBJ, TERMS, 1>; break;
@@ -1402,9 +1524,15 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
         return launch_xyt_t<128, true, false, 3, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
     }
     if (E->kp == 64) {
-        if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
-        // Euclidean products with k padded to 64: the 32-row kernel (NMFX_XYT16=1 keeps the 16-row form, for A/B runs)
+        // k padded to 64: the 32-row kernel (NMFX_XYT16=1 keeps the 16-row form, for A/B runs)
         static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        if (kl && tiled && !rows16) {
+#define NMFX_X32K(OBJ_, T_) launch_xyt32_t<OBJ_, T_, true>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, nullptr, ng)
+            if (terms == 3) return obj ? NMFX_X32K(true, 3) : NMFX_X32K(false, 3);
+            return obj ? NMFX_X32K(true, 4) : NMFX_X32K(false, 4);
+#undef NMFX_X32K
+        }
+        if (kl) return obj ? NMFX_XYT(64, true, true) : NMFX_XYT(64, false, true);
         if (tiled && gram_part && !rows16) {
 #define NMFX_X32(OBJ_, T_) launch_xyt32_t<OBJ_, T_>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
             if (terms == 3) return obj ? NMFX_X32(true, 3) : NMFX_X32(false, 3);

@@ -14,6 +14,8 @@
 #include "nmfx_internal.h"
 #include "kernels_small.h"
 
+static int launch_h_row_sums(nmfx_engine* E);      // (defined next to the split-bf16 path below)
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // --------------------------------------------------------------------------
@@ -256,10 +258,7 @@ int nmfx_mur_kl_phase_a(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[j & 1];
     float* Wnew = E->W[(j + 1) & 1];
     int rc;
-    { ProfScope ps(E, "row_sums");        // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
-      hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)E->kp), dim3(256), 0, E->stream, E->H, E->np, E->np,
-                         E->HHt, &E->state->flag);
-      NMFX_HIP(hipGetLastError()); }
+    if ((rc = launch_h_row_sums(E))) return rc;      // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
     if ((rc = nmfx_launch_wphase(E, Wold, true, true, true))) return rc;
     { ProfScope ps(E, "w_update");
       const int64_t count = E->mp * E->kp;
@@ -315,15 +314,54 @@ __global__ __launch_bounds__(256) void col_sums_part_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(128) void col_sums_final_kernel(const float* __restrict__ part, int nblk, int kp,
+// out[j] = sum_b part[b][j]: one wavefront per j (lane-strided partial sums, then the shuffle tree: fixed order).  The
+// single 128-thread block that walked all partials serially took 30 us of the 41 us "row_sums" of config 4.
+__global__ __launch_bounds__(256) void col_sums_final_kernel(const float* __restrict__ part, int nblk, int kp,
                                                              float* __restrict__ out, const int* __restrict__ flag)
 {
     if (*flag) return;
-    const int j = threadIdx.x;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= kp) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * kp + j];
-    out[j] = s;
+    for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * kp + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[j] = s;
+}
+
+// part[chunk][j] = sum of 4096 columns of row j of X (row sums of H in two stages: kp blocks of one row each streamed
+// 64 KiB through 256 threads -- 64 blocks, latency bound, 40 us at n = 16384)
+__global__ __launch_bounds__(256) void row_sums_part_kernel(const float* __restrict__ X, int64_t cols, int64_t ld, int kp,
+                                                            float* __restrict__ part, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    __shared__ float sh[4];
+    const int64_t c0 = (int64_t)blockIdx.x * 4096;
+    const float* p = X + (int64_t)blockIdx.y * ld;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t c = c0 + (threadIdx.x + 256 * u) * 4;
+        if (c < cols) { const float4 v = *reinterpret_cast<const float4*>(p + c); s += (v.x + v.y) + (v.z + v.w); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * kp + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// HHt[0 .. kp) = row sums of H (b = 1 H^T, mur.py:26): two small launches; scratch: the head of B_part (dead between the
+// pack of one iteration and the H phase of the next)
+static int launch_h_row_sums(nmfx_engine* E) {
+    ProfScope ps(E, "row_sums");
+    const int nchunk = (int)((E->np + 4095) / 4096);
+    hipLaunchKernelGGL(row_sums_part_kernel, dim3((unsigned)nchunk, (unsigned)E->kp), dim3(256), 0, E->stream, E->H, E->np, E->np,
+                       E->kp, E->B_part, &E->state->flag);
+    hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream, E->B_part, nchunk, E->kp,
+                       E->HHt, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
@@ -334,10 +372,7 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
     if (!E->ht_ready) { if ((rc = nmfx_bf16_images_h(E, true))) return rc; E->ht_ready = true; }
-    { ProfScope ps(E, "row_sums");        // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
-      hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)E->kp), dim3(256), 0, E->stream, E->H, E->np, E->np,
-                         E->HHt, &E->state->flag);
-      NMFX_HIP(hipGetLastError()); }
+    if ((rc = launch_h_row_sums(E))) return rc;      // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
     if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", true, 3))) return rc;
     { ProfScope ps(E, "w_update");
       const int64_t count = E->mp * E->kp;
@@ -352,8 +387,8 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
       float* part = E->B_part;                                   // scratch: the exact-f32 H phase's slabs are unused here
       hipLaunchKernelGGL(col_sums_part_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, Wnew, E->kp, part,
                          &E->state->flag);
-      hipLaunchKernelGGL(col_sums_final_kernel, dim3(1), dim3(128), 0, E->stream, part, nblk, E->kp, E->G_part,
-                         &E->state->flag);
+      hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream, part, nblk, E->kp,
+                         E->G_part, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     return nmfx_bf16_pack_t(E, E->G_part, 1, (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
