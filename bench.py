@@ -35,6 +35,10 @@ os.environ.setdefault("NMF_AMD_QUIET", "1")
 
 import numpy as np  # noqa: E402
 
+from nmf_amd.synth import limit_blas_threads  # noqa: E402
+
+HOST_THREADS = limit_blas_threads()      # BLAS pool = the CPUs the container may use (see nmf_amd.synth.usable_cpus)
+
 M, N, K = 16384, 8192, 64
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
@@ -198,6 +202,7 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
         eng.synchronize()
         t0 = time.perf_counter()
         queue(eng, warmup, steps)
+        t_queued = time.perf_counter() - t0
         eng.synchronize()
         dt = (time.perf_counter() - t0) / steps
         _, _, n_obj = eng.state()
@@ -224,7 +229,7 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             prof[dom]["us_per_launch"] = round(eng.profile_repeat(dom, 20, repeat_dist) * 1e3, 2)
         dsec = prof[dom]["us_per_launch"] * 1e-6
         return {"config": name, "workload": workload, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
-                "warmup": warmup, "precision": eng.precision(),
+                "warmup": warmup, "precision": eng.precision(), "host_ms_to_queue_all_steps": t_queued * 1e3,
                 "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
                 "dominant_kernel": {"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
@@ -286,6 +291,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch
     import torch.distributed as dist
+    limit_blas_threads(HOST_THREADS)              # (torch's OpenMP pool too, now that it is loaded)
+    torch.set_num_threads(HOST_THREADS)
     from nmf_amd.synth import planted_matrix      # (the oracle is imported by the cpu_baseline leg only)
     from nmf_amd import dist as nd
 
@@ -480,9 +487,9 @@ def main():
         parity = parity_block(v_full, par_gpu[0], par_gpu[1], par_gpu[2], w_r, h_r, obj_r)
         if not os.environ.get("NMFX_BENCH_NOASSERT"):
             assert parity["wh_rel_err"] < 1e-4 and parity["obj_max_rel_diff"] < 2e-4, f"full-size parity failed: {parity}"
-        cpu = {"value": val, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"full {m}x{n} k={k} shape, {args.cpu_iters} iterations after 1 warm-up, "
-                         f"numpy {np.__version__} default BLAS threading"}
+        cpu = {"value": val, "unit": "iter/s", "cores": HOST_THREADS, "kind": "port",
+               "sample": f"full {m}x{n} k={k} shape, {args.cpu_iters} iterations after 1 warm-up, numpy {np.__version__}, "
+                         f"BLAS pool of {HOST_THREADS} threads = the container's CPU quota (os.cpu_count() = {os.cpu_count()})"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3

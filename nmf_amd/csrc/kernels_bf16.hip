@@ -569,7 +569,11 @@ extern "C" int nmfx_debug_stamps(unsigned long long* out) {
 // quotient is formed in registers -- accumulator register 4 a + c sits on the lane that holds the same element of X in the
 // operand layout (see above), so it is split to bf16 where it stands and used as the A operand of the second product -- and
 // with WITH_OBJ the objective term x log(x / zy) [inf, nan -> 0] - x + zy (nmf/utils.py:21-26) comes from the same registers.
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false>
+// KP = 128 (config 3 and 5): four factor tiles, eight k-steps of the residual product, Y images of 2 x 16 KiB per group
+// (double buffered: 64 KiB), V ring 3 deep; stages of (k-step, pair of factor tiles) so that the fragment registers stay
+// at 2 x 16; no cross-group pipeline (its second V register set does not fit next to 64 accumulator and 64 Z registers),
+// no Gram by-product, Euclidean only.
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -579,10 +583,13 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 {
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
-    constexpr int KP = 64;
-    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = 2 * YBUF, VRING = 4, VSLOT = 8192;
+    static_assert(KP == 64 || (KP == 128 && !KL && ABL == 0), "KP = 128: Euclidean products only");
+    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = 2 * YBUF, VRING = (KP == 64) ? 4 : 3, VSLOT = 8192;
+    constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
+    constexpr int NK = KP / 16;                        // k-steps of the product Z Y
+    constexpr int YPW = 2 * (KP / 8) / 4;              // Y pieces (8 rows x 128 B) per loader wave and group
     constexpr bool WITH_D = WITH_OBJ || KL;            // the product Z Y is formed
-    constexpr int NA = 2, ND = (WITH_OBJ && !KL) ? 2 : 0, NS = NA + ND;
+    constexpr int NA = 2 * NTP, ND = (WITH_OBJ && !KL) ? NK / 2 : 0, NS = NA + ND;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -599,12 +606,12 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //   waves 0..3: the V tile [32][64] of row group lw (8 pieces of 4 rows x 256 B), VRING (- 1) groups ahead
     const bool yrole = wave >= 4;
     const int lw = wave & 3;
-    const int ytile = lw >> 1, p0 = (lw & 1) * 4;
+    const int ytile = (lw * YPW) / (KP / 8), p0 = (lw * YPW) % (KP / 8);
     const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
     unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * 128ull;
-    unsigned yoffs[4];
+    unsigned yoffs[YPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < YPW; ++i) {
         const int row = 8 * (p0 + i) + (lane >> 3), pos = lane & 7, chunk = pos ^ yswz32(row);
         yoffs[i] = (unsigned)(((int64_t)row * ldy + 8 * chunk) * 2);
     }
@@ -619,7 +626,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const unsigned vdstA = smem0 + VOFF + lw * (VRING * VSLOT), vdstB = vdstA + 4096;
     int yq = 0, vq = 0;
     auto issue_y = [&]() {
-        dma_run4(ybase, smem0 + yq * YBUF + ydst, yoffs[0], yoffs[1], yoffs[2], yoffs[3]);
+#pragma unroll
+        for (int i = 0; i < YPW; i += 4)
+            dma_run4(ybase, smem0 + yq * YBUF + ydst + i * 1024, yoffs[i], yoffs[i + 1], yoffs[i + 2], yoffs[i + 3]);
         ybase += 128ull; yq ^= 1;
     };
     auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
@@ -661,12 +670,12 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     }
     const unsigned char* vring = smem + VOFF + rg * (VRING * VSLOT);
 
-    f32x16 accA[2];
+    f32x16 accA[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
-    const bool do_gram = !KL && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
+    const bool do_gram = KP == 64 && !KL && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0;
@@ -679,13 +688,13 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //    of group g also guarantees V(g + 1), whose reads and split run between the MFMAs of group g into the other
     //    register set (the group loop is unrolled by two, the sets alternate).  The slot of V(g) is free at that barrier
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
-    constexpr bool PIPE = WITH_OBJ && !KL;
+    constexpr bool PIPE = WITH_OBJ && !KL && KP == 64;
     constexpr bool EARLY = !PIPE;
     constexpr int VAHEAD = VRING;                      // groups requested before the loop
-    Frag8 zh[WITH_D ? 4 : 1], zl[WITH_D ? 4 : 1];      // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
+    Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
     if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NK; ++s) {
             zh[s].u = *reinterpret_cast<const uint4*>(Zhi + (r0 + n31) * KP + 16 * s + 8 * b);
             zl[s].u = *reinterpret_cast<const uint4*>(Zlo + (r0 + n31) * KP + 16 * s + 8 * b);
         }
@@ -696,9 +705,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         for (int a = 0; a < VAHEAD; ++a) if (g0 + a < g1) issue_v();
     }
     if (WITH_D) {
-        if (yrole) dma_wait_le<4>(); else dma_wait_le<32>();      // (an upper bound of the DMAs issued above: the Z loads are older)
+        if (yrole) dma_wait_le<YPW>(); else dma_wait_le<8 * VRING>();      // (an upper bound of the DMAs issued above: the Z loads are older)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
+        for (int s = 0; s < NK; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
     }
     int ycur = 0, vcur = 0;
 #ifdef NMFX_EXP_STAMPS
@@ -768,8 +777,8 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         const unsigned char* vtn = vring + (vcur == VRING - 1 ? 0 : vcur + 1) * VSLOT;
         auto issue = [&](int st, int set) {
             if ((ABL & 8) && grp > g0 + 1) { pinu(fh[set][0].u); pinu(fh[set][1].u); pinu(fl[set][0].u); pinu(fl[set][1].u); return; }
-            if (st < NA) {                             // Y rows (factors) 32 t + n31, columns of k-step st
-                const unsigned char* ys = ybuf + yrow[st];
+            if (st < NA) {                             // Y rows (factors) 32 (2 tp + t) + n31, columns of k-step st / NTP
+                const unsigned char* ys = ybuf + yrow[st / NTP] + (st % NTP) * 8192;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     fh[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096);
@@ -818,16 +827,17 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             if (st + 1 < NS) issue(st + 1, set ^ 1);
             NMFX_FENCE();
             if (st < NA) {
+                const int ks = st / NTP, t0 = 2 * (st % NTP);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vh[st], fh[set][t], accA[t]);
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vh[ks], fh[set][t], accA[t0 + t]);
                 if (PIPE) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fh[set][t], accA[t]);
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vl[ks], fh[set][t], accA[t0 + t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vh[st], fl[set][t], accA[t]);
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vh[ks], fl[set][t], accA[t0 + t]);
                 if (TERMS >= 4) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(cur.vl[st], fl[set][t], accA[t]);
+                    for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vl[ks], fl[set][t], accA[t0 + t]);
                 }
             } else if (!(PIPE && st == NS - 1)) {      // (PIPE: the last stage is carried over the barrier)
 #pragma unroll
@@ -880,6 +890,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
                 }
             }
         }
+        if (WITH_OBJ && !PIPE) residual(cur);          // (PIPE: one group late, see above)
         NMFX_STAMP(ts4);
 #ifdef NMFX_EXP_STAMPS
         acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_early += ts3 - ts2; acc_mfma += ts4 - ts3;
@@ -1041,20 +1052,26 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     }
 #endif
 
-    // ---- the two column halves of a row group exchange partial A tiles: wave (rg, hh) finishes factor tile hh ----
+    // ---- the two column halves of a row group exchange partial A tiles: wave (rg, hh) finishes the factor tiles NTP hh .. ----
     __syncthreads();                                   // everybody is done with the LDS tiles
     {
-        float* xch = reinterpret_cast<float*>(smem);   // slot (rg, t): [16 registers][64 lanes]
-        float* mine = xch + (rg * 2 + (1 - hh)) * 1024 + lane;
+        float* xch = reinterpret_cast<float*>(smem);   // slot (rg, tile): [16 registers][64 lanes]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r * 64] = hh ? accA[0][r] : accA[1][r];
+        for (int u = 0; u < NTP; ++u) {
+            float* mine = xch + (rg * NT + NTP * (1 - hh) + u) * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = hh ? accA[u][r] : accA[NTP + u][r];
+        }
         __syncthreads();
-        const float* theirs = xch + (rg * 2 + hh) * 1024 + lane;
-        float* out = Apart + ((int64_t)sp * R + r0) * KP + 32 * hh + n31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float own = hh ? accA[1][r] : accA[0][r];
-            out[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * b) * KP] = own + theirs[r * 64];
+        for (int u = 0; u < NTP; ++u) {
+            const float* theirs = xch + (rg * NT + NTP * hh + u) * 1024 + lane;
+            float* out = Apart + ((int64_t)sp * R + r0) * KP + 32 * (NTP * hh + u) + n31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float own = hh ? accA[NTP + u][r] : accA[u][r];
+                out[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * b) * KP] = own + theirs[r * 64];
+            }
         }
     }
     if (do_gram) {
@@ -1068,7 +1085,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     if (WITH_OBJ) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
-        double* red = reinterpret_cast<double*>(smem + 8 * 4096);      // behind the exchange slots
+        double* red = reinterpret_cast<double*>(smem + 4 * NT * 4096);      // behind the exchange slots
         if (lane == 0) red[wave] = osum;
         __syncthreads();
         if (tid == 0) {
@@ -1476,15 +1493,15 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
     return NMFX_OK;
 }
 
-template <bool OBJ, int TERMS, bool KL = false>
+template <bool OBJ, int TERMS, bool KL = false, int KP = 64>
 static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
                           const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                           const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
-    auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL>;
+    auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP>;
 #ifdef NMFX_EXP_ABLATE
-    if (OBJ && TERMS == 3 && !KL) {
+    if (OBJ && TERMS == 3 && !KL && KP == 64) {
         static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
         switch (abl) {
             case 1: kern = xyt32_bf16_kernel<OBJ, TERMS, 1>; break;
@@ -1542,6 +1559,15 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
     }
     if (kl) return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
+    {   // Euclidean products with k padded to 128: the 32-row kernel as well (NMFX_XYT16=1: the 16-row form)
+        static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        if (tiled && !rows16) {
+#define NMFX_X32B(OBJ_, T_) launch_xyt32_t<OBJ_, T_, false, 128>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, nullptr, ng)
+            if (terms == 3) return obj ? NMFX_X32B(true, 3) : NMFX_X32B(false, 3);
+            return obj ? NMFX_X32B(true, 4) : NMFX_X32B(false, 4);
+#undef NMFX_X32B
+        }
+    }
     return obj ? NMFX_XYT(128, true, false) : NMFX_XYT(128, false, false);
 #undef NMFX_XYT2
 #undef NMFX_XYT

@@ -22,3 +22,36 @@ def planted_matrix(m, n, k, seed=0, dtype=np.float32, noise=0.01, rows=None):
             blk = (left[lo:hi] @ right) / k + noise * nz[lo - a:hi - a]
             out[lo - r0:hi - r0] = blk.astype(dtype)
     return out
+
+
+def usable_cpus():
+    """CPUs this process may actually use: os.cpu_count() capped by the cgroup's CPU quota (cpu.max).  On a box that
+    shows 256 CPUs to a container with a 16-CPU quota, a 256-thread BLAS pool burns the quota in spinning idle threads
+    (OpenBLAS workers busy-wait ~100 ms after every call) and the kernel then throttles EVERY thread of the process for
+    the rest of the 100 ms period -- seen as one 70-80 ms hole in a GPU loop that had been queued right after a numpy
+    call (cpu.stat: nr_throttled + 1).  bench.py and the tests size their BLAS pools with this."""
+    import os
+    n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return n
+
+
+def limit_blas_threads(n=None):
+    """Cap the BLAS / OpenMP pools of this process at `n` (default usable_cpus()); returns the count in effect."""
+    n = n or usable_cpus()
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=n)
+    except Exception:  # noqa: BLE001  (threadpoolctl missing: leave the pools alone)
+        pass
+    return n

@@ -14,6 +14,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's BLAS pool = the CPUs the container may use: a 256-thread pool under a 16-CPU quota gets the whole
+    # process throttled (nmf_amd.synth.usable_cpus), which made the full-size oracle runs several times slower
+    from nmf_amd.synth import limit_blas_threads
+    limit_blas_threads()
 
 
 def load_golden(name):

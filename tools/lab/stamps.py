@@ -28,7 +28,10 @@ for kind, name in ((1, "W phase (objective)"), (0, "H phase")):
     a = out[kind].astype(np.float64)
     tot, rt = a[..., 4], a[..., 5]
     print(name, "median block: %.0f cycles, %.1f us, clock %.2f GHz" % (np.median(tot), np.median(rt) / 100.0, np.median(tot / rt) / 10.0))
+    blk = rt.max(axis=1) / 100.0
+    print("   block durations (us): min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f; the 8 slowest blocks: %s"
+          % (blk.min(), np.percentile(blk, 10), np.median(blk), np.percentile(blk, 90), blk.max(), np.argsort(blk)[-8:].tolist()))
     for role, ws in (("V loaders (waves 0-3)", slice(0, 4)), ("Y loaders (waves 4-7)", slice(4, 8))):
         seg = np.median(a[:, ws, :4].reshape(-1, 4), axis=0)
         print("   %-22s wait+barrier %6.0f  head (LDS reads + split) %6.0f  early barrier %6.0f  MFMA stages %6.0f  | per group: %s"
-              % (role, *seg, np.round(seg / 32.0, 0) if kind == 0 else np.round(seg / 64.0, 0)))
+              % (role, *seg, np.round(seg / 64.0, 0)))
