@@ -29,6 +29,8 @@ def test_config2_mur_eu_16384x8192_k64_vs_oracle():
     ref = R.mur(v, k, **kw)
     assert res.i == ref.i == iters - 1 and len(res.obj_history) == iters + 1
     err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
     direct = direct_objective(v, res.w, res.h, "eu")
@@ -48,6 +50,8 @@ def test_config4_mur_kl_32768x16384_k64_vs_oracle():
     ref = R.mur(v, k, **kw)
     assert res.i == ref.i == iters - 1
     err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-3)
     direct = direct_objective(v, res.w, res.h, "kl")
@@ -73,6 +77,8 @@ def test_config3_aoadmm_l1n_16384x8192_k128_vs_oracle():
     assert res.i == ref.i == iters - 1
     assert [tuple(int(c) for c in row) for row in inner] == [tuple(p) for p in ref.trace["inner"]]
     err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
     direct = direct_objective(v, res.w, res.h, "eu")
@@ -91,6 +97,8 @@ def test_config5_shard_mur_eu_16384x16384_k128_vs_oracle():
     np.random.seed(0)
     ref = R.mur(v, k, **kw)
     err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
     direct = direct_objective(v, res.w, res.h, "eu")
@@ -110,5 +118,7 @@ def test_admm_fixed_rho_8192x4096_k64_vs_oracle():
     np.random.seed(4)
     ref = R.admm(v, k, **kw)
     err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
