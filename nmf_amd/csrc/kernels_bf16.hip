@@ -19,6 +19,7 @@
 #include "nmfx_internal.h"
 #include "kernels_small.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Terms of a split product x y with x = xh + xl + ex, y = yh + yl + ey (|xl| <= 2^-8 |x|, |ex| <= 2^-16 |x|):
 //   4: xh yh + xh yl + xl yh + xl yl;
@@ -34,6 +35,18 @@
 // compared, nothing is computed from it (3 vs 4 terms moves it by ~1e-8 relative).
 // NMFX_BF16_TERMS=4 in the environment forces 4 for every product that is fed back.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// t_i = x_i * log2(q_i), i = 0..3, with v_mul_legacy_f32 (0 * anything, inf and nan included, = 0).  ONE asm block: the four
+// logarithms first, then the products -- a transcendental's result must not be consumed by the very next VALU instruction
+// on this part, and the hazard recogniser does not look inside inline asm (a lone `v_mul_legacy_f32` right behind a compiler
+// generated `v_log_f32` read a stale register).
+__device__ __forceinline__ void xlog2_legacy4(const float4& x, float q0, float q1, float q2, float q3,
+                                              float& t0, float& t1, float& t2, float& t3) {
+    asm("v_log_f32 %0, %4\n\tv_log_f32 %1, %5\n\tv_log_f32 %2, %6\n\tv_log_f32 %3, %7\n\t"
+        "v_mul_legacy_f32 %0, %8, %0\n\tv_mul_legacy_f32 %1, %9, %1\n\tv_mul_legacy_f32 %2, %10, %2\n\tv_mul_legacy_f32 %3, %11, %3"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+}
 union Frag8 { uint4 u; bf16x8 v; };
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
 
@@ -584,7 +597,8 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
     static_assert(KP == 64 || (KP == 128 && !KL && ABL == 0), "KP = 128: Euclidean products only");
-    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = 2 * YBUF, VRING = (KP == 64) ? 4 : 3, VSLOT = 8192;
+    constexpr int YR = KL ? 3 : 2;                     // Y ring (KL: the second product runs one group behind the first)
+    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
     constexpr int YPW = 2 * (KP / 8) / 4;              // Y pieces (8 rows x 128 B) per loader wave and group
@@ -629,12 +643,12 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int i = 0; i < YPW; i += 4)
             dma_run4(ybase, smem0 + yq * YBUF + ydst + i * 1024, yoffs[i], yoffs[i + 1], yoffs[i + 2], yoffs[i + 3]);
-        ybase += 128ull; yq ^= 1;
+        ybase += 128ull; yq = (yq == YR - 1) ? 0 : yq + 1;
     };
     auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
         if (yrole) {
             if (st < 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * st], yoffs[2 * st + 1]);
-            if (st == 1) { ybase += 128ull; yq ^= 1; }
+            if (st == 1) { ybase += 128ull; yq = (yq == YR - 1) ? 0 : yq + 1; }
         } else {
             dma_run2_nt(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
             if (st == 3) { vbaseA += 32768ull; vbaseB += 32768ull; vq = (vq == VRING - 1) ? 0 : vq + 1; }
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const bool do_gram = KP == 64 && !KL && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    double osum = 0.0;
+    double osum = 0.0, olog = 0.0;                     // (olog: KL, the sum of x log2(q))
     // Two loop structures.
     //  !WITH_OBJ (H phase and the other objective-free products; bound by the bytes in flight): a V slot is refilled as
     //    soon as every wave holds its tile in registers, VRING groups ahead, at the price of a second barrier per group.
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
     constexpr bool PIPE = WITH_OBJ && !KL && KP == 64;
     constexpr bool EARLY = !PIPE;
-    constexpr int VAHEAD = VRING;                      // groups requested before the loop
+    constexpr int VAHEAD = KL ? 2 : VRING;             // groups requested before the loop
     Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
     if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
@@ -717,7 +731,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #define NMFX_FENCE() __builtin_amdgcn_sched_barrier(0)
     // a wave's V tile of one group: the f32 values (row n31, columns 16 s + 8 b + 4 e ..), their split A operands, and the
     // product tile Z Y of the same group (register 4 a + c <-> va[a >> 1][a & 1], component c)
-    struct VRegs { Frag8 vh[2], vl[2]; float4 va[2][2]; f32x16 d; };
+    struct VRegs { Frag8 vh[2], vl[2]; float4 va[2][2]; f32x16 d; unsigned slow; };
     // residual of a finished group: d[4 a + c] = (Z Y)[row n31][column 32 hh + 8 a + 4 b + c].  PIPE: evaluated one group
     // late, right behind the next group's barrier, where it covers the latency of that group's first fragment reads (at
     // the end of its own group it was a serial tail of ~250 cycles -- MFMA result, 16 dependent adds, an f64 add -- with
@@ -898,17 +912,20 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         ycur ^= 1;
         vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
     };
-    // ---- KL: product, quotient, product; one register set, the slot of V refilled as soon as it is in registers ----
-    auto group_kl = [&](int grp, VRegs& cur) {
-        if (yrole) dma_wait_le<0>();
-        else {
-            const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
-            if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
-        }
-        __syncthreads();
-        if (yrole) { if (grp + 1 < g1) issue_y(); }
-        const unsigned char* ybuf = smem + ycur * YBUF;
-        const unsigned char* vt = vring + vcur * VSLOT;
+    // ---- KL: product, quotient, product -- software-pipelined across groups ----
+    // In its first form (one register set: product Z Y, quotient + split with the matrix pipe idle, second product with the
+    // objective terms between its MFMAs, two barriers per group) a group took ~4000 cycles against 1536 of MFMA: the eight
+    // waves run in step behind the barriers, so the serial quotient section of one wave never met the MFMAs of another.
+    // Now iteration g runs  [product Z Y of group g  ||  objective terms of group g - 1]  and then
+    // [second product of group g - 1  ||  quotient + split of group g]  on two register sets (P / Q, loop unrolled by two):
+    // every VALU section has independent MFMAs around it.  Y ring of three (the second product of g - 1 reads Y(g - 1) while
+    // Y(g + 1) lands), V ring of three (V(g + 2) goes into the slot of V(g - 1) behind the barrier of group g), one barrier
+    // per group, the DMA requests in pairs between the MFMAs as in the Euclidean pipeline.
+    auto kl_iter = [&](int grp, VRegs& cur, VRegs& prv, auto do_d_t, auto do_a_t) {
+        constexpr bool DO_D = decltype(do_d_t)::value, DO_A = decltype(do_a_t)::value;
+        const unsigned char* ybuf = smem + ycur * YBUF;                              // Y(grp)
+        const unsigned char* ybp = smem + (ycur == 0 ? YR - 1 : ycur - 1) * YBUF;    // Y(grp - 1)
+        bool dma_on = false;
         auto issue_d = [&](int half, int set) {        // factors 16 s .. + 15 (s = 2 half, 2 half + 1) of the wave's 32 columns, transposed
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -921,94 +938,138 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
                 fl[set][ss].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         };
-        auto issue_a = [&](int ks, int set) {          // Y rows (factors) 32 t + n31, columns of k-step ks
-            const unsigned char* ys = ybuf + yrow[ks];
+        auto issue_a = [&](int ks, int set) {          // Y(grp - 1) rows (factors) 32 t + n31, columns of k-step ks
+            const unsigned char* ys = ybp + yrow[ks];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 fh[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096);
                 fl[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096 + YT);
             }
         };
-        auto d_stage = [&](int half, int set, f32x16& d) {
+        // Objective terms x log(x / zy) [inf, nan -> 0] - x + zy (utils.py:23-26).  The kernel is bound by VALU issue (two
+        // waves per SIMD: ~270 VALU instructions with 48 transcendentals per wave and group next to 24 MFMAs), so the terms
+        // are formed with as few instructions as the arithmetic allows:
+        //   * zy >= 2^-5 in all four registers of a chunk (signed-integer minimum of the bit patterns): there zy + 1e-9f == zy
+        //     in f32, so the quotient q of the update IS x / zy -- its logarithm is taken one group later (kl_chunk, between
+        //     the MFMAs of the next first product; q stays in the accumulator registers), multiplied with v_mul_legacy_f32
+        //     (0 * -inf = 0: the x = 0 entries that utils.py:24 zeroes), and zy - x is summed at once in packed f32;
+        //   * otherwise (small, zero or negative zy; wave-uniform branch): the exact expression with its own reciprocal,
+        //     inf / nan zeroed as utils.py:24 does, here and now, and the chunk is marked (`slow`) so that kl_chunk skips it.
+        // The sums of x log2(q) and of zy - x go to f64 separately (they cancel to second order).
+        float klog = 0.f;
+        auto kl_chunk = [&](int a) {
+            if (prv.slow & (1u << a)) return;          // (wave-uniform)
+            const float4 x4 = prv.va[a >> 1][a & 1];
+            float t0, t1, t2, t3;
+            xlog2_legacy4(x4, prv.d[4 * a], prv.d[4 * a + 1], prv.d[4 * a + 2], prv.d[4 * a + 3], t0, t1, t2, t3);
+            klog += (t0 + t1) + (t2 + t3);
+        };
+        // quotient x / (zy + 1e-9) where the accumulator stands (v_rcp_f32, 1 ulp, instead of an IEEE division)
+        float4 qa[2][2];
+        f32x2 klin2 = {0.f, 0.f};
+        auto quot = [&](int a) {
+            const float4 x4 = cur.va[a >> 1][a & 1];
+            const f32x2 x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w};
+            const f32x2 p01 = {cur.d[4 * a], cur.d[4 * a + 1]}, p23 = {cur.d[4 * a + 2], cur.d[4 * a + 3]};
+            const f32x2 e01 = p01 + 1e-9f, e23 = p23 + 1e-9f;
+            const f32x2 r01 = {__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};
+            const f32x2 r23 = {__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
+            const f32x2 q01 = x01 * r01, q23 = x23 * r23;
+            qa[a >> 1][a & 1] = make_float4(q01.x, q01.y, q23.x, q23.y);
+            if (WITH_OBJ) {
+                const int mn = min(min(__float_as_int(p01.x), __float_as_int(p01.y)), min(__float_as_int(p23.x), __float_as_int(p23.y)));
+                if (__builtin_amdgcn_ballot_w64(mn < 0x3D000000) != 0ull) {
+                    const float vv[4] = {x4.x, x4.y, x4.z, x4.w};
+                    float k0 = 0.f, k1 = 0.f;
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const int s = WITH_D ? 2 * half + ss : 0;
-                d = MFMA32_BF16(fh[set][ss], zh[s], d);
-                d = MFMA32_BF16(fl[set][ss], zh[s], d);
-                d = MFMA32_BF16(fh[set][ss], zl[s], d);
-                if (TERMS >= 4) d = MFMA32_BF16(fl[set][ss], zl[s], d);
+                    for (int c = 0; c < 4; ++c) {
+                        const float pv = cur.d[4 * a + c];
+                        float t = vv[c] * (__builtin_amdgcn_logf(vv[c] * __builtin_amdgcn_rcpf(pv)) * 0.69314718055994531f);
+                        t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                        if (c & 1) k1 += (t - vv[c]) + pv; else k0 += (t - vv[c]) + pv;
+                    }
+                    klin2.x += k0; klin2.y += k1;
+                    cur.slow |= 1u << a;
+                } else {
+                    klin2 += (p01 - x01) + (p23 - x23);
+                }
+                cur.d[4 * a] = q01.x; cur.d[4 * a + 1] = q01.y; cur.d[4 * a + 2] = q23.x; cur.d[4 * a + 3] = q23.y;
             }
         };
-        read_va(vt, cur.va);
-        issue_d(0, 0);
-        NMFX_FENCE();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the V tile is in registers: its slot can be refilled
-        __syncthreads();
-        if (!yrole && grp + VRING < g1) issue_v();
-        f32x16& d = cur.d;
+        if (DO_D) {
+            if (yrole) dma_wait_le<0>();               // Y(grp)
+            else if (grp + 1 < g1) dma_wait_le<8>();   // V(grp); V(grp + 1) may stay in flight
+            else dma_wait_le<0>();
+            __syncthreads();
+            dma_on = !(ABL & 1) && (yrole ? grp + 1 < g1 : grp + 2 < g1);
+            f32x16& d = cur.d;
+            cur.slow = 0u;
+            read_va(vring + vcur * VSLOT, cur.va);
+            issue_d(0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = 0.f;
-        issue_d(1, 1);
-        NMFX_FENCE();
-        d_stage(0, 0, d);
-        NMFX_FENCE();
-        issue_a(0, 0);
-        NMFX_FENCE();
-        d_stage(1, 1, d);
-        NMFX_FENCE();
-        {   // quotient x / (zy + 1e-9) where the accumulator stands (v_rcp_f32, 1 ulp, instead of an IEEE division)
-            float4 qa[2][2];
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            issue_d(1, 1);
+            NMFX_FENCE();
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const float4 x4 = cur.va[a >> 1][a & 1];
-                qa[a >> 1][a & 1] = make_float4(x4.x * __builtin_amdgcn_rcpf(d[4 * a] + 1e-9f), x4.y * __builtin_amdgcn_rcpf(d[4 * a + 1] + 1e-9f),
-                                                x4.z * __builtin_amdgcn_rcpf(d[4 * a + 2] + 1e-9f), x4.w * __builtin_amdgcn_rcpf(d[4 * a + 3] + 1e-9f));
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int s = 2 * half + ss;
+                    d = MFMA32X(fh[half][ss], zh[WITH_D ? s : 0], d);
+                    d = MFMA32X(fl[half][ss], zh[WITH_D ? s : 0], d);
+                    NMFX_FENCE();
+                    if (dma_on) dma_step(s);
+                    if (DO_A && WITH_OBJ) kl_chunk(s);
+                    NMFX_FENCE();
+                    d = MFMA32X(fh[half][ss], zl[WITH_D ? s : 0], d);
+                    if (TERMS >= 4) d = MFMA32X(fl[half][ss], zl[WITH_D ? s : 0], d);
+                }
+                NMFX_FENCE();
+                if (DO_A) issue_a(half, half);         // (behind the MFMAs that read this register set)
+                NMFX_FENCE();
             }
+        } else {
+            issue_a(0, 0); issue_a(1, 1);
+            NMFX_FENCE();
+        }
+        if (DO_A) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vh[ks], fh[ks][t], accA[t]);
+                NMFX_FENCE();
+                if (DO_D) quot(2 * ks); else if (WITH_OBJ) kl_chunk(2 * ks);
+                NMFX_FENCE();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vl[ks], fh[ks][t], accA[t]);
+                NMFX_FENCE();
+                if (DO_D) quot(2 * ks + 1); else if (WITH_OBJ) kl_chunk(2 * ks + 1);
+                NMFX_FENCE();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vh[ks], fl[ks][t], accA[t]);
+                if (TERMS >= 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vl[ks], fl[ks][t], accA[t]);
+                }
+                NMFX_FENCE();
+                if (DO_D) split8(qa[ks][0], qa[ks][1], cur.vh[ks], cur.vl[ks]);
+                NMFX_FENCE();
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) quot(a);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) split8(qa[s2][0], qa[s2][1], cur.vh[s2], cur.vl[s2]);
         }
-        NMFX_FENCE();
-        // The objective terms x log(x / zy) [inf, nan -> 0] - x + zy (utils.py:23-26) of the same registers ride between the
-        // MFMAs of the second product, half of them per k-step: in the serial section above (matrix pipe idle: the second
-        // product waits for the quotient) they cost the W phase a third of its time.  v_rcp_f32 / v_log_f32 instead of an
-        // IEEE division and logf: 0 * log(0 / p), x * log(x / 0) and 0 / 0 still come out as nan / inf / nan and are zeroed
-        // exactly like utils.py:24 does.
-        auto kl_terms = [&](int half) {
-            float k0 = 0.f, k1 = 0.f;
-#pragma unroll
-            for (int a = 2 * half; a < 2 * half + 2; ++a) {
-                const float4 x4 = cur.va[a >> 1][a & 1];
-                const float vv[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float pv = d[4 * a + c];
-                    float t = vv[c] * (__builtin_amdgcn_logf(vv[c] * __builtin_amdgcn_rcpf(pv)) * 0.69314718055994531f);
-                    t = (t != t || t == __builtin_inff()) ? 0.f : t;
-                    if (c & 1) k1 += (t - vv[c]) + pv; else k0 += (t - vv[c]) + pv;
-                }
-            }
-            osum += (double)(k0 + k1);
-        };
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int set = ks & 1;
-            if (ks == 0) issue_a(1, 1);
-            NMFX_FENCE();
-#pragma unroll
-            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vh[ks], fh[set][t], accA[t]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vl[ks], fh[set][t], accA[t]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vh[ks], fl[set][t], accA[t]);
-            if (TERMS >= 4) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) accA[t] = MFMA32_BF16(cur.vl[ks], fl[set][t], accA[t]);
-            }
-            if (WITH_OBJ) { kl_terms(ks); asm volatile("" : "+v"(osum)); }
-            NMFX_FENCE();
+        if (WITH_OBJ) {
+            if (DO_A) olog += (double)klog;
+            if (DO_D) osum += (double)(klin2.x + klin2.y);
+            asm volatile("" : "+v"(osum), "+v"(olog));
         }
-        ycur ^= 1;
-        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+        if (DO_D) {
+            ycur = (ycur == YR - 1) ? 0 : ycur + 1;
+            vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+        }
     };
     VRegs P, Q;
     if (PIPE) {
@@ -1030,7 +1091,15 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
     if (KL) {
-        for (int grp = g0; grp < g1; ++grp) group_kl(grp, P);
+        if (g0 < g1) {
+            const std::true_type yes; const std::false_type no;
+            kl_iter(g0, P, Q, yes, no);
+            int grp = g0 + 1;
+            for (; grp + 1 < g1; grp += 2) { kl_iter(grp, Q, P, yes, yes); kl_iter(grp + 1, P, Q, yes, yes); }
+            if (grp < g1) { kl_iter(grp, Q, P, yes, yes); kl_iter(grp + 1, P, Q, no, yes); }
+            else kl_iter(grp, Q, P, no, yes);
+            osum += 0.69314718055994531 * olog;
+        }
     } else {
         for (int grp = g0; grp < g1; grp += 2) {
             group(grp, P, Q);
@@ -1501,6 +1570,15 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
     const size_t shm = 160 * 1024;
     auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP>;
 #ifdef NMFX_EXP_ABLATE
+    if constexpr (TERMS == 3 && KL && KP == 64) {
+        static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
+        switch (abl) {
+            case 1: kern = xyt32_bf16_kernel<OBJ, TERMS, 1, KL, KP>; break;
+            case 16: kern = xyt32_bf16_kernel<OBJ, TERMS, 16, KL, KP>; break;
+            case 17: kern = xyt32_bf16_kernel<OBJ, TERMS, 17, KL, KP>; break;
+            default: break;
+        }
+    }
     if (OBJ && TERMS == 3 && !KL && KP == 64) {
         static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
         switch (abl) {
