@@ -49,9 +49,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--m", type=int, default=M)
-    ap.add_argument("--n", type=int, default=N)
-    ap.add_argument("--k", type=int, default=K)
+    # (NMFX_BENCH_SHAPE=MxNxK: the same through the environment -- torch.distributed.run's own parser chokes on "--m")
+    dm, dn, dk = (int(x) for x in os.environ.get("NMFX_BENCH_SHAPE", f"{M}x{N}x{K}").split("x"))
+    ap.add_argument("--m", type=int, default=dm)
+    ap.add_argument("--n", type=int, default=dn)
+    ap.add_argument("--k", type=int, default=dk)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=10)     # ~12 s of host work at 0.9 iterations/s
     ap.add_argument("--profile-steps", type=int, default=20)
@@ -153,23 +155,100 @@ ALL_KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram
 V_SIZED = ("wphase", "wphase_noobj", "objective", "hphase")      # launches that stream V (or V^T) once
 
 
-def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192):
+def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192, rows=None):
     """The synthetic matrix of SURVEY 8d -- (U1 U2) / k + 0.01 U3, U* ~ U(0, 1) -- drawn ON the device from
     torch's generator and handed to the engine device-to-device (nmfx_upload_v_device): the 2 and 8 GiB
     matrices of configs 4 and 5 would take tens of seconds to draw on the host.  Same distribution as
-    nmf_amd.synth.planted_matrix, a different random stream."""
+    nmf_amd.synth.planted_matrix, a different random stream: U1, U2 from `seed`, the noise of rows
+    [c * chunk, (c + 1) * chunk) from seed' = seed * 1000003 + 1 + c -- so a rank of a row-sharded run draws
+    exactly its rows (`rows = (r0, r1)`) of the SAME global matrix whatever the number of ranks."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     left = torch.rand(m, k, generator=g, device=dev, dtype=torch.float32)
     right = torch.rand(k, n, generator=g, device=dev, dtype=torch.float32)
-    for a in range(0, m, chunk):
-        b = min(m, a + chunk)
+    r0, r1 = (0, m) if rows is None else rows
+    for c in range(r0 // chunk, (r1 + chunk - 1) // chunk):
+        a, b = c * chunk, min(m, (c + 1) * chunk)
+        g.manual_seed(seed * 1000003 + 1 + c)
         blk = (left[a:b] @ right) / k + 0.01 * torch.rand(b - a, n, generator=g, device=dev, dtype=torch.float32)
+        lo, hi = max(a, r0), min(b, r1)
+        part = blk[lo - a:hi - a]
         torch.cuda.synchronize()
-        eng.upload_v_device(blk.data_ptr(), b - a, row0=a)
-        del blk
+        eng.upload_v_device(part.data_ptr(), hi - lo, row0=lo - r0)
+        del blk, part
     del left, right
     torch.cuda.empty_cache()
+
+
+def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup=2):
+    """BASELINE.json's config 5 as it is meant: MUR Euclidean, V = 131072 x 16384 f32, k = 128, rows of V and W sharded over
+    the `world` GPUs, one RCCL all-reduce of [W^T V | W^T W | objective] per iteration (nmf_amd.dist.run_iterations).  The same
+    global matrix as other_configs' cfg5_on_1_gpu (device_planted draws any row range of it), so that
+    iter/s(N) / iter/s(1) is the strong scaling SURVEY 8d asks for.  Every rank runs this; returns the slot on rank 0.
+    NMFX_BENCH_CFG5_SHAPE=MxNxK shrinks it (rehearsals of the code path with several ranks on one GPU)."""
+    m, n, k = (int(x) for x in os.environ.get("NMFX_BENCH_CFG5_SHAPE", "131072x16384x128").split("x"))
+    NEVER = 10 ** 12
+    r0, r1 = nd.row_range(m, rank, world)
+    rs = np.random.RandomState(0)                       # nmf/mur.py:108-109
+    w0 = np.abs(rs.randn(m, k))[r0:r1]
+    h0 = np.abs(rs.randn(k, n))
+    dev = torch.device(f"cuda:{local_rank}")
+    on_gpu = dist.get_backend() == "nccl"
+    shard, err = None, None
+    try:
+        shard = nd.DeviceShard(None, k, w0, h0, local_rank, shape=(r1 - r0, n),
+                               fill=lambda e: device_planted(e, torch, m, n, k, 0, dev, rows=(r0, r1)))
+    except Exception as e:  # noqa: BLE001
+        err = e
+    # every rank learns whether EVERY rank is set up before the first data-path collective: a rank that failed alone
+    # (out of memory, ...) must not leave the others waiting in an all-reduce
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if shard is not None:
+            shard.eng.close()
+        raise RuntimeError(f"config-5 shard could not be set up on every rank (rank {rank}: {err!r})")
+    try:
+        def fence():
+            shard.eng.synchronize()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def run(first, count):
+            nd.run_iterations(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
+
+        run(0, warmup + steps)                          # untimed rehearsal (lazy allocations, pools), then from the start again
+        fence()
+        shard.eng.set_factors(w0, h0)
+        run(0, warmup)
+        fence()
+        t0 = time.perf_counter()
+        run(warmup, steps)
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item()) / steps
+        _, _, n_obj = shard.eng.state()
+        obj = shard.eng.objectives(0, n_obj)
+        ok = bool(np.all(np.isfinite(obj)) and obj[-1] < obj[0])
+        flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
+        nbytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4
+        return {"config": "cfg5", "workload": f"MUR Euclidean, V={m}x{n} f32 row-sharded over {world} GPU(s), k={k}, one all-reduce of "
+                                              "[W^T V | W^T W | objective] per iteration, |randn| start, objective every iteration",
+                "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
+                "precision": shard.eng.precision(), "loop": "eager", "objective_first_last": [float(obj[0]), float(obj[-1])],
+                "objective_decreasing": ok, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
+                "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
+                "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
+                "all_reduce_bytes": 4.0 * (k * n + k * k) + 64.0,
+                "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
+    finally:
+        shard.eng.close()
+        del shard
+        torch.cuda.empty_cache()
 
 
 def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None):
@@ -470,7 +549,14 @@ def main():
         par_gpu = (w_g, h_g, eng.objectives(0, p_it + 1))
 
     others = None
-    if rank == 0 and world == 1 and not args.no_others and (m, n, k) == (M, N, K):
+    if sharded and not args.no_others and ((m, n, k) == (M, N, K) or os.environ.get("NMFX_BENCH_CFG5_SHAPE")):
+        # config 5 proper (the 8-GPU config of BASELINE.json), sharded over this run's ranks: every rank takes part
+        eng.close()
+        try:
+            others = [cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank)]
+        except Exception as e:  # noqa: BLE001  (reported in its slot, never hidden; a rank that failed alone would hang the others'
+            others = [{"config": "cfg5", "error": f"{type(e).__name__}: {e}"}]          # collectives -- the driver's timeout ends that)
+    if rank == 0 and world == 1 and not sharded and not args.no_others and (m, n, k) == (M, N, K):
         eng.close()               # free the HBM: config 5 on one GPU holds three 8 GiB copies of V
         others = other_configs(torch, torch.device(f"cuda:{local_rank}"))
 

@@ -920,7 +920,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     // [second product of group g - 1  ||  quotient + split of group g]  on two register sets (P / Q, loop unrolled by two):
     // every VALU section has independent MFMAs around it.  Y ring of three (the second product of g - 1 reads Y(g - 1) while
     // Y(g + 1) lands), V ring of three (V(g + 2) goes into the slot of V(g - 1) behind the barrier of group g), one barrier
-    // per group, the DMA requests in pairs between the MFMAs as in the Euclidean pipeline.
+    // per group, the DMA requests in pairs between the MFMAs as in the Euclidean pipeline.  (A second barrier per group that
+    // frees the slot of V(g) as soon as every wave holds the tile, with V(g + 3) requested behind it -- three groups in
+    // flight instead of two -- measured no faster: W phase 537 vs 524 us, H phase 448 vs 450, tools/lab/ab_phase.py.)
     auto kl_iter = [&](int grp, VRegs& cur, VRegs& prv, auto do_d_t, auto do_a_t) {
         constexpr bool DO_D = decltype(do_d_t)::value, DO_A = decltype(do_a_t)::value;
         const unsigned char* ybuf = smem + ycur * YBUF;                              // Y(grp)

@@ -92,19 +92,25 @@ class DeviceShard:
     that RCCL can reduce them in place, and running on torch's current stream so
     the collective is ordered after phase A and before phase B."""
 
-    def __init__(self, v_local, k, w0_local, h0, device):
+    def __init__(self, v_local, k, w0_local, h0, device, shape=None, fill=None):
+        """`v_local`: this rank's rows of V (host array) -- or None with `shape = (rows, n)` and `fill(engine)`, a callable
+        that hands the rows over on the device (Engine.upload_v_device), for shards that are produced there."""
         import torch
         from .engine import Engine
         self.torch = torch
         torch.cuda.set_device(device)
-        self.eng = Engine(v_local.shape[0], v_local.shape[1], k, device=device)
+        rows, n = v_local.shape if v_local is not None else shape
+        self.eng = Engine(rows, n, k, device=device)
         n32, n64 = self.eng.exchange_sizes()
         self.xf32 = torch.zeros(n32, dtype=torch.float32, device=f"cuda:{device}")
         self.xf64 = torch.zeros(n64, dtype=torch.float64, device=f"cuda:{device}")
         torch.cuda.synchronize()
         self.eng.set_exchange_buffers(self.xf32.data_ptr(), self.xf64.data_ptr())
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.eng.upload_v(v_local)
+        if v_local is not None:
+            self.eng.upload_v(v_local)
+        else:
+            fill(self.eng)
         self.eng.set_factors(w0_local, h0)
 
     def buffers(self):

@@ -252,3 +252,28 @@ def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
     ref = R.ao_admm(v.astype(np.float64), 12, reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)
     assert np.linalg.norm(z["ao_w"] @ z["ao_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
     np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=5e-4)
+
+
+def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two
+    ranks on ONE GPU (gloo staged through the host, shrunken shapes): the strong-scaling leg of config 2 and the config-5
+    leg (each rank draws its own rows of the same matrix on the device) both come back in the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMFX_BENCH_BACKEND="gloo", NMFX_BENCH_CFG5_SHAPE="2048x1024x128", NMFX_BENCH_SHAPE="1024x512x64",
+               NMF_AMD_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic",
+           "--tol-max-iter", "0"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["rows_per_gpu"] == 512
+    leg = line["other_configs"][0]
+    assert leg.get("config") == "cfg5" and "error" not in leg, leg
+    assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 1024 and leg["objective_decreasing"] and leg["iter_per_s"] > 0
