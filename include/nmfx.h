@@ -199,6 +199,21 @@ int nmfx_aoadmm_phase_w_close(nmfx_handle_t h, int admm_iter, int64_t j);
  * { phase_w_round . all-reduce } x admm_iter . phase_w_close: 3 collectives per outer iteration instead of 2 + admm_iter. */
 int nmfx_aoadmm_phase_w_fused(nmfx_handle_t h, int prox_w, double lambda_w, int admm_iter);
 int nmfx_aoadmm_phase_w_repair(nmfx_handle_t h, int prox_w, double lambda_w, int admm_iter, int64_t j);
+
+/* Row-sharded AO-ADMM with the KL loss (nmf/ao_admm.py:71-101, 277-283: admm_kl_update for H, then for W on the
+ * transposed data).  Its V-sized products sit INSIDE the inner rounds, so the exchange is per round:
+ *   for r in range(admm_iter):  nmfx_aoadmm_kl_phase_h_products(j, r); all-reduce(f32 buffer [, f64[0..7] when r == 0]);
+ *                               nmfx_aoadmm_kl_phase_h_round(prox_h, lambda_h, r, min_iter, tol1, tol2, j)
+ *   nmfx_aoadmm_kl_phase_h_close(admm_iter, min_iter, tol1, tol2, j)
+ *   for r in range(admm_iter):  nmfx_aoadmm_kl_phase_w_round(prox_w, lambda_w, r); all-reduce(f64[1..4])
+ *   nmfx_aoadmm_kl_phase_w_close(admm_iter, j)
+ * The rounds behind the inner stop (`ADMM break`, ao_admm.py:96-98) are no-ops on every rank. */
+int nmfx_aoadmm_kl_phase_h_products(nmfx_handle_t h, int64_t j, int round);
+int nmfx_aoadmm_kl_phase_h_round(nmfx_handle_t h, int prox_h, double lambda_h, int round, int64_t min_iter, double tol1,
+                                 double tol2, int64_t j);
+int nmfx_aoadmm_kl_phase_h_close(nmfx_handle_t h, int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_aoadmm_kl_phase_w_round(nmfx_handle_t h, int prox_w, double lambda_w, int round);
+int nmfx_aoadmm_kl_phase_w_close(nmfx_handle_t h, int admm_iter, int64_t j);
 /* f64 exchange buffer [0] = this rank's objective partial of the current factor pair.        */
 int nmfx_objective_partial(nmfx_handle_t h);
 /* Record the objective / convergence test of the last queued iteration.       */

@@ -55,6 +55,11 @@ SIGNATURES = {
     "nmfx_aoadmm_phase_w_close": (_i32, [_vp, _i32, _i64]),
     "nmfx_aoadmm_phase_w_fused": (_i32, [_vp, _i32, _dbl, _i32]),
     "nmfx_aoadmm_phase_w_repair": (_i32, [_vp, _i32, _dbl, _i32, _i64]),
+    "nmfx_aoadmm_kl_phase_h_products": (_i32, [_vp, _i64, _i32]),
+    "nmfx_aoadmm_kl_phase_h_round": (_i32, [_vp, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64]),
+    "nmfx_aoadmm_kl_phase_h_close": (_i32, [_vp, _i32, _i64, _dbl, _dbl, _i64]),
+    "nmfx_aoadmm_kl_phase_w_round": (_i32, [_vp, _i32, _dbl, _i32]),
+    "nmfx_aoadmm_kl_phase_w_close": (_i32, [_vp, _i32, _i64]),
     "nmfx_objective_partial": (_i32, [_vp]),
     "nmfx_anls_phase_objective": (_i32, [_vp, _i64]),
     "nmfx_anls_phase_w": (_i32, [_vp, _dbl, _i64, _dbl, _dbl, _i64]),

@@ -1323,6 +1323,84 @@ extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t
     return ao_new_pair_objective(E);
 }
 
+// ---- row-sharded form, KL loss (ao_admm.py:71-101, 277-283) ---------------------------------------------------------
+// The KL inner loop keeps the V-sized products INSIDE the rounds (w.T @ (v_aux + dual_v) for the H sub-problem,
+// (v_aux + dual_v) @ h.T for the W sub-problem), so the row-sharded form exchanges once per round:
+//   H sub-problem, round r:  nmfx_aoadmm_kl_phase_h_products(j, r)  ->  all-reduce of [W^T S | W^T W] (round 0: and the objective)
+//                            nmfx_aoadmm_kl_phase_h_round(..., r)      replicated solve / prox / dual step, rank-local v_aux step
+//   then nmfx_aoadmm_kl_phase_h_close: inner-iteration bookkeeping, H H^T and its inverse for the W side (replicated)
+//   W sub-problem, round r:  nmfx_aoadmm_kl_phase_w_round(..., r)   ->  all-reduce of the 4 norm sums (`terminate` looks at all of W)
+//   then nmfx_aoadmm_kl_phase_w_close: bookkeeping + the KL objective partials of the new pair.
+// After the inner stop has fired the remaining rounds are no-ops on every rank (the decision is taken from replicated /
+// all-reduced numbers), their exchanges move stale buffers that nothing reads.
+static int ao_kl_sharded_ready(nmfx_engine* E, int64_t j) {
+    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    if ((rc = nmfx_kl_state_alloc(E))) return rc;
+    E->lazy_objective = false; E->himg_both = false;
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_aoadmm_kl_phase_h_products(nmfx_handle_t E, int64_t j, int round) {
+    int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    float* W = E->W[0];
+    if (round == 0) {
+        if (j == 0 && (rc = nmfx_launch_wphase(E, W, false, true, true))) return rc;      // obj[0] partials (ao_admm.py:256)
+        const bool fuse_g = nmfx_hphase_can_fuse_gram(E);
+        if (!fuse_g && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+        if ((rc = nmfx_launch_hphase(E, W, fuse_g, E->S))) return rc;
+        return nmfx_launch_pack(E);
+    }
+    const int* stop = &E->state->inner_stop;
+    if ((rc = nmfx_launch_hphase(E, W, false, E->S, stop))) return rc;
+    return nmfx_launch_pack(E, stop);
+}
+
+extern "C" int nmfx_aoadmm_kl_phase_h_round(nmfx_handle_t E, int prox_h, double lambda_h, int round, int64_t min_iter,
+                                            double tol1, double tol2, int64_t j) {
+    int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    if (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if (round == 0 && (rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+    if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lambda_h, round))) return rc;
+    return nmfx_launch_kl_vaux(E, E->W[0], E->auxH, &E->state->inner_stop);
+}
+
+extern "C" int nmfx_aoadmm_kl_phase_h_close(nmfx_handle_t E, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                                            int64_t j) {
+    int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);
+}
+
+// One round of the W sub-problem on this rank's rows; leaves this rank's norm sums of the round in the f64 exchange
+// buffer [1..4] for the caller to all-reduce (round r + 1 takes the stop decision of round r from the reduced sums).
+extern "C" int nmfx_aoadmm_kl_phase_w_round(nmfx_handle_t E, int prox_w, double lambda_w, int round) {
+    int rc = ao_kl_sharded_ready(E, 0); if (rc) return rc;
+    if (prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    float* W = E->W[0];
+    const int* stop = &E->state->inner_stop;
+    if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->H, E->S, stop))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
+    if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lambda_w, round,
+                              round > 0 ? E->xf64 + 1 : nullptr))) return rc;
+    if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->H, stop))) return rc;
+    hipLaunchKernelGGL(ao_norm_gather_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part,
+                       (int)(E->mp / 64), round, E->xf64 + 1);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_aoadmm_kl_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
+    int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
+    return nmfx_launch_wphase(E, E->W[0], false, true, true);                             // KL objective partials (utils.py:21-26)
+}
+
 // Row-sharded W sub-problem with ONE exchange instead of one per round: all admm_iter rounds run speculatively on
 // this rank's rows (ao_fused_rows_kernel) and the four norm sums of every round go to the f64 exchange buffer
 // [8 + 4 round + component]; after the caller's all-reduce of that table nmfx_aoadmm_phase_w_repair finds the round at

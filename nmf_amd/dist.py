@@ -150,6 +150,21 @@ class DeviceShard:
     def ao_w_repair(self, prox_w, lam_w, admm_iter, j):
         self.eng.aoadmm_phase_w_repair(prox_w, lam_w, admm_iter, j)
 
+    def ao_kl_h_products(self, j, rnd):
+        self.eng.aoadmm_kl_phase_h_products(j, rnd)
+
+    def ao_kl_h_round(self, prox_h, lam_h, rnd, min_iter, tol1, tol2, j):
+        self.eng.aoadmm_kl_phase_h_round(prox_h, lam_h, rnd, min_iter, tol1, tol2, j)
+
+    def ao_kl_h_close(self, admm_iter, min_iter, tol1, tol2, j):
+        self.eng.aoadmm_kl_phase_h_close(admm_iter, min_iter, tol1, tol2, j)
+
+    def ao_kl_w_round(self, prox_w, lam_w, rnd):
+        self.eng.aoadmm_kl_phase_w_round(prox_w, lam_w, rnd)
+
+    def ao_kl_w_close(self, admm_iter, j):
+        self.eng.aoadmm_kl_phase_w_close(admm_iter, j)
+
     def admm_products(self, dist_code, rho, prox_w, prox_h, j):
         self.eng.admm_phase_products(dist_code, rho, prox_w, prox_h, j)
 
@@ -386,20 +401,49 @@ def _prox_code(kind):
 MAX_FUSED_ROUNDS = 64         # rows of the norm table in the engine's f64 exchange buffer
 
 
-def aoadmm_sharded(shard, comm, *, reg_w=(0, 'nn'), reg_h=(0, 'nn'), min_iter=10, max_iter=100000,
+def aoadmm_sharded(shard, comm, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'nn'), min_iter=10, max_iter=100000,
                    admm_iter=10, tol1=1e-3, tol2=1e-3, batch=4, experiment=None, fused=None):
-    """AO-ADMM, Euclidean loss (nmf/ao_admm.py:259-301), over a row-sharded V.
+    """AO-ADMM (nmf/ao_admm.py:259-301) over a row-sharded V.  Euclidean loss:
 
     H sub-problem (ao_admm.py:263): [W^T V | W^T W | objective] is all-reduced once, the Cholesky
     solve / prox / dual rounds are then replicated work.  W sub-problem (ao_admm.py:265): rank-local
     rows, except that `terminate` (ao_admm.py:33-43) takes norms over the whole factor: all rounds run
     speculatively, the [admm_iter x 4] table of their sums of squares is all-reduced ONCE and every rank
     derives the same stopping round from it and repairs its rows if that round is not the last
-    (nmfx_aoadmm_phase_w_fused / _repair; 3 collectives per outer iteration).  Returns Results with THIS
-    rank's rows of w."""
+    (nmfx_aoadmm_phase_w_fused / _repair; 3 collectives per outer iteration).
+
+    KL loss (admm_kl_update, ao_admm.py:71-101): the V-sized products w.T @ (v_aux + dual_v) and (v_aux + dual_v) @ h.T sit
+    INSIDE the inner rounds, so every round of the H sub-problem all-reduces [W^T S | W^T W] and every round of the W
+    sub-problem its four norm sums; v_aux and dual_v (m x n) are rank-local rows.  Returns Results with THIS rank's rows
+    of w."""
+    if distance_type not in ('eu', 'kl'):
+        raise KeyError('Distance type unknown: use "kl" or "eu"')
     prox_h, prox_w = _prox_code(reg_h[1]), _prox_code(reg_w[1])     # H's regulariser is met first
     x32, x64 = shard.buffers()
     norms = x64[1:5]
+    if distance_type == 'kl':
+        def queue_kl(first, count):
+            for j in range(first, first + count):
+                for rnd in range(admm_iter):
+                    shard.ao_kl_h_products(j, rnd)
+                    if rnd == 0:
+                        comm.all_reduce(x32, x64[:8])
+                    else:
+                        comm.all_reduce(x32)
+                    shard.ao_kl_h_round(prox_h, reg_h[0], rnd, min_iter, tol1, tol2, j)
+                shard.ao_kl_h_close(admm_iter, min_iter, tol1, tol2, j)
+                for rnd in range(admm_iter):
+                    shard.ao_kl_w_round(prox_w, reg_w[0], rnd)
+                    comm.all_reduce(norms)
+                shard.ao_kl_w_close(admm_iter, j)
+
+        def finish_kl(done):
+            shard.objective_partial()
+            comm.all_reduce(x64[:8])
+            shard.finish_b(min_iter, tol1, tol2, done)
+
+        return _sharded_loop(shard, comm, queue_kl, finish_kl, max_iter=max_iter, tol1=tol1, tol2=tol2,
+                             batch=batch, experiment=experiment)
     # ONE exchange for the whole W sub-problem where the shard can run its rounds speculatively (the HIP engine, for
     # 2 <= admm_iter <= 64): the [admm_iter x 4] table of norm sums.  `fused=False` keeps one exchange per round.
     if fused is None:
@@ -572,9 +616,10 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
     nmf/admm.py:233, nmf/ao_admm.py:201).  Returns the reference's Results(w, h, i, obj_history, experiment): with
     gather=True `w` is the full m x k factor on rank 0 (its own row block on the other ranks), h / i / obj_history are
     identical everywhere.  Exchange per outer iteration: one RCCL all-reduce of [W^T V | W^T W] (+ objective) -- MUR,
-    ADMM, ANLS -- or three (AO-ADMM: + the H products' objective, the norm table of the W sub-problem).
+    ADMM, ANLS -- or three (AO-ADMM: + the H products' objective, the norm table of the W sub-problem); AO-ADMM with the
+    KL loss exchanges in every inner round (its V-sized products sit inside the rounds, nmf/ao_admm.py:71-101).
 
-    Not available sharded (NotImplementedError): AO-ADMM with the KL loss, prox 'l1inf*' on W.  The in-place lift of
+    Not available sharded (NotImplementedError): prox 'l1inf*' on W (couples all rows).  The in-place lift of
     negative data (nmf/mur.py:99-101) is applied to a private copy of the rank's rows when `data` is not writeable."""
     import torch
     import torch.distributed as tdist
@@ -586,9 +631,6 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
     if unknown:
         raise TypeError(f"{method}() got an unexpected keyword argument '{sorted(unknown)[0]}'")
     kw.update(method_params)
-    if method == 'ao_admm' and kw['distance_type'] == 'kl':
-        raise NotImplementedError('AO-ADMM with the KL loss is not available row-sharded (its H sub-problem exchanges '
-                                  'a k x n product in every inner round)')
     experiment = _experiment(mod, method, k, kw)
     m, n = data.shape
     if world > m:
@@ -632,7 +674,7 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
     make = shard_factory or (lambda v, kk, w, h: DeviceShard(v, kk, w, h, dev.index or 0))
     shard = make(v_local, k, w0[r0:r1], h0)
     run_kw = {key: val for key, val in kw.items()
-              if key not in ('nndsvd_init', 'use_fcnnls') and not (method == 'ao_admm' and key == 'distance_type')}
+              if key not in ('nndsvd_init', 'use_fcnnls')}
     try:
         res = _SOLVERS[method](shard, comm, experiment=experiment, **run_kw)
         w = res.w

@@ -175,6 +175,23 @@ class Engine:
     def aoadmm_phase_w_repair(self, prox_w, lam_w, admm_iter, j):
         self._ck(self.lib.nmfx_aoadmm_phase_w_repair(self.h, prox_w, float(lam_w), int(admm_iter), int(j)))
 
+    # row-sharded AO-ADMM, KL loss: one exchange per inner round (include/nmfx.h)
+    def aoadmm_kl_phase_h_products(self, j, rnd):
+        self._ck(self.lib.nmfx_aoadmm_kl_phase_h_products(self.h, int(j), int(rnd)))
+
+    def aoadmm_kl_phase_h_round(self, prox_h, lam_h, rnd, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_aoadmm_kl_phase_h_round(self.h, prox_h, float(lam_h), int(rnd), int(min_iter), float(tol1),
+                                                       float(tol2), int(j)))
+
+    def aoadmm_kl_phase_h_close(self, admm_iter, min_iter, tol1, tol2, j):
+        self._ck(self.lib.nmfx_aoadmm_kl_phase_h_close(self.h, int(admm_iter), int(min_iter), float(tol1), float(tol2), int(j)))
+
+    def aoadmm_kl_phase_w_round(self, prox_w, lam_w, rnd):
+        self._ck(self.lib.nmfx_aoadmm_kl_phase_w_round(self.h, prox_w, float(lam_w), int(rnd)))
+
+    def aoadmm_kl_phase_w_close(self, admm_iter, j):
+        self._ck(self.lib.nmfx_aoadmm_kl_phase_w_close(self.h, int(admm_iter), int(j)))
+
     def admm_phase_products(self, dist, rho, prox_w, prox_h, j):
         self._ck(self.lib.nmfx_admm_phase_products(self.h, dist, float(rho), prox_w, prox_h, int(j)))
 

@@ -208,6 +208,95 @@ class HostShard:
             self.w, self.dual_w = wt.T.copy(), dt.T.copy()
         self.inner[(j, 1)] = rounds
 
+    # ---- AO-ADMM, KL loss (nmf/ao_admm.py:71-101, 277-283) in the sharded protocol: one exchange per inner round ----
+    def _ao_kl_init(self):
+        self._ao_init()
+        self.obj_kind = 1
+        if not hasattr(self, "v_aux"):
+            self.v_aux = np.zeros_like(self.v)
+            self.dual_v = np.zeros_like(self.v)
+
+    def ao_kl_h_products(self, j, rnd):
+        self._ao_kl_init()
+        if self.flag or (rnd > 0 and self._h_stop):
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        x[:] = 0
+        x[:k * n] = (self.w.T @ (self.v_aux + self.dual_v)).ravel()
+        x[k * n:k * n + k * k] = (self.w.T @ self.w).ravel()
+        if rnd == 0:
+            self.x64.zero_()
+            self.x64[0] = self._local_objective(1)
+            self._h_stop, self._h_ran = False, 0
+
+    def ao_kl_h_round(self, prox_h, lam_h, rnd, min_iter, tol1, tol2, j):
+        import scipy.linalg as sla
+        if self.flag:
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        if rnd == 0:
+            if self._record(min_iter, tol1, tol2, j):
+                return
+            g = x[k * n:k * n + k * k].reshape(k, k).copy()
+            self._rho_h = np.trace(g) / k
+            self._chol_h = sla.cholesky(g + self._rho_h * np.eye(k), lower=True)
+        if self._h_stop:
+            return
+        b = x[:k * n].reshape(k, n)
+        aux = sla.cho_solve((self._chol_h, True), b + self._rho_h * (self.h + self.dual_h))
+        prev = self.h
+        self.h = self._prox(prox_h, aux, self.dual_h, self._rho_h, lam_h)
+        v_bar = self.w @ aux - self.dual_v
+        self.v_aux = 0.5 * ((v_bar - 1) + np.sqrt((v_bar - 1) ** 2 + 4 * self.v))
+        self.dual_h = self.dual_h + self.h - aux
+        self.dual_v = self.dual_v + self.v_aux - self.w @ aux
+        self._h_ran = rnd + 1
+        self._h_stop = bool(R.inner_stop(self.h, prev, aux, self.dual_h))
+
+    def ao_kl_h_close(self, admm_iter, min_iter, tol1, tol2, j):
+        import scipy.linalg as sla
+        if self.flag:
+            return
+        self.inner[(j, 0)] = self._h_ran
+        g = self.h @ self.h.T
+        self._rho_w = np.trace(g) / self.k
+        self._chol_w = sla.cholesky(g + self._rho_w * np.eye(self.k), lower=True)
+        self._w_stop, self._w_ran = False, 0
+
+    def ao_kl_w_round(self, prox_w, lam_w, rnd):
+        import scipy.linalg as sla
+        if self.flag:
+            return
+        if rnd > 0 and not self._w_stop:                    # all-reduced sums of the previous round
+            n0, n1, n2, n3 = (float(t) for t in self.x64[1:5])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = np.sqrt(n0) / np.sqrt(n1)
+                s = np.sqrt(n2) / np.sqrt(n3)
+            self._w_stop = bool(r < 1e-2 and s < 1e-2)
+        if self._w_stop:
+            return
+        wt, dt = self.w.T, self.dual_w.T
+        st = (self.v_aux + self.dual_v).T                   # n x m_local
+        aux = sla.cho_solve((self._chol_w, True), self.h @ st + self._rho_w * (wt + dt))
+        new = self._prox(prox_w, aux, dt, self._rho_w, lam_w)
+        v_bar = self.h.T @ aux - self.dual_v.T
+        v_aux_t = 0.5 * ((v_bar - 1) + np.sqrt((v_bar - 1) ** 2 + 4 * self.v.T))
+        dual = dt + new - aux
+        self.dual_v = (self.dual_v.T + v_aux_t - self.h.T @ aux).T.copy()
+        self.v_aux = v_aux_t.T.copy()
+        self.x64[1] = np.sum((new - aux) ** 2)
+        self.x64[2] = np.sum(new ** 2)
+        self.x64[3] = np.sum((new - wt) ** 2)
+        self.x64[4] = np.sum(dual ** 2)
+        self.w, self.dual_w = new.T.copy(), dual.T.copy()
+        self._w_ran = rnd + 1
+
+    def ao_kl_w_close(self, admm_iter, j):
+        if not self.flag:
+            self.inner[(j, 1)] = self._w_ran
+
     # ---- ADMM (nmf/admm.py:292-334) in the sharded protocol ----
     def set_l2n_operator(self, which, p):
         if not hasattr(self, "l2n"):

@@ -194,10 +194,15 @@ GENERIC_CASES = [
          kw=dict(rho=1, distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=6, max_iter=6)),
     dict(solver="admm", m=90, n=66, k=4, seed=23, batch=3, svd=True,       # the row-coupled prox on the replicated side
          kw=dict(rho=1, distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.05, "l1inf"), min_iter=3, max_iter=3)),
+    dict(solver="ao_admm", m=90, n=66, k=4, seed=24, batch=2, svd=True,    # KL loss: one exchange per inner round
+         kw=dict(distance_type="kl", reg_w=(0.02, "l1n"), reg_h=(0, "nn"), min_iter=4, max_iter=4, admm_iter=6)),
+    dict(solver="ao_admm", m=96, n=70, k=5, seed=12, batch=2, svd=True, uniform=True,   # KL loss, long inner loops / stop rule
+         kw=dict(distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=2, max_iter=12, admm_iter=25, tol1=1e-3, tol2=1e-1)),
 ]
 
 
-@pytest.mark.parametrize("case", GENERIC_CASES, ids=["ao_admm_round_by_round", "admm_eu_l1n_l2n", "admm_kl", "admm_l1inf_h"])
+@pytest.mark.parametrize("case", GENERIC_CASES, ids=["ao_admm_round_by_round", "admm_eu_l1n_l2n", "admm_kl", "admm_l1inf_h",
+                                                     "ao_admm_kl", "ao_admm_kl_long_inner"])
 def test_sharded_admm_and_unfused_aoadmm_equal_single_process_oracle(case, tmp_path):
     world = 2
     mp.spawn(_generic_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
@@ -220,10 +225,12 @@ API_CASES = [
          kw=dict(reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)),                           # default NNDSVD start
     dict(api=True, solver="admm", m=90, n=70, k=4, seed=34, kw=dict(reg_h=(0.2, "l2n"), min_iter=5, max_iter=5)),
     dict(api=True, solver="anls", m=50, n=40, k=3, seed=35, kw=dict(distance_type="kl", min_iter=3, max_iter=3, lambda_h=0.05)),
+    dict(api=True, solver="ao_admm", m=70, n=50, k=3, seed=36,
+         kw=dict(distance_type="kl", reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=3, max_iter=3, admm_iter=5)),
 ]
 
 
-@pytest.mark.parametrize("case", API_CASES, ids=["mur_eu", "mur_default_kl", "ao_admm", "admm", "anls_kl"])
+@pytest.mark.parametrize("case", API_CASES, ids=["mur_eu", "mur_default_kl", "ao_admm", "admm", "anls_kl", "ao_admm_kl"])
 def test_factorize_api_over_two_ranks_matches_the_single_process_reference_semantics(case, tmp_path):
     """nmf_amd.dist.factorize: reference keyword names / defaults per method, the global numpy RNG consumed in the
     reference's order on every rank, NNDSVD from rank 0 broadcast, rank 0 returns the gathered m x k factor."""

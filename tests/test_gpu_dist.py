@@ -148,6 +148,12 @@ def _solver_case(solver):
         v = R.planted_matrix(m, n, k, seed=33, dtype=np.float32)
         w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
         return m, n, k, v, w0, h0, kw
+    if solver == "ao_admm_kl":                             # KL loss: one exchange per inner round of both sub-problems
+        m, n, k = 320, 200, 8
+        kw = dict(distance_type="kl", reg_w=(0.02, "l1n"), reg_h=(0, "nn"), min_iter=4, max_iter=4, admm_iter=6)
+        v = R.planted_matrix(m, n, k, seed=35, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
     if solver.startswith("ao_admm"):
         m, n, k = 520, 300, (40 if solver.endswith("bf16") else 12)    # k = 40: split-bf16 products, lazy objective
         kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=8, max_iter=8, admm_iter=10)
@@ -189,7 +195,8 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "admm", "admm_bf16", "admm_kl", "anls"])
+@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "admm", "admm_bf16",
+                                    "admm_kl", "anls"])
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
@@ -207,7 +214,7 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
         assert any(t[1] < 10 for t in ref.trace["inner"]), "case must exercise the repair launch of the W sub-problem"
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-3 if solver == "admm_kl" else 5e-4)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-3 if solver in ("admm_kl", "ao_admm_kl") else 5e-4)
         np.testing.assert_array_equal(p["h"], h)
         if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
