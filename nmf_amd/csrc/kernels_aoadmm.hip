@@ -284,6 +284,13 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
 }
 
 // ---- inner stop test -------------------------------------------------------
+// `terminate` (ao_admm.py:33-43) on the four sums of squares: ||X - aux|| / ||X|| < 1e-2 and ||X - X_prev|| / ||U|| < 1e-2,
+// written without the square roots and divisions (~1500 cycles of f64 per test on the serial path of every round):
+// sqrt(a) / sqrt(b) < 1e-2  <=>  a < 1e-4 b for a >= 0, b > 0; b = 0 gives inf or nan on the left (false) and a < 0 on the
+// right (false); a nan makes both false.  Only sums within a rounding error of the threshold could be told apart.
+__device__ __forceinline__ bool inner_test(double a, double b, double c, double d) {
+    return (a < 1e-4 * b) && (c < 1e-4 * d);
+}
 // Sum the four norm partials of the previous round; identical in every block.
 __device__ __forceinline__ bool inner_round_fired(const double* __restrict__ part, int nblk, double* sh)
 {
@@ -295,10 +302,9 @@ __device__ __forceinline__ bool inner_round_fired(const double* __restrict__ par
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && wave < 4) sh[wave] = s;
     __syncthreads();
-    const double r = sqrt(sh[0]) / sqrt(sh[1]);        // ||X - aux|| / ||X||
-    const double d = sqrt(sh[2]) / sqrt(sh[3]);        // ||X - X_prev|| / ||U||   (x/0 -> inf/nan -> false)
+    const bool hit = inner_test(sh[0], sh[1], sh[2], sh[3]);
     __syncthreads();
-    return (r < 1e-2) && (d < 1e-2);
+    return hit;
 }
 
 __device__ __forceinline__ float prox_apply(float aux, float dual, float shift) {
@@ -546,37 +552,44 @@ __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
 // the first round whose four norm sums satisfy `terminate` (ao_admm.py:33-43), i.e. how many rounds count.
 // Wave w sums component w of up to 8 rounds at a time (their loads are in flight together); per (round,
 // component) the per-lane strides and the shuffle tree are those of inner_round_fired, so the sums are
-// the same numbers.  sh: 32 doubles.  256 or 512 threads.
+// the same numbers.  sh: 64 doubles.  256 or 512 threads.
 __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_rounds, int nblk, int admm_iter,
                                             double* sh, int* fired_out)
 {
+    // Up to 16 rounds at a time with ALL their loads in flight together (4 block strides x 16 rounds per lane): the no-op
+    // REPAIR launch of the common case (no early stop) is nothing but this function, and as 2 x 4 dependent round trips
+    // plus the f64 square roots / divisions of the tests it took 17 us per launch -- 6 % of a config-3 iteration.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int count = admm_iter, fired = 0;
-    for (int r0 = 0; r0 < admm_iter && !fired; r0 += 8) {
-        double sums[8];
+    for (int r0 = 0; r0 < admm_iter && !fired; r0 += 16) {
+        double sums[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sums[u] = 0.0;
+        for (int u = 0; u < 16; ++u) sums[u] = 0.0;
         if (wave < 4) {                                // (blocks of 512 threads: waves 4..7 only wait)
-            for (int b = lane; b < nblk; b += 64) {
+            for (int b0 = lane; b0 < nblk; b0 += 256) {
+                double t[4][16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (r0 + u < admm_iter) sums[u] += nrm_rounds[((int64_t)(r0 + u) * nblk + b) * 4 + wave];
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        t[i][u] = (b0 + 64 * i < nblk && r0 + u < admm_iter)
+                                      ? nrm_rounds[((int64_t)(r0 + u) * nblk + b0 + 64 * i) * 4 + wave] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)            // (block order per lane as in inner_round_fired: the same sums)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sums[u] += t[i][u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) sums[u] += __shfl_down(sums[u], off, 64);
                 if (lane == 0) sh[u * 4 + wave] = sums[u];
             }
         }
         __syncthreads();
-        // the f64 square roots and divisions of one test are ~1500 cycles: lane u tests round r0 + u
         bool hit = false;
-        if (lane < 8 && r0 + lane < admm_iter) {
-            const double r = sqrt(sh[lane * 4 + 0]) / sqrt(sh[lane * 4 + 1]);  // ||X - aux|| / ||X||
-            const double d = sqrt(sh[lane * 4 + 2]) / sqrt(sh[lane * 4 + 3]);  // ||X - X_prev|| / ||U||
-            hit = (r < 1e-2) && (d < 1e-2);
-        }
+        if (lane < 16 && r0 + lane < admm_iter)        // lane u tests round r0 + u (inner_test: no square roots, no divisions)
+            hit = inner_test(sh[lane * 4 + 0], sh[lane * 4 + 1], sh[lane * 4 + 2], sh[lane * 4 + 3]);
         const unsigned long long mask = __ballot(hit);                          // the same in every wave
         if (mask) { count = r0 + __ffsll((long long)mask); fired = 1; }
         __syncthreads();
@@ -1061,7 +1074,7 @@ static int ao_fused_cols_cb(const nmfx_engine* E) { return (E->np / 64 < (int64_
 
 template <int KP, int CB>
 static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
-    const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
+    const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
     auto kern = ao_fused_cols_kernel<KP, CB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
@@ -1085,7 +1098,7 @@ static int ao_fused_rows_rb(const nmfx_engine* E) {
 template <int KP, int RB>
 static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
                                const double* decide_tab) {
-    const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 32 * sizeof(double);
+    const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP, RB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     // ao_a_slabs > 0: the W-side product's slabs are added here instead of by a sum_partials launch
