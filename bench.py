@@ -264,6 +264,8 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
         rs = np.random.RandomState(0)
         if init == "randn":                      # nmf/mur.py:108-109
             w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+        elif init == "rand":                     # nmf/anls.py:104-105
+            w0, h0 = rs.rand(m, k), rs.rand(k, n)
         else:                                    # NNDSVD 'zero' (nmf/utils.py:36-93) from the device's singular triplets
             class _Shape:
                 shape = (m, n)
@@ -345,6 +347,13 @@ def other_configs(torch, dev):
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
              flops=4.0 * 131072 * 16384 * 128 + 4.0 * 128 * 128 * (131072 + 16384),
              nbytes=2.0 * 131072 * 16384 * 4 + 3.0 * (131072 + 16384) * 128 * 4),
+        # not one of BASELINE.json's configs: the fourth solver of the API on the headline shape (anls.py:112-126; exact NNLS per
+        # row of W / column of H).  Algorithmic work: the two V-sized products + the objective pass over V
+        dict(name="anls_on_cfg2_shape", workload="ANLS Euclidean (exact NNLS, lambda = 0), V=16384x8192 f32, k=64, uniform random start, "
+                                                "objective every iteration",
+             m=16384, n=8192, k=64, steps=10, warmup=4, init="rand",
+             queue=lambda e, f, c: e.anls_run(0.0, 0.0, NEVER, 1e-3, 1e-3, f, c),
+             flops=6.0 * 16384 * 8192 * 64, nbytes=3.0 * 16384 * 8192 * 4),
     ]
     for sp in specs:
         try:

@@ -42,7 +42,8 @@ __device__ __forceinline__ float wave_max(float v) {
 template <int KP>
 __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, const int* __restrict__ todo,
+    const int* __restrict__ inv_bad)
 {
     if (st->flag) return;
     constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * NW + wave;
     if (c >= nprob) return;                              // whole wave leaves together
+    if (todo && !*inv_bad && !todo[c]) return;           // solved by nnls_cinv_kernel
     float* M = lds + (size_t)wave * (KP * LDM + KP);     // [KP][KP+1] augmented rows
     float* xs = M + KP * LDM;                            // [KP] broadcast copy of x
 
@@ -202,12 +204,14 @@ __device__ unsigned long long nnls_dbg[8];     // [sum of iterations, max, probl
 template <int KP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void nnls_bpp_reg_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, const int* __restrict__ todo,
+    const int* __restrict__ inv_bad)
 {
     if (st->flag) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
     if (c >= nprob) return;                              // whole wave leaves together
+    if (todo && !*inv_bad && !todo[c]) return;           // solved by nnls_cinv_kernel
     const bool owner = lane < KP, valid = lane < k;
     float g[KP];
 #pragma unroll
@@ -304,9 +308,11 @@ extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build wit
 // waves exchanged through LDS.  Same algorithm as nnls_bpp_reg_kernel.
 __device__ __forceinline__ void nnls_bpp_reg128_body(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, const int* __restrict__ todo,
+    const int* __restrict__ inv_bad)
 {
     if (st->flag) return;
+    if (todo && !*inv_bad && !todo[blockIdx.x]) return;  // (block-uniform) solved by nnls_cinv_kernel
     constexpr int KP = 128;
     __shared__ __attribute__((aligned(16))) float prow_s[2][KP + 4];   // pivot row, [KP] = its right-hand side
     __shared__ __attribute__((aligned(16))) float xs[KP];
@@ -425,32 +431,304 @@ __device__ __forceinline__ void nnls_bpp_reg128_body(
 // scratch) or 512 (one wave per SIMD, no scratch).  NMFX_NNLS128_OCC=1 selects the second; measured in tools/anls_perf.py.
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) void nnls_bpp_reg128_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
-{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st); }
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, const int* __restrict__ todo,
+    const int* __restrict__ inv_bad)
+{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st, todo, inv_bad); }
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void nnls_bpp_reg128_wide_kernel(
     const float* __restrict__ G, float diag_add, const float* __restrict__ R, float* __restrict__ X,
-    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st)
-{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st); }
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, const int* __restrict__ todo,
+    const int* __restrict__ inv_bad)
+{ nnls_bpp_reg128_body(G, diag_add, R, X, sj, sc, nprob, k, st, todo, inv_bad); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NNLS through the INVERSE of the Gram matrix and the COMPLEMENT of the passive set.
+// The elimination kernels above solve G_FF x_F = r_F per right-hand side: |F| ~ 57 pivots over 64-entry rows at k = 64,
+// 1.05 ms per half-step at 16384 x 8192 -- the largest item of an ANLS iteration.  With u = G^-1 r (the unconstrained
+// solution) and C the ACTIVE set (x_C = 0; ~6 indices once the supports have settled) the same KKT point is
+//     z = ((G^-1)_CC)^-1 u_C,    x_F = u_F - (G^-1)_FC z,    y_C = (G x - r)_C = -z
+// (from G x - r = mu, mu_F = 0, x_C = 0), i.e. a |C| x |C| solve and |C| rank-1 corrections per exchange instead of a
+// |F| x |F| elimination.  A first version with an f32 inverse was too inaccurate (G^-1 squares the condition number of
+// the data matrix); here G^-1 is formed ONCE per half-step in f64 (nnls_inverse_kernel: in-place Gauss-Jordan of
+// G + diag_add I in LDS, one workgroup) and every per-problem quantity is f64.  Same exchange rules, tolerances, warm
+// start and iteration cap as nnls_bpp_kernel.  What this path does not take it leaves to the elimination kernels, which
+// run afterwards on exactly those problems: a half-step whose Gram matrix is singular or too ill-conditioned for an
+// explicit inverse (`inv_bad`: a dead or collinear component at lambda = 0 -- their pivot guard handles it), and
+// single problems whose complement outgrows the workspace (todo[c] = 1).
+// ---------------------------------------------------------------------------------------------------------------------
+#define NMFX_NNLS_INV_EPS 1e-9            // pivot below this fraction of the mean diagonal: no explicit inverse
+
+template <int KP>
+__global__ __launch_bounds__(256) void nnls_inverse_kernel(const float* __restrict__ G, float diag_add, int k,
+                                                           double* __restrict__ Ginv, int* __restrict__ inv_bad,
+                                                           const DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    constexpr int LD = KP + 1;
+    extern __shared__ __attribute__((aligned(16))) double inv_lds[];
+    double* A = inv_lds;                                // [KP][LD]
+    double* colp = A + KP * LD;                         // [KP] pivot column of the step
+    __shared__ double scal[2];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int i = tid; i < KP * KP; i += 256) {
+        const int r = i / KP, c = i % KP;
+        double v = (double)G[(int64_t)r * KP + c];
+        if (r == c) v += (r < k) ? (double)diag_add : 1.0;       // padded variables: decoupled unit block
+        A[r * LD + c] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {                                     // mean diagonal: the scale of the pivot guard
+        double t = 0.0;
+        for (int i = tid; i < k; i += 64) t += A[i * LD + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (tid == 0) scal[0] = t / (double)k;
+    }
+    __syncthreads();
+    const double floor_ = NMFX_NNLS_INV_EPS * scal[0];
+    for (int p = 0; p < KP; ++p) {
+        const double piv = A[p * LD + p];
+        if (!(piv > floor_)) { if (tid == 0) bad = 1; }
+        for (int i = tid; i < KP; i += 256) colp[i] = A[i * LD + p];
+        __syncthreads();
+        if (bad) break;
+        const double inv = 1.0 / piv;
+        // row p: scaled; every other row i: A[i][j] -= A[i][p] * A[p][j] / piv (j != p), A[i][p] = -A[i][p] / piv
+        for (int i = tid; i < KP * KP; i += 256) {
+            const int r = i / KP, c = i % KP;
+            if (r == p) continue;
+            const double f = colp[r];
+            A[r * LD + c] = (c == p) ? -f * inv : fma(-f * inv, A[p * LD + c], A[r * LD + c]);
+        }
+        __syncthreads();
+        for (int c = tid; c < KP; c += 256) A[p * LD + c] = (c == p) ? inv : A[p * LD + c] * inv;
+        __syncthreads();
+    }
+    if (tid == 0) *inv_bad = bad;
+    if (bad) return;
+    for (int i = tid; i < KP * KP; i += 256) Ginv[i] = A[(i / KP) * LD + (i % KP)];
+}
+
+template <int KP>
+__global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
+    const double* __restrict__ Ginv, const int* __restrict__ inv_bad, const float* __restrict__ R, float* __restrict__ X,
+    int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, int* __restrict__ todo)
+{
+    if (st->flag || *inv_bad) return;
+    constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
+    constexpr int NW = KP <= 64 ? 4 : 2;                // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
+    constexpr int MC = KP <= 64 ? 32 : 36;              // largest complement solved here
+    constexpr int LDS_ = MC + 1;
+    constexpr int WSZ = MC * LDS_ + MC + KP;            // per wave: S [MC][MC + 1] | z [MC] | r broadcast [KP]
+    extern __shared__ __attribute__((aligned(16))) double cinv_lds[];
+    double* gi = cinv_lds;                              // G^-1 [KP][KP] (symmetric: row j is read for column j)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* S = gi + KP * KP + wave * WSZ;
+    double* zv = S + MC * LDS_;
+    double* rv = zv + MC;
+    for (int i = threadIdx.x; i < KP * KP; i += 64 * NW) gi[i] = Ginv[i];
+    __syncthreads();
+    for (int64_t c = (int64_t)blockIdx.x * NW + wave; c < nprob; c += (int64_t)gridDim.x * NW) {
+        int idx[NV]; bool valid[NV], inF[NV];
+        double r[NV], u[NV], x[NV], y[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            idx[t] = lane + 64 * t;
+            valid[t] = idx[t] < k;
+            r[t] = valid[t] ? (double)R[(int64_t)idx[t] * sj + c * sc] : 0.0;
+            inF[t] = valid[t] && X[(int64_t)idx[t] * sj + c * sc] > 0.f;      // warm start: the previous support
+            if (idx[t] < KP) rv[idx[t]] = r[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float ar = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) ar = fmaxf(ar, fabsf((float)r[t]));
+        const double toly = (double)(NMFX_NNLS_TOL * wave_max(ar));
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {                  // u = G^-1 r
+            double a0 = 0.0, a1 = 0.0;
+            if (idx[t] < KP) {
+#pragma unroll 8
+                for (int j = 0; j < KP; j += 2) {
+                    a0 = fma(gi[j * KP + idx[t]], rv[j], a0);
+                    a1 = fma(gi[(j + 1) * KP + idx[t]], rv[j + 1], a1);
+                }
+            }
+            u[t] = a0 + a1; x[t] = 0.0; y[t] = 0.0;
+        }
+        int best = k + 1, spare = 3, iter = 0;
+        bool give_up = false;
+        for (; iter < 8 * KP + 64; ++iter) {
+            unsigned long long Im[NV];
+            if (iter > 0) {
+                float ax = 0.f;
+#pragma unroll
+                for (int t = 0; t < NV; ++t) ax = fmaxf(ax, fabsf((float)x[t]));
+                const double tolx = (double)(NMFX_NNLS_TOL * wave_max(ax));
+                int n_inf = 0;
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const bool bad = valid[t] && (inF[t] ? (x[t] < -tolx) : (y[t] < -toly));
+                    Im[t] = __ballot(bad);
+                    n_inf += __popcll(Im[t]);
+                }
+                if (n_inf == 0) break;
+                bool full = true;
+                if (n_inf < best) { best = n_inf; spare = 3; }
+                else if (spare > 0) { --spare; }
+                else full = false;
+                if (!full) {                            // back-up rule: largest infeasible index only
+#pragma unroll
+                    for (int t = NV - 1; t >= 0; --t) {
+                        if (Im[t]) {
+                            const int hi = 63 - __clzll((long long)Im[t]);
+                            Im[t] = 1ull << hi;
+#pragma unroll
+                            for (int w2 = 0; w2 < t; ++w2) Im[w2] = 0ull;
+                            break;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NV; ++t) Im[t] = 0ull;
+            }
+            unsigned long long Cm[NV];
+            int m = 0, base[NV];
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                if ((Im[t] >> lane) & 1ull) inF[t] = !inF[t];
+                Cm[t] = __ballot(valid[t] && !inF[t]);
+                base[t] = m;
+                m += __popcll(Cm[t]);
+            }
+            if (m > MC) { give_up = true; break; }
+            // S = (G^-1)_CC with the right-hand side u_C: the owner of the s-th member fills row s
+            int slot[NV];
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                slot[t] = base[t] + __popcll(Cm[t] & ((1ull << lane) - 1ull));
+                const bool mine = (Cm[t] >> lane) & 1ull;
+                int col = 0;
+#pragma unroll
+                for (int t2 = 0; t2 < NV; ++t2) {
+                    unsigned long long left = Cm[t2];
+                    while (left) {
+                        const int j = __ffsll((long long)left) - 1 + 64 * t2;
+                        left &= left - 1;
+                        if (mine) S[slot[t] * LDS_ + col] = gi[j * KP + idx[t]];
+                        ++col;
+                    }
+                }
+                if (mine) S[slot[t] * LDS_ + m] = u[t];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // Gauss-Jordan on the m x m system, lane s = row s (no pivoting: a principal block of an SPD matrix)
+            bool sing = false;
+            for (int p = 0; p < m; ++p) {
+                const double piv = S[p * LDS_ + p];
+                if (!(piv > 0.0)) { sing = true; break; }
+                const double inv = 1.0 / piv;
+                if (lane < m && lane != p) {
+                    const double f = S[lane * LDS_ + p] * inv;
+                    for (int cc = p + 1; cc <= m; ++cc) S[lane * LDS_ + cc] = fma(-f, S[p * LDS_ + cc], S[lane * LDS_ + cc]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (sing) { give_up = true; break; }
+            if (lane < m) zv[lane] = S[lane * LDS_ + m] / S[lane * LDS_ + lane];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const bool mine = (Cm[t] >> lane) & 1ull;
+                double acc = u[t];
+                int col = 0;
+#pragma unroll
+                for (int t2 = 0; t2 < NV; ++t2) {
+                    unsigned long long left = Cm[t2];
+                    while (left) {
+                        const int j = __ffsll((long long)left) - 1 + 64 * t2;
+                        left &= left - 1;
+                        if (idx[t] < KP) acc = fma(-gi[j * KP + idx[t]], zv[col], acc);
+                        ++col;
+                    }
+                }
+                x[t] = (valid[t] && !mine) ? acc : 0.0;                  // passive: u_F - (G^-1)_FC z
+                y[t] = mine ? -zv[slot[t]] : 0.0;                        // active: the dual G x - r
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (iter == 8 * KP + 64) { give_up = true; if (lane == 0) atomicAdd(&st->nnls_capped, 1); }
+        if (lane == 0 && todo) todo[c] = give_up ? 1 : 0;
+        if (!give_up) {
+#pragma unroll
+            for (int t = 0; t < NV; ++t)
+                if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.0) ? (float)x[t] : 0.f;
+        }
+    }
+}
 
 template <int KP>
 static int launch_nnls_reg(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
-                           int64_t sc, int64_t nprob) {
+                           int64_t sc, int64_t nprob, const int* todo, const int* bad) {
     hipLaunchKernelGGL((nnls_bpp_reg_kernel<KP>), dim3((unsigned)((nprob + 3) / 4)), dim3(256), 0, E->stream, G, diag_add,
-                       R, X, sj, sc, nprob, E->k, E->state);
+                       R, X, sj, sc, nprob, E->k, E->state, todo, bad);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
 template <int KP>
 static int launch_nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj,
-                       int64_t sc, int64_t nprob) {
+                       int64_t sc, int64_t nprob, const int* todo, const int* bad) {
     constexpr int NW = KP <= 64 ? 4 : 2;
     const size_t shm = (size_t)NW * (KP * (KP + 1) + KP) * sizeof(float);
     auto kern = nnls_bpp_kernel<KP>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)((nprob + NW - 1) / NW)), dim3(64 * NW), shm, E->stream, G, diag_add,
-                       R, X, sj, sc, nprob, E->k, E->state);
+                       R, X, sj, sc, nprob, E->k, E->state, todo, bad);
     NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+template <typename T>
+static int lazy_alloc(nmfx_engine* E, T** p, int64_t count) {
+    if (*p) return NMFX_OK;
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T)));
+    NMFX_HIP(hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), E->stream));
+    return NMFX_OK;
+}
+
+// the inverse-based pass (see nnls_cinv_kernel); leaves *todo / *bad for the elimination kernel that follows
+template <int KP>
+static int launch_nnls_cinv(nmfx_engine* E, const float* G, float diag_add, const float* R, float* X, int64_t sj, int64_t sc,
+                            int64_t nprob, const int** todo, const int** bad) {
+    int rc;
+    if ((rc = lazy_alloc(E, &E->nnls_ginv, (int64_t)KP * KP + 2))) return rc;
+    { const int64_t need = E->mp > E->np ? E->mp : E->np;
+      if ((rc = lazy_alloc(E, &E->nnls_todo, need))) return rc; }
+    int* inv_bad = reinterpret_cast<int*>(E->nnls_ginv + (int64_t)KP * KP);
+    if constexpr (KP >= 64) {                           // the blocked f64-MFMA Gauss-Jordan of the AO-ADMM `prepare` (153 -> ~20 us at k = 64)
+        if ((rc = nmfx_launch_inverse64(E, G, (double)diag_add, E->nnls_ginv, inv_bad))) return rc;
+    } else {
+        const size_t shm = (size_t)(KP * (KP + 1) + KP) * sizeof(double);
+        auto kern = nnls_inverse_kernel<KP>;
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), shm, E->stream, G, diag_add, E->k, E->nnls_ginv, inv_bad, E->state);
+        NMFX_HIP(hipGetLastError());
+    }
+    {
+        constexpr int NW = KP <= 64 ? 4 : 2, MC = KP <= 64 ? 32 : 36;
+        const size_t shm = (size_t)(KP * KP + NW * (MC * (MC + 1) + MC + KP)) * sizeof(double);
+        auto kern = nnls_cinv_kernel<KP>;
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+        const int64_t blocks_needed = (nprob + NW - 1) / NW;
+        const unsigned grid = (unsigned)(blocks_needed < 1024 ? blocks_needed : 1024);     // waves loop over the problems
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, E->stream, E->nnls_ginv, inv_bad, R, X, sj, sc, nprob, E->k,
+                           E->state, E->nnls_todo);
+        NMFX_HIP(hipGetLastError());
+    }
+    *todo = E->nnls_todo; *bad = inv_bad;
     return NMFX_OK;
 }
 
@@ -458,18 +736,31 @@ static int nnls(nmfx_engine* E, const float* G, float diag_add, const float* R, 
                 int64_t nprob) {
     ProfScope ps(E, "nnls");
     static const bool lds_only = getenv("NMFX_NNLS_LDS") && atoi(getenv("NMFX_NNLS_LDS")) != 0;
+    // NMFX_NNLS_CINV=0: elimination kernels only (the round-1 path; A/B runs and tests/test_gpu_knobs.py)
+    static const bool cinv = !(getenv("NMFX_NNLS_CINV") && atoi(getenv("NMFX_NNLS_CINV")) == 0);
+    const int* todo = nullptr; const int* bad = nullptr;
+    int rc;
+    if (cinv) {
+        switch (E->kp) {
+            case 16: rc = launch_nnls_cinv<16>(E, G, diag_add, R, X, sj, sc, nprob, &todo, &bad); break;
+            case 32: rc = launch_nnls_cinv<32>(E, G, diag_add, R, X, sj, sc, nprob, &todo, &bad); break;
+            case 64: rc = launch_nnls_cinv<64>(E, G, diag_add, R, X, sj, sc, nprob, &todo, &bad); break;
+            default: rc = launch_nnls_cinv<128>(E, G, diag_add, R, X, sj, sc, nprob, &todo, &bad); break;
+        }
+        if (rc) return rc;
+    }
     switch (E->kp) {
-        case 16: return lds_only ? launch_nnls<16>(E, G, diag_add, R, X, sj, sc, nprob)
-                                 : launch_nnls_reg<16>(E, G, diag_add, R, X, sj, sc, nprob);
-        case 32: return lds_only ? launch_nnls<32>(E, G, diag_add, R, X, sj, sc, nprob)
-                                 : launch_nnls_reg<32>(E, G, diag_add, R, X, sj, sc, nprob);
-        case 64: return lds_only ? launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob)
-                                 : launch_nnls_reg<64>(E, G, diag_add, R, X, sj, sc, nprob);
+        case 16: return lds_only ? launch_nnls<16>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad)
+                                 : launch_nnls_reg<16>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad);
+        case 32: return lds_only ? launch_nnls<32>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad)
+                                 : launch_nnls_reg<32>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad);
+        case 64: return lds_only ? launch_nnls<64>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad)
+                                 : launch_nnls_reg<64>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad);
         default:
-            if (lds_only) return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob);
+            if (lds_only) return launch_nnls<128>(E, G, diag_add, R, X, sj, sc, nprob, todo, bad);
             { static const bool wide = getenv("NMFX_NNLS128_OCC") && atoi(getenv("NMFX_NNLS128_OCC")) == 1;
               hipLaunchKernelGGL(wide ? nnls_bpp_reg128_wide_kernel : nnls_bpp_reg128_kernel, dim3((unsigned)nprob), dim3(128), 0,
-                                 E->stream, G, diag_add, R, X, sj, sc, nprob, E->k, E->state); }
+                                 E->stream, G, diag_add, R, X, sj, sc, nprob, E->k, E->state, todo, bad); }
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
     }

@@ -169,8 +169,13 @@ template <int KP>
 __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
     const float* __restrict__ src, int k, float* __restrict__ Minv, DevState* __restrict__ st,
     int record_obj, const double* __restrict__ xf64, long long j, long long min_iter,
-    double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho)
+    double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho,
+    double* __restrict__ out64 = nullptr, int* __restrict__ soft_bad = nullptr)
 {
+    // out64 != nullptr (ANLS, nnls_cinv_kernel): the f64 inverse of src + fixed_rho I goes to out64 [KP][KP] instead of the
+    // f32 one to Minv, padded variables (index >= k) get a unit diagonal, the solver state is left alone, and
+    // "not positive definite" or "too ill-conditioned for an explicit inverse" (max diag(inverse) x mean diag(matrix)
+    // > 1e9) are reported in *soft_bad instead of stopping the run
     if (st->flag) return;
     if (record_obj) {
         const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
         for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
         if (lane == 0) {
             const double rho = (fixed_rho >= 0.0) ? fixed_rho : tr / (double)k;
-            misc[0] = rho; misc[1] = 0.0;
-            st->rho = rho; st->inner_stop = 0; st->inner_count = 0;
+            misc[0] = rho; misc[1] = 0.0; misc[2] = tr / (double)k + rho;
+            if (!out64) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
         }
     }
     f64x4 t[NB];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
     for (int jb = 0; jb < NB; ++jb)
         if (jb == w) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (q + 4 * r == c) t[jb][r] += rho;
+            for (int r = 0; r < 4; ++r) if (q + 4 * r == c) t[jb][r] += (out64 && 16 * w + c >= k) ? 1.0 : rho;
         }
 
 #pragma unroll
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
         }
         __syncthreads();
         if (misc[1] != 0.0) {
-            if (tid == 0) { st->notpd = 1; st->flag = 3; }
+            if (tid == 0) { if (soft_bad) *soft_bad = 1; else { st->notpd = 1; st->flag = 3; } }
             return;
         }
         if (w != kb) {
@@ -276,6 +281,30 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
                 }
             }
         }
+    }
+    if (out64) {
+        double dmax = 0.0;                              // largest diagonal entry of the inverse
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+            if (jb == w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (q + 4 * r == c && 16 * w + c < k) dmax = fmax(dmax, t[jb][r]);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+        __syncthreads();                                // (dinv is free: every wave is behind the last step)
+        if (lane == 0) dinv[w] = dmax;
+        __syncthreads();
+        if (tid == 0) {
+            double mx = 0.0;
+            for (int i = 0; i < NB; ++i) mx = fmax(mx, dinv[i]);
+            *soft_bad = (mx * misc[2] > 1e9 || !(mx == mx)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out64[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c] = t[jb][r];
+        return;
     }
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb)
@@ -913,7 +942,7 @@ static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int6
     if constexpr (KP >= 64) {
         if (!scalar) {
             constexpr int NB = KP / 16;
-            constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 2) * sizeof(double);
+            constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 4) * sizeof(double);
             { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>), (int)shm); if (rc_) return rc_; }
             hipLaunchKernelGGL((ao_prepare_mfma_kernel<KP>), dim3(1), dim3(KP * 4), shm, E->stream, src, E->k, E->Minv,
                                E->state, record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
@@ -927,6 +956,23 @@ static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int6
                        record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+
+// f64 inverse of src + diag_add I (k >= 64: the blocked f64-MFMA Gauss-Jordan above) for the ANLS complement solver
+int nmfx_launch_inverse64(nmfx_engine* E, const float* src, double diag_add, double* out64, int* soft_bad) {
+    auto go = [&](auto kp_t) -> int {
+        constexpr int KP = decltype(kp_t)::value;
+        constexpr int NB = KP / 16;
+        constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 4) * sizeof(double);
+        { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>), (int)shm); if (rc_) return rc_; }
+        hipLaunchKernelGGL((ao_prepare_mfma_kernel<KP>), dim3(1), dim3(KP * 4), shm, E->stream, src, E->k, (float*)nullptr,
+                           E->state, 0, (const double*)nullptr, 0ll, 0ll, 0.0, 0.0, (double*)nullptr, diag_add, out64, soft_bad);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    };
+    if (E->kp == 64) return go(std::integral_constant<int, 64>{});
+    if (E->kp == 128) return go(std::integral_constant<int, 128>{});
+    E->err = "inverse64: k padded to 64 or 128 only"; return NMFX_E_ARG;
 }
 
 int nmfx_launch_prepare(nmfx_engine* E, const float* src, int record_obj, int64_t j, int64_t min_iter,

@@ -91,6 +91,8 @@ struct nmfx_engine {
     unsigned short *HThi = nullptr, *HTlo = nullptr; // [np][kp], only where H^T is the Z operand (AO-ADMM's fused objective)
     double* nrm_part = nullptr;    // [blocks][4]
     double* nrm_rounds = nullptr;  // [admm_iter][blocks][4]: norm partials of the fused inner rounds
+    double* nnls_ginv = nullptr;   // ANLS: f64 inverse of the half-step's Gram matrix [kp][kp], then { int inv_bad } behind it
+    int* nnls_todo = nullptr;      // ANLS: per problem, 1 = left to the elimination kernel
     int64_t nrm_rounds_cap = 0;
     float *bkX = nullptr, *bkU = nullptr;   // initial X, U of a fused sub-problem (restart point of the repair launch)
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
@@ -118,6 +120,7 @@ struct nmfx_engine {
 // Hsrc / Vsrc: use these instead of E->H / E->V; flag2: optional second "skip" flag
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false,
                        const float* Hsrc = nullptr, const float* Vsrc = nullptr, const int* flag2 = nullptr);
+int nmfx_launch_inverse64(nmfx_engine* E, const float* src, double diag_add, double* out64, int* soft_bad);   // f64 (src + diag_add I)^-1, kp 64 / 128
 int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2 = nullptr);
 // B_part[sr] = W^T V over the rows of split sr.
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc = nullptr,
