@@ -262,6 +262,7 @@ int nmfx_synchronize(nmfx_handle_t E) {
 }
 
 int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int64_t row0, int64_t rows) {
+    if (E) E->anls_a_ready = false;
     if (!E) return NMFX_E_ARG;
     if (!host || row0 < 0 || rows < 0 || row0 + rows > E->m || ld < E->n) {
         E->err = "upload_v: bad row range or leading dimension"; return NMFX_E_ARG; }
@@ -297,6 +298,7 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
 }
 
 int nmfx_upload_v_device(nmfx_handle_t E, const void* dev, int dtype, int64_t ld, int64_t row0, int64_t rows) {
+    if (E) E->anls_a_ready = false;
     if (!E) return NMFX_E_ARG;
     if (!dev || row0 < 0 || rows < 0 || row0 + rows > E->m || ld < E->n) {
         E->err = "upload_v_device: bad row range or leading dimension"; return NMFX_E_ARG; }
@@ -363,6 +365,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->ht_ready = false;
     E->himg_both = false;
     E->lazy_objective = false;
+    E->anls_a_ready = false;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;
@@ -498,6 +501,7 @@ int nmfx_shift_iteration_base(nmfx_handle_t E, int64_t delta) {
 
 // ---- MUR -------------------------------------------------------------------
 static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
+    E->anls_a_ready = false;                           // (another solver's products overwrite A_part)
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));

@@ -776,12 +776,20 @@ static int anls_objective(nmfx_engine* E) {
     int rc;
     // distance_type = 'kl' (anls.py:108,118 + utils.py:21-26): the KL objective of the least-squares iterates,
     // by the exact-f32 objective pass in either arithmetic mode
+    E->anls_a_ready = false;
     if (E->anls_dist == NMFX_KL) return nmfx_launch_wphase(E, E->W[0], false, true, true);
     if (!anls_bf16(E)) return nmfx_launch_wphase(E, E->W[0], false, true);
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_images_w(E, E->W[0], 1))) return rc;
     if ((rc = nmfx_bf16_images_h(E, false))) return rc;
-    return nmfx_bf16_objective(E, 1, "objective");
+    // The objective pass over V is the W-side product of the NEXT iteration as well: V H^T with the residual objective of
+    // (W, H) in one launch (the MUR W phase), instead of an objective-only pass now and a product pass over the same V
+    // then.  (NMFX_ANLS_FUSE_OBJ=0: the two separate passes.)
+    static const bool fuse = !(getenv("NMFX_ANLS_FUSE_OBJ") && atoi(getenv("NMFX_ANLS_FUSE_OBJ")) == 0);
+    if (!fuse) return nmfx_bf16_objective(E, 1, "objective");
+    if ((rc = nmfx_bf16_vht(E, true, 1, "wphase", false, 4))) return rc;
+    E->anls_a_ready = true;
+    return NMFX_OK;
 }
 
 static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, double tol1, double tol2, int64_t j) {
@@ -792,8 +800,11 @@ static int anls_w_and_products(nmfx_engine* E, double lam_w, int64_t min_iter, d
     if (anls_bf16(E)) {     // the same steps with the products on the split-bf16 kernels (kp = 64 / 128)
         const bool byprod = E->kp == 64;                                   // Gram matrices as by-products
         if ((rc = nmfx_bf16_prepare(E))) return rc;
-        if ((rc = nmfx_bf16_images_h(E, false))) return rc;
-        if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
+        if (!E->anls_a_ready) {                                            // (else: A_part and the H H^T slabs come from the objective pass)
+            if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+            if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj"))) return rc;
+        }
+        E->anls_a_ready = false;
         if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
         if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
         if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
@@ -873,6 +884,7 @@ extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
 extern "C" int nmfx_anls_set_distance(nmfx_handle_t E, int distance) {
     if (!E || (distance != NMFX_EU && distance != NMFX_KL)) { if (E) E->err = "Unknown distance type."; return NMFX_E_ARG; }
     E->anls_dist = distance;
+    E->anls_a_ready = false;
     return NMFX_OK;
 }
 

@@ -1307,6 +1307,7 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
         E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
+    E->anls_a_ready = false;
     int rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -1333,6 +1334,7 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
+    E->anls_a_ready = false;
     int rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;

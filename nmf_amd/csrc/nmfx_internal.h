@@ -100,6 +100,7 @@ struct nmfx_engine {
     int wsplit = 1, hsplit = 1, gsplit = 1;
     bool have_v = false, have_f = false;
     int anls_dist = NMFX_EU;       // objective ANLS reports (anls.py:108,118): the iterates are least-squares either way
+    bool anls_a_ready = false;    // ANLS: A_part / H H^T slabs of the CURRENT (W, H) are valid (produced by the fused objective pass)
     int wsel = 0;                  // W buffer holding the current iterate
     bool w_in_place = false;       // solver updates W[0] in place (all but MUR, which ping-pongs)
     // profiling
