@@ -111,6 +111,10 @@ int nmfx_get_objectives(nmfx_handle_t h, int64_t first, int64_t count, double* o
  * (a dead or collinear component at lambda = 0; their x stays 0 like in scipy's nnls / nmf/fcnnls.py) and solves that
  * ran into the iteration cap (8 k + 64 exchanges; the reference's FCNNLS prints 'Not converged.' in that case).      */
 int nmfx_get_diagnostics(nmfx_handle_t h, int64_t* nnls_evicted, int64_t* nnls_capped);
+/* How often the default NNLS path (f64 inverse of the Gram matrix + complement of the passive set) handed work
+ * to the elimination kernels since the last nmfx_set_factors: single problems (complement larger than its workspace), and whole
+ * half-steps (Gram matrix singular or too ill-conditioned for an explicit inverse).                                         */
+int nmfx_get_nnls_fallbacks(nmfx_handle_t h, int64_t* problems, int64_t* half_steps);
 
 /* ---- MUR (replaces the loop body nmf/mur.py:119-131) -------------------- */
 /* Queue `count` outer iterations starting at iteration `first` (= number of

@@ -67,7 +67,7 @@ __global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t lds,
 __global__ void init_state_kernel(DevState* st) {
     st->flag = 0; st->stop_i = -1; st->n_obj = 0; st->obj_prev = 0.0;
     st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0; st->j_base = 0;
-    st->nnls_evicted = 0; st->nnls_capped = 0;
+    st->nnls_evicted = 0; st->nnls_capped = 0; st->nnls_fallback = 0; st->nnls_noinv = 0;
 }
 
 __global__ void shift_iteration_base_kernel(DevState* st, long long delta) { st->j_base += delta; }
@@ -437,6 +437,15 @@ int nmfx_get_diagnostics(nmfx_handle_t E, int64_t* nnls_evicted, int64_t* nnls_c
     if ((rc = read_state(E, &hs))) return rc;
     if (nnls_evicted) *nnls_evicted = hs.nnls_evicted;
     if (nnls_capped) *nnls_capped = hs.nnls_capped;
+    return NMFX_OK;
+}
+
+int nmfx_get_nnls_fallbacks(nmfx_handle_t E, int64_t* problems, int64_t* half_steps) {
+    if (!E) return NMFX_E_ARG;
+    DevState hs; int rc;
+    if ((rc = read_state(E, &hs))) return rc;
+    if (problems) *problems = hs.nnls_fallback;
+    if (half_steps) *half_steps = hs.nnls_noinv;
     return NMFX_OK;
 }
 

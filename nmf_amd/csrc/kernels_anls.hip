@@ -515,7 +515,8 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
     const double* __restrict__ Ginv, const int* __restrict__ inv_bad, const float* __restrict__ R, float* __restrict__ X,
     int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, int* __restrict__ todo)
 {
-    if (st->flag || *inv_bad) return;
+    if (st->flag) return;
+    if (*inv_bad) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st->nnls_noinv, 1); return; }
     constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
     constexpr int NW = KP <= 64 ? 4 : 2;                // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
     constexpr int MC = KP <= 64 ? 32 : 36;              // largest complement solved here
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
         }
         if (iter == 8 * KP + 64) { give_up = true; if (lane == 0) atomicAdd(&st->nnls_capped, 1); }
         if (lane == 0 && todo) todo[c] = give_up ? 1 : 0;
+        if (lane == 0 && give_up) atomicAdd(&st->nnls_fallback, 1);
         if (!give_up) {
 #pragma unroll
             for (int t = 0; t < NV; ++t)

@@ -36,6 +36,8 @@ struct DevState {          // lives in device memory, written by kernels
     // component at lambda = 0: its x stays 0, as in Lawson-Hanson / FCNNLS), solves that hit the iteration cap
     int nnls_evicted;
     int nnls_capped;
+    int nnls_fallback;     // problems the inverse + complement pass left to the elimination kernel (complement too large)
+    int nnls_noinv;        // half-steps whose Gram matrix had no usable explicit inverse (all problems to the elimination kernel)
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };

@@ -258,6 +258,12 @@ class Engine:
         self._ck(self.lib.nmfx_get_diagnostics(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def nnls_fallbacks(self):
+        """(problems, half-steps) the inverse + complement NNLS pass left to the elimination kernels."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_get_nnls_fallbacks(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def anls_run(self, lam_w, lam_h, min_iter, tol1, tol2, first, count):
         self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
                                         float(tol2), int(first), int(count)))

@@ -18,7 +18,7 @@ prof = {}
 for kn in ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "pack", "nnls", "small", "sums"):
     ms, cnt = eng.profile_get(kn)
     if cnt: prof[kn] = (round(ms / cnt * 1e3, 1), cnt / 3)
-print(f"ANLS {m}x{n} k={k}: {1/dt:.1f} iter/s {dt*1e3:.2f} ms", prof)
+print(f"ANLS {m}x{n} k={k}: {1/dt:.1f} iter/s {dt*1e3:.2f} ms", prof, "nnls fallbacks (problems, half-steps) after 10 iterations:", eng.nnls_fallbacks())
 if "--stats" in sys.argv:          # library built with NMFX_EXTRA_DEFS=-DNMFX_NNLS_STATS
     import ctypes
     from nmf_amd import _lib
