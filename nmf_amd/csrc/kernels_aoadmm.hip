@@ -627,6 +627,20 @@ __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_round
     return count;
 }
 
+// ---- split-bf16 pieces for the inner product of the fused W-side rounds (k padded to 64 / 128) ----
+typedef __bf16 ao_bf16x8 __attribute__((ext_vector_type(8)));
+union AoFrag8 { uint4 u; ao_bf16x8 v; };
+#define AO_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, (c), 0, 0, 0)
+__device__ __forceinline__ void ao_split2(float a, float b, unsigned& hi, unsigned& lo) {      // x = hi + lo, both bf16 (round to nearest even)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));
+}
+__device__ __forceinline__ void ao_split8(const float4& p, const float4& q, AoFrag8& hi, AoFrag8& lo) {
+    ao_split2(p.x, p.y, hi.u.x, lo.u.x); ao_split2(p.z, p.w, hi.u.y, lo.u.y);
+    ao_split2(q.x, q.y, hi.u.z, lo.u.z); ao_split2(q.z, q.w, hi.u.w, lo.u.w);
+}
+
 // ---- all rounds of a sub-problem in ONE launch ------------------------------
 // A round only couples the blocks through `terminate` (four global norms, ao_admm.py:33-43).
 // The fused kernels therefore run ALL admm_iter rounds speculatively with X, U (and the
@@ -824,9 +838,33 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     }
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    // k padded to 64 / 128: the product of a round, aux = rhs M^-1 (16 x KP x KP per wave), runs on the bf16 matrix cores with
+    // BOTH operands split hi + lo and all four terms (f32-grade, like the V-sized products of ADMM / ANLS): 128 MFMAs of 16
+    // cycles per wave and round at k = 128 instead of 256 f32 MFMAs of 32 -- the rounds were bound by the f32 MFMA rate of
+    // the CU a block runs on.  M^-1 is staged ONCE as two bf16 images [KP][KP] (16-byte chunk c of row r at c ^ swz(r)), the
+    // right-hand side tile of a wave [16][KP] f32 with chunk c of row r at c ^ r: conflict-free for the fragment reads
+    // (tools/lab/swizzle_search.py's bank model).
+    constexpr bool SPLIT = KP >= 64;
+    constexpr int KS = KP / 32;                        // k-steps of 32
+    unsigned short* mhi = reinterpret_cast<unsigned short*>(lds);
+    unsigned short* mlo = mhi + KP * KP;
+    auto swzm = [](int r) { return KP == 128 ? (r & 15) : ((r & 15) >> 1); };
+    if (SPLIT) {
+        for (int i = tid; i < KP * (KP / 8); i += RB * 4) {
+            const int r = i / (KP / 8), c8 = i % (KP / 8);
+            const float4 a = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8);
+            const float4 b = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8 + 4);
+            AoFrag8 h, l;
+            ao_split8(a, b, h, l);
+            const int pos = c8 ^ swzm(r);
+            *reinterpret_cast<uint4*>(mhi + r * KP + 8 * pos) = h.u;
+            *reinterpret_cast<uint4*>(mlo + r * KP + 8 * pos) = l.u;
+        }
+    } else {
     for (int i = tid; i < KP * (KP / 4); i += RB * 4) {
         const int r = i / (KP / 4), c4 = i % (KP / 4);
         *reinterpret_cast<float4*>(lds + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
+    }
     }
     const int64_t r0 = (int64_t)blockIdx.x * RB + wave * 16;
     float* myrs = rs + wave * 16 * LDR;
@@ -850,15 +888,45 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
 #pragma unroll
         for (int it = 0; it < JT; ++it)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) myrs[(4 * q + g) * LDR + 16 * it + x] = ax0[it][g] + rho * (wx[it][g] + dx[it][g]);
+            for (int g = 0; g < 4; ++g) {
+                const float v = ax0[it][g] + rho * (wx[it][g] + dx[it][g]);
+                if (SPLIT) { const int row = 4 * q + g, col = 16 * it + x; myrs[row * KP + 4 * ((col >> 2) ^ row) + (col & 3)] = v; }
+                else myrs[(4 * q + g) * LDR + 16 * it + x] = v;
+            }
         __syncthreads();
-        float4 xf[JT];
+        float4 xf[SPLIT ? 1 : JT];
+        AoFrag8 ah[SPLIT ? KS : 1], al[SPLIT ? KS : 1];
+        if (SPLIT) {                                   // A operand: row x of the tile, k block q of k-step u (8 consecutive factors)
 #pragma unroll
-        for (int u = 0; u < JT; ++u) xf[u] = *reinterpret_cast<const float4*>(myrs + x * LDR + 16 * u + 4 * q);
+            for (int u = 0; u < KS; ++u) {
+                const float4 p0 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q) ^ x));
+                const float4 p1 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q + 1) ^ x));
+                ao_split8(p0, p1, ah[u], al[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < JT; ++u) xf[u] = *reinterpret_cast<const float4*>(myrs + x * LDR + 16 * u + 4 * q);
+        }
         float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
 #pragma unroll
         for (int it = 0; it < JT; ++it) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (SPLIT) {
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};     // two chains: consecutive MFMAs never wait for each other
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {         // B operand: M^-1 row 16 it + x (= column, by symmetry of the convention), k block q
+                    const int off = (16 * it + x) * KP + 8 * ((4 * u + q) ^ swzm(x));
+                    AoFrag8 bh, bl;
+                    bh.u = *reinterpret_cast<const uint4*>(mhi + off);
+                    bl.u = *reinterpret_cast<const uint4*>(mlo + off);
+                    acc = AO_MFMA_BF16(ah[u], bh, acc);
+                    acc2 = AO_MFMA_BF16(al[u], bh, acc2);
+                    acc = AO_MFMA_BF16(ah[u], bl, acc);
+                    acc2 = AO_MFMA_BF16(al[u], bl, acc2);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] += acc2[g];
+            } else {
 #pragma unroll
             for (int u = 0; u < JT; ++u) {
                 const float4 mb = *reinterpret_cast<const float4*>(lds + (16 * it + x) * LDM + 16 * u + 4 * q);
@@ -866,6 +934,7 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
                 acc = MFMA(xf[u].y, mb.y, acc);
                 acc = MFMA(xf[u].z, mb.z, acc);
                 acc = MFMA(xf[u].w, mb.w, acc);
+            }
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
