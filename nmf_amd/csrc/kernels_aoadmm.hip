@@ -130,10 +130,13 @@ __global__ __launch_bounds__((KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4)
 //   (a) wave kb inverts its diagonal tile D in place (16 scalar pivots inside ONE wave, row broadcast by
 //       ds_bpermute, column broadcast by DPP row_share, no barrier; these are the pivots of the unblocked
 //       elimination, so "not positive definite" is detected on the same condition),
-//   (b) wave kb turns its row panel into D^-1 T[kb][j] (MFMA) and publishes it with D^-1,
+//       and publishes D^-1 and its OLD row panel T[kb][j],
 //       -- one workgroup barrier --
-//   (c) every other wave i: T[i][j] -= T[i][kb] (D^-1 T[kb][j]),  T[i][kb] = -T[i][kb] D^-1  (MFMA).
-// Wave kb+1 goes on to (a), (b) of the next step as soon as its own (c) is done; the published
+//   (b) wave kb turns its own row panel into D^-1 T[kb][j] (MFMA),
+//   (c) at the same time every other wave i: L = -T[i][kb] D^-1 (its new T[i][kb]), T[i][j] += L T_old[kb][j]  (MFMA) --
+//       the reassociated form of T[i][j] -= T[i][kb] (D^-1 T[kb][j]), so that (b) is no longer between (a) and (c) on the
+//       critical path of a step (r2: 52 -> 44 us at k = 128).
+// Wave kb+1 goes on to (a) of the next step as soon as its own (c) is done; the published
 // panels are double buffered, so the one barrier per step is enough.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -221,7 +224,12 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
         double* dv = dinv + (kb & 1) * 16 * LDD;
         double* rn = rown + (kb & 1) * 16 * LDP;
         if (w == kb) {
+            // the OLD row panel (updated through step kb - 1) for everybody, then
             // (a) in-wave inversion of the diagonal tile; same adjusted-pivot update as the scalar kernel
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rn[(q + 4 * r) * LDP + 16 * jb + c] = t[jb][r];
             f64x4 a = t[kb];
             const bool bad = !(gj16_pivot<0>(a, c, q) && gj16_pivot<1>(a, c, q) && gj16_pivot<2>(a, c, q) &&
                                gj16_pivot<3>(a, c, q) && gj16_pivot<4>(a, c, q) && gj16_pivot<5>(a, c, q) &&
@@ -233,34 +241,30 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dv[(q + 4 * r) * LDD + c] = a[r];
-                // (b) row panel: old tiles through LDS into the B layout, new = D^-1 * old
-#pragma unroll
-                for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rowo[(q + 4 * r) * LDP + 16 * jb + c] = t[jb][r];
-                __builtin_amdgcn_wave_barrier();
-                double af[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) af[s4] = dv[c * LDD + 4 * s4 + q];
-#pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    if (jb == kb) { t[jb] = a; continue; }
-                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(af[s4], rowo[(4 * s4 + q) * LDP + 16 * jb + c], acc);
-                    t[jb] = acc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rn[(q + 4 * r) * LDP + 16 * jb + c] = acc[r];
-                }
             }
+            t[kb] = a;
         }
         __syncthreads();
         if (misc[1] != 0.0) {
             if (tid == 0) { if (soft_bad) *soft_bad = 1; else { st->notpd = 1; st->flag = 3; } }
             return;
         }
-        if (w != kb) {
-            // (c) A operand = -T[w][kb] (through this wave's own LDS tile), B = the published panel / D^-1
+        if (w == kb) {
+            // (b) own row panel: new = D^-1 * old (old tiles from the published panel) -- off the critical path of the step:
+            //     the other waves no longer wait for it (r2), they use the OLD panel, see (c)
+            double af[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) af[s4] = dv[c * LDD + 4 * s4 + q];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                if (jb == kb) continue;
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(af[s4], rn[(4 * s4 + q) * LDP + 16 * jb + c], acc);
+                t[jb] = acc;
+            }
+        } else {
+            // (c) L = -T[w][kb] D^-1 (the new T[w][kb]), then T[w][j] += L T_old[kb][j]: A operands through this wave's own LDS tile
             double* cp = colp + w * 16 * LDD;
 #pragma unroll
             for (int r = 0; r < 4; ++r) cp[(q + 4 * r) * LDD + c] = t[kb][r];
@@ -268,17 +272,21 @@ __global__ __launch_bounds__(KP * 4) void ao_prepare_mfma_kernel(
             double af[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) af[s4] = -cp[c * LDD + 4 * s4 + q];
+            f64x4 l = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) l = MFMA_F64(af[s4], dv[(4 * s4 + q) * LDD + c], l);
+            t[kb] = l;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[(q + 4 * r) * LDD + c] = l[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) af[s4] = cp[c * LDD + 4 * s4 + q];
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
-                if (jb == kb) {
-                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                if (jb == kb) continue;
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(af[s4], dv[(4 * s4 + q) * LDD + c], acc);
-                    t[jb] = acc;
-                } else {
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) t[jb] = MFMA_F64(af[s4], rn[(4 * s4 + q) * LDP + 16 * jb + c], t[jb]);
-                }
+                for (int s4 = 0; s4 < 4; ++s4) t[jb] = MFMA_F64(af[s4], rn[(4 * s4 + q) * LDP + 16 * jb + c], t[jb]);
             }
         }
     }
