@@ -510,16 +510,19 @@ __global__ __launch_bounds__(256) void nnls_inverse_kernel(const float* __restri
     for (int i = tid; i < KP * KP; i += 256) Ginv[i] = A[(i / KP) * LD + (i % KP)];
 }
 
-template <int KP>
-__global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
+// SECOND = true (k = 128 only): a second pass over the problems the first one left (todo[c] = 1), one wave per block with
+// the whole remaining LDS as its workspace (complements up to 56): at k = 128 a fifth of the problems of the first
+// iterations have complements above 36, and the elimination kernel needs ~280 us for each of them.
+template <int KP, bool SECOND = false>
+__global__ __launch_bounds__(SECOND ? 64 : (KP <= 64 ? 256 : 128)) void nnls_cinv_kernel(
     const double* __restrict__ Ginv, const int* __restrict__ inv_bad, const float* __restrict__ R, float* __restrict__ X,
     int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, int* __restrict__ todo)
 {
     if (st->flag) return;
-    if (*inv_bad) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st->nnls_noinv, 1); return; }
+    if (*inv_bad) { if (!SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st->nnls_noinv, 1); return; }
     constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
-    constexpr int NW = KP <= 64 ? 4 : 2;                // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
-    constexpr int MC = KP <= 64 ? 32 : 36;              // largest complement solved here
+    constexpr int NW = SECOND ? 1 : (KP <= 64 ? 4 : 2); // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
+    constexpr int MC = SECOND ? 56 : (KP <= 64 ? 32 : 36);   // largest complement solved here
     constexpr int LDS_ = MC + 1;
     constexpr int WSZ = MC * LDS_ + MC + KP;            // per wave: S [MC][MC + 1] | z [MC] | r broadcast [KP]
     extern __shared__ __attribute__((aligned(16))) double cinv_lds[];
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
     for (int i = threadIdx.x; i < KP * KP; i += 64 * NW) gi[i] = Ginv[i];
     __syncthreads();
     for (int64_t c = (int64_t)blockIdx.x * NW + wave; c < nprob; c += (int64_t)gridDim.x * NW) {
+        if (SECOND && !todo[c]) continue;               // (wave-uniform) solved by the first pass
         int idx[NV]; bool valid[NV], inF[NV];
         double r[NV], u[NV], x[NV], y[NV];
 #pragma unroll
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_cinv_kernel(
         }
         if (iter == 8 * KP + 64) { give_up = true; if (lane == 0) atomicAdd(&st->nnls_capped, 1); }
         if (lane == 0 && todo) todo[c] = give_up ? 1 : 0;
-        if (lane == 0 && give_up) atomicAdd(&st->nnls_fallback, 1);
+        if (lane == 0 && give_up && (SECOND || KP <= 64)) atomicAdd(&st->nnls_fallback, 1);      // (k = 128: counted where it is final)
         if (!give_up) {
 #pragma unroll
             for (int t = 0; t < NV; ++t)
@@ -727,6 +731,16 @@ static int launch_nnls_cinv(nmfx_engine* E, const float* G, float diag_add, cons
         const int64_t blocks_needed = (nprob + NW - 1) / NW;
         const unsigned grid = (unsigned)(blocks_needed < 1024 ? blocks_needed : 1024);     // waves loop over the problems
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, E->stream, E->nnls_ginv, inv_bad, R, X, sj, sc, nprob, E->k,
+                           E->state, E->nnls_todo);
+        NMFX_HIP(hipGetLastError());
+    }
+    if constexpr (KP == 128) {                          // second pass: larger workspace, one wave per block, the first pass's leftovers
+        constexpr int MC2 = 56;
+        const size_t shm = (size_t)(KP * KP + (MC2 * (MC2 + 1) + MC2 + KP)) * sizeof(double);
+        auto kern = nnls_cinv_kernel<KP, true>;
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+        const unsigned grid = (unsigned)(nprob < 512 ? nprob : 512);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shm, E->stream, E->nnls_ginv, inv_bad, R, X, sj, sc, nprob, E->k,
                            E->state, E->nnls_todo);
         NMFX_HIP(hipGetLastError());
     }
