@@ -1834,6 +1834,125 @@ static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int6
 // MUR-Euclidean, k = 128: split-bf16 products, the same epilogue kernels as k = 64 (they also write the
 // images of the new factors), Gram matrices from the Gram kernels (no by-product at this width)
 // between them, and one image pass per factor update.
+// ---------------------------------------------------------------------------------------------------------------------
+// W^T W from the transposed bf16 images of W (WThi / WTlo [kp][mp], written by the W epilogue) for k padded to 128, where
+// the product kernel has no Gram by-product.  The exact-f32 gram_tn_kernel reads W eight times through L2 (one block per
+// tile ROW of G and row split) with 4-byte loads: 124 us at 131072 rows.  Here a block takes a range of rows and ALL 64
+// tiles: wave w = tile row w; per step of 64 rows every wave loads ITS OWN tile row (the lane's 16 bytes are its A
+// fragment as they stand), publishes it in LDS (chunk c of factor row f at c ^ (f >> 1 & 7): conflict free for the
+// fragment reads), and takes the eight B fragments from there; four-term split products; double-buffered stage, one
+// barrier per step.  Up to 256 row splits, folded to E->gsplit slabs by a second small launch.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(KP * 4) void gram_tn_bf16_kernel(
+    const unsigned short* __restrict__ Thi, const unsigned short* __restrict__ Tlo, int64_t ld, int64_t nsteps,
+    float* __restrict__ out, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    constexpr int NB = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gst[];     // [2 buffers][2 images][KP][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, x = lane & 15, g = lane >> 4;
+    const int S = gridDim.x, s = blockIdx.x;
+    const int64_t t0 = nsteps * s / S, t1 = nsteps * (s + 1) / S;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int swz = (x >> 1) & 7;
+    const unsigned short* ph = Thi + (int64_t)(16 * w + x) * ld + 8 * g;
+    const unsigned short* pl = Tlo + (int64_t)(16 * w + x) * ld + 8 * g;
+    Frag8 nh[2], nl[2];
+    if (t0 < t1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            nh[ks].u = *reinterpret_cast<const uint4*>(ph + 64 * t0 + 32 * ks);
+            nl[ks].u = *reinterpret_cast<const uint4*>(pl + 64 * t0 + 32 * ks);
+        }
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+        unsigned char* bufh = gst + (size_t)((t - t0) & 1) * (2 * KP * 128);
+        unsigned char* bufl = bufh + KP * 128;
+        Frag8 ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ah[ks] = nh[ks]; al[ks] = nl[ks];
+            const int off = (16 * w + x) * 128 + 16 * ((4 * ks + g) ^ swz);
+            *reinterpret_cast<uint4*>(bufh + off) = ah[ks].u;
+            *reinterpret_cast<uint4*>(bufl + off) = al[ks].u;
+        }
+        __syncthreads();
+        if (t + 1 < t1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                nh[ks].u = *reinterpret_cast<const uint4*>(ph + 64 * (t + 1) + 32 * ks);
+                nl[ks].u = *reinterpret_cast<const uint4*>(pl + 64 * (t + 1) + 32 * ks);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int off = (16 * j + x) * 128 + 16 * ((4 * ks + g) ^ swz);
+                Frag8 bh, bl;
+                bh.u = *reinterpret_cast<const uint4*>(bufh + off);
+                bl.u = *reinterpret_cast<const uint4*>(bufl + off);
+                acc[j] = MFMA_BF16(ah[ks], bh, acc[j]);
+                acc[j] = MFMA_BF16(al[ks], bh, acc[j]);
+                acc[j] = MFMA_BF16(ah[ks], bl, acc[j]);
+                acc[j] = MFMA_BF16(al[ks], bl, acc[j]);
+            }
+        }
+    }
+    float* o = out + (int64_t)s * KP * KP;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(int64_t)(16 * w + 4 * g + r) * KP + 16 * j + x] = acc[j][r];
+}
+
+// out[f] = sum over p = f, f + F, f + 2 F, ... of part[p]   (slabs of `count` floats; fixed order)
+__global__ __launch_bounds__(256) void fold_slabs_kernel(const float* __restrict__ part, int slabs, int64_t count, int F,
+                                                         float* __restrict__ out, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (i4 * 4 >= count) return;
+    float4 a = *reinterpret_cast<const float4*>(part + (int64_t)f * count + i4 * 4);
+    for (int p = f + F; p < slabs; p += F) {
+        const float4 t = *reinterpret_cast<const float4*>(part + (int64_t)p * count + i4 * 4);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)f * count + i4 * 4) = a;
+}
+
+int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs) {
+    ProfScope ps(E, "gram_tn");
+    if (E->kp != 128) { E->err = "bf16_gram_tn: k padded to 128 only"; return NMFX_E_ARG; }
+    constexpr int KP = 128;
+    int rc;
+    const int64_t nsteps = E->mp / 64, kk = (int64_t)KP * KP;
+    int S = (int)std::min<int64_t>(256, std::max<int64_t>(1, nsteps / 4));
+    const size_t shm = (size_t)2 * 2 * KP * 128;
+    auto kern = gram_tn_bf16_kernel<KP>;
+    if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+    const bool fold = S > E->gsplit;
+    float* dst = E->G_part;
+    if (fold) {
+        if ((rc = lazy_alloc(E, &E->G_big, (int64_t)256 * kk))) return rc;
+        dst = E->G_big;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(KP * 4), shm, E->stream, E->WThi, E->WTlo, E->mp, nsteps, dst, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    if (fold) {
+        hipLaunchKernelGGL(fold_slabs_kernel, dim3((unsigned)((kk / 4 + 255) / 256), (unsigned)E->gsplit), dim3(256), 0, E->stream,
+                           E->G_big, S, kk, E->gsplit, E->G_part, &E->state->flag);
+        NMFX_HIP(hipGetLastError());
+        S = E->gsplit;
+    }
+    *slabs = S;
+    return NMFX_OK;
+}
+
 static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) {
     int rc;
     const int cur = (int)(j & 1), nxt = cur ^ 1;
@@ -1842,9 +1961,10 @@ static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) 
       if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc; }
     if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", false, 3))) return rc;
     if ((rc = launch_w_update_bf16<128>(E, E->W[cur], E->W[nxt], nxt, E->HHt, 1, (float)lambda_w))) return rc;
-    if ((rc = nmfx_launch_gram_tn(E, E->W[nxt], E->mp, E->G_part, E->gsplit))) return rc;
+    int gslabs = E->gsplit;                            // W^T W from the images the epilogue above has just written
+    if ((rc = nmfx_bf16_gram_tn(E, &gslabs))) return rc;
     if ((rc = nmfx_bf16_vtw(E, false, "hphase", false, 3))) return rc;
-    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, E->gsplit, (int64_t)(E->mp / 128) * E->bf_wsplit);
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, gslabs, (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
 static int mur_eu_phase_b_bf16_k128(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
