@@ -706,9 +706,31 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     const int64_t c0 = (int64_t)blockIdx.x * CB;
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    // k padded to 64 / 128, 32-column blocks (r2): the product aux = M^-1 rhs on the bf16 matrix cores, both operands split,
+    // four terms -- as on the W side.  M^-1 staged once as two swizzled bf16 images (A operand: its rows); the right-hand side
+    // tile is kept TRANSPOSED in LDS ([column][factor] f32, 16-byte chunk c of the row of lane x at c ^ x), so that the B
+    // operand -- 8 consecutive factors of one column -- is two 16-byte reads + a split.
+    constexpr bool SPLIT = KP >= 64 && CB == 32;
+    constexpr int KS = KP / 32;
+    unsigned short* mhi = reinterpret_cast<unsigned short*>(ms);
+    unsigned short* mlo = mhi + KP * KP;
+    auto swzm = [](int r) { return KP == 128 ? (r & 15) : ((r & 15) >> 1); };
+    if (SPLIT) {
+        for (int i = tid; i < KP * (KP / 8); i += 256) {
+            const int r = i / (KP / 8), c8 = i % (KP / 8);
+            const float4 a4 = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8);
+            const float4 b4 = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8 + 4);
+            AoFrag8 h, l;
+            ao_split8(a4, b4, h, l);
+            const int pos = c8 ^ swzm(r);
+            *reinterpret_cast<uint4*>(mhi + r * KP + 8 * pos) = h.u;
+            *reinterpret_cast<uint4*>(mlo + r * KP + 8 * pos) = l.u;
+        }
+    } else {
     for (int i = tid; i < KP * (KP / 4); i += 256) {
         const int r = i / (KP / 4), c4 = i % (KP / 4);
         *reinterpret_cast<float4*>(ms + r * LDM + 4 * c4) = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 4 * c4);
+    }
     }
     float hx[ITW][4][NE], ux[ITW][4][NE], bx[ITW][4][NE];
     const float* srcX = repair ? Xb : X;
@@ -736,6 +758,17 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
         for (int r = 0; r < ITW; ++r) {
             const int it = wave + 4 * r;
             if (it < JT) {
+                if (SPLIT) {                           // transposed: column NE x + e, factors 16 it + 4 q .. + 3 = chunk 4 it + q
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float4 t4;
+                        t4.x = bx[r][0][e] + rho * (hx[r][0][e] + ux[r][0][e]);
+                        t4.y = bx[r][1][e] + rho * (hx[r][1][e] + ux[r][1][e]);
+                        t4.z = bx[r][2][e] + rho * (hx[r][2][e] + ux[r][2][e]);
+                        t4.w = bx[r][3][e] + rho * (hx[r][3][e] + ux[r][3][e]);
+                        *reinterpret_cast<float4*>(lds + (NE * x + e) * KP + 4 * ((4 * it + q) ^ x)) = t4;
+                    }
+                } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float t[NE];
@@ -743,14 +776,27 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                     for (int e = 0; e < NE; ++e) t[e] = bx[r][g][e] + rho * (hx[r][g][e] + ux[r][g][e]);
                     stv<NE>(lds + (16 * it + 4 * q + g) * CB + NE * x, t);
                 }
+                }
             }
         }
         __syncthreads();
         float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
         // CB = 32: the wave's B fragments of the whole RHS tile (KP x NE floats per lane) are read ONCE per
         // round and shared by its row tiles; read inside the MFMA loop they cost one LDS latency per k-step
-        constexpr bool PRE = (CB == 32);
+        constexpr bool PRE = (CB == 32) && !SPLIT;
         float rball[PRE ? JT : 1][4][NE];
+        AoFrag8 bh[SPLIT ? KS : 1][NE], bl[SPLIT ? KS : 1][NE];
+        if (SPLIT) {                                   // B operands of the whole tile, once per round: column NE x + e, k block q of k-step u
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const float* row = lds + (NE * x + e) * KP;
+                    const float4 p0 = *reinterpret_cast<const float4*>(row + 4 * ((8 * u + 2 * q) ^ x));
+                    const float4 p1 = *reinterpret_cast<const float4*>(row + 4 * ((8 * u + 2 * q + 1) ^ x));
+                    ao_split8(p0, p1, bh[SPLIT ? u : 0][e], bl[SPLIT ? u : 0][e]);
+                }
+        }
         if (PRE) {
 #pragma unroll
             for (int u = 0; u < JT; ++u)
@@ -764,12 +810,29 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                 f32x4 acc[NE];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float4 mfa[JT];
+                if (SPLIT) {
 #pragma unroll
-                for (int u = 0; u < JT; ++u)
+                    for (int u = 0; u < KS; ++u) {     // A operand: M^-1 row 16 it + x, k block q of k-step u
+                        const int off = (16 * it + x) * KP + 8 * ((4 * u + q) ^ swzm(x));
+                        AoFrag8 ah, al;
+                        ah.u = *reinterpret_cast<const uint4*>(mhi + off);
+                        al.u = *reinterpret_cast<const uint4*>(mlo + off);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(ah, bh[SPLIT ? u : 0][e], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(al, bh[SPLIT ? u : 0][e], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(ah, bl[SPLIT ? u : 0][e], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(al, bl[SPLIT ? u : 0][e], acc[e]);
+                    }
+                }
+                float4 mfa[SPLIT ? 1 : JT];
+#pragma unroll
+                for (int u = 0; u < (SPLIT ? 0 : JT); ++u)
                     mfa[u] = *reinterpret_cast<const float4*>(ms + (16 * it + x) * LDM + 16 * u + 4 * q);
 #pragma unroll
-                for (int u = 0; u < JT; ++u) {
+                for (int u = 0; u < (SPLIT ? 0 : JT); ++u) {
                     const float ma[4] = {mfa[u].x, mfa[u].y, mfa[u].z, mfa[u].w};
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) {

@@ -1932,7 +1932,6 @@ int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs) {
     int rc;
     const int64_t nsteps = E->mp / 64, kk = (int64_t)KP * KP;
     int S = (int)std::min<int64_t>(256, std::max<int64_t>(1, nsteps / 4));
-    if (S > E->gsplit && S <= 2 * E->gsplit) S = E->gsplit;     // (a second launch to fold a few slabs costs more than the longer blocks)
     const size_t shm = (size_t)2 * 2 * KP * 128;
     auto kern = gram_tn_bf16_kernel<KP>;
     if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
