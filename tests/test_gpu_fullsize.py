@@ -122,3 +122,53 @@ def test_admm_fixed_rho_8192x4096_k64_vs_oracle():
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+
+
+def test_anls_16384x8192_k64_kkt_of_both_half_steps():
+    """ANLS (nmf/anls.py:112-126) at the headline shape, where the per-column scipy oracle would take minutes: the exact NNLS
+    solutions are characterised by their KKT conditions, so those are checked in float64 instead -- H >= 0 with the gradient
+    G H - W^T V zero on its support and non-negative off it (the last half-step of an iteration), the same for the rows of
+    W against the H they were solved for -- together with objective == directly evaluated objective and monotone descent.
+    Exercises the f64 inverse + complement NNLS path and its fallback counters at scale."""
+    from nmf_amd.engine import Engine
+    m, n, k, iters = 16384, 8192, 64, 3
+    v = R.planted_matrix(m, n, k, seed=0, dtype=np.float32)
+    rs = np.random.RandomState(3)
+    w0, h0 = rs.rand(m, k), rs.rand(k, n)
+    with Engine(m, n, k) as eng:
+        eng.upload_v(v)
+        eng.set_factors(w0, h0)
+        never = 10 ** 9
+        eng.anls_run(0.0, 0.0, never, 1e-3, 1e-3, 0, iters - 1)
+        w_prev, h_prev = eng.get_factors()                 # the pair before the last iteration
+        eng.anls_run(0.0, 0.0, never, 1e-3, 1e-3, iters - 1, 1)
+        eng.aoadmm_finish(never, 1e-3, 1e-3, iters)        # records the objective of the final pair (nmf_amd/anls.py does the same)
+        w, h = eng.get_factors()
+        _, _, n_obj = eng.state()
+        obj = eng.objectives(0, n_obj)
+        left_problems, left_half_steps = eng.nnls_fallbacks()
+    v64 = v.astype(np.float64)
+
+    def kkt(g, r, x, name):
+        y = g @ x - r                                      # gradient of 0.5 x^T G x - r^T x, column by column
+        scale = np.abs(r).max(axis=0, keepdims=True) + 1e-300
+        assert x.min() >= 0.0, name
+        on, off = x > 0, x == 0
+        worst_on = float(np.max(np.abs(y / scale)[on]))
+        worst_off = float(np.min((y / scale)[off])) if off.any() else 0.0
+        print(f"KKT {name}: support {on.mean():.3f}, |grad| on support <= {worst_on:.2e} of max|r|, min grad off support {worst_off:.2e}")
+        assert worst_on < 5e-5, (name, worst_on)
+        assert worst_off > -5e-5, (name, worst_off)
+
+    # last half-step: H from (W^T W, W^T V) with the final W
+    kkt(w.T @ w, w.T @ v64, h, "H")
+    # the W half-step before it: rows of W from (H_prev H_prev^T, V H_prev^T)
+    kkt(h_prev @ h_prev.T, (v64 @ h_prev.T).T, w.T, "W")
+    assert np.all(np.isfinite(obj)) and np.all(np.diff(obj) < 0), obj
+    direct = direct_objective(v, w, h, "eu")
+    assert len(obj) == iters + 1
+    assert abs(direct - obj[-1]) <= 1e-5 * direct
+    # (how many problems the inverse + complement pass hands to the elimination kernel depends on the sparsity of the
+    #  iterates -- a third of them in these first iterations from a uniform random start, where half of H is zero)
+    print(f"NNLS problems left to the elimination kernel: {left_problems} of {iters * (m + n)}")
+    assert left_half_steps == 0
