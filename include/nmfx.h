@@ -157,6 +157,12 @@ int nmfx_exchange_sizes(nmfx_handle_t h, int64_t* n_f32, int64_t* n_f64);
  * before nmfx_mur_finish_* / the run entry points, which take absolute indices. */
 int nmfx_reserve_objectives(nmfx_handle_t h, int64_t count);
 int nmfx_shift_iteration_base(nmfx_handle_t h, int64_t delta);
+/* One collective per outer iteration instead of two (MUR, Euclidean loss, k padded to 64 / 128): with rank / world set, phase A
+ * also writes this rank's f64 objective partial into the tail of the f32 exchange buffer -- its four 16-bit digits as exact small
+ * floats in the rank's own slot, zeros in the other ranks' slots -- so that the SUM all-reduce of the f32 buffer alone delivers every
+ * rank's partial bit for bit; phase B adds them in rank order.  nmfx_exchange_sizes already includes the tail (64 ranks).
+ * world = 0 switches back to the separate all-reduce of the f64 buffer.  NMFX_E_STATE when the split-bf16 epilogues are not in use. */
+int nmfx_set_exchange_rank(nmfx_handle_t h, int rank, int world);
 int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, void* dev_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
 

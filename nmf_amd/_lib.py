@@ -68,6 +68,7 @@ SIGNATURES = {
     "nmfx_reserve_objectives": (_i32, [_vp, _i64]),
     "nmfx_shift_iteration_base": (_i32, [_vp, _i64]),
     "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),
+    "nmfx_set_exchange_rank": (_i32, [_vp, _i32, _i32]),
     "nmfx_get_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nmfx_aoadmm_run": (_i32, [_vp, _i32, _i32, _dbl, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_aoadmm_finish": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),

@@ -175,7 +175,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));
     TRY(dev_alloc(E, &E->obj_part, std::max<int64_t>(rb * ws, cb * hs) + 64));
-    TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp));
+    TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp + NMFX_XTAIL));
     TRY(dev_alloc(E, &E->xf64, 8 + 4 * NMFX_MAX_FUSED_ROUNDS));
     TRY(dev_alloc(E, &E->state, 1));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
@@ -472,8 +472,17 @@ int nmfx_get_inner_counts(nmfx_handle_t E, int64_t first, int64_t count, int32_t
 // ---- exchange buffers ----------------------------------------------------
 int nmfx_exchange_sizes(nmfx_handle_t E, int64_t* n_f32, int64_t* n_f64) {
     if (!E) return NMFX_E_ARG;
-    if (n_f32) *n_f32 = (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp;
+    if (n_f32) *n_f32 = (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp + NMFX_XTAIL;
     if (n_f64) *n_f64 = 8 + 4 * NMFX_MAX_FUSED_ROUNDS;
+    return NMFX_OK;
+}
+
+int nmfx_set_exchange_rank(nmfx_handle_t E, int rank, int world) {
+    if (!E) return NMFX_E_ARG;
+    if (world == 0) { E->xrank = -1; E->xworld = 0; return NMFX_OK; }           // back to the separate f64 exchange
+    if (world < 1 || world > NMFX_XTAIL_RANKS || rank < 0 || rank >= world) { E->err = "set_exchange_rank: 1 <= world <= 64, 0 <= rank < world"; return NMFX_E_ARG; }
+    if (!(E->precision == 1 && nmfx_bf16_supported(E))) { E->err = "set_exchange_rank: only with the split-bf16 epilogues (k padded to 64 / 128)"; return NMFX_E_STATE; }
+    E->xrank = rank; E->xworld = world;
     return NMFX_OK;
 }
 

@@ -1398,7 +1398,8 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
     int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
     DevState* __restrict__ st, double* __restrict__ obj_hist,
-    unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo)
+    unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
+    const float* __restrict__ xtail = nullptr, int xworld = 0)   // NMFX_XTAIL: every rank's objective partial, as 16-bit digits
 {
     constexpr int CB = 64, LDG = KP + 4, LDC = 80, LDD = 68, NT = 512;
     constexpr int TV = KP / 32;                        // 16-byte pieces per thread of the KP x 64 H tile / the 64 x KP B^T tile
@@ -1423,6 +1424,14 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const int stop = st->flag;
     double sacc = 0.0;
     if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += NT) sacc += osrc[i]; }
+    else if (xtail) {                                  // the partials of all ranks, exact, summed in rank order (the same on every rank)
+        for (int r = 0; r < xworld; ++r) {
+            const float4 dg = *reinterpret_cast<const float4*>(xtail + 4 * r);
+            const unsigned long long bits = (unsigned long long)dg.x | ((unsigned long long)dg.y << 16) |
+                                            ((unsigned long long)dg.z << 32) | ((unsigned long long)dg.w << 48);
+            sacc += __longlong_as_double((long long)bits);
+        }
+    }
     else sacc = osrc[0];
     float4 ht[TV];
 #pragma unroll
@@ -1826,7 +1835,8 @@ static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int6
     else
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, false>), grid, block, shm, E->stream, E->xf32, 1,
                            E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
-                           lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo);
+                           lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo,
+                           E->xworld > 0 ? E->xf32 + (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp : (const float*)nullptr, E->xworld);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

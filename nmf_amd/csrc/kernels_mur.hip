@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
     const float* __restrict__ Gpart, int gsplit, int64_t gcount,
     const double* __restrict__ objpart, int64_t nobj,
     float* __restrict__ xf32, double* __restrict__ xf64, int nb, const int* __restrict__ flag,
-    const int* __restrict__ flag2)
+    const int* __restrict__ flag2, float* __restrict__ xtail = nullptr, int xrank = 0, int xworld = 0)
 {
     if (*flag || (flag2 && *flag2)) return;
     __shared__ double sh[4];
@@ -66,6 +66,13 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
     } else {
         const double t = block_sum_f64(objpart, nobj, sh);
         if (threadIdx.x == 0) xf64[0] = t;
+        if (xtail) {                                   // NMFX_XTAIL: own slot = the four 16-bit digits of t, zeros elsewhere
+            __shared__ unsigned long long tbits;
+            if (threadIdx.x == 0) tbits = (unsigned long long)__double_as_longlong(t);
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4 * xworld; i += blockDim.x)
+                xtail[i] = (i >> 2) == xrank ? (float)((tbits >> (16 * (i & 3))) & 0xffffull) : 0.f;
+        }
     }
 }
 
@@ -215,9 +222,10 @@ int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const 
     ProfScope ps(E, "pack");
     const int nb = 256;
     const int ngb = (int)(((int64_t)E->kp * E->kp + 255) / 256);
+    float* tail = E->xworld > 0 ? E->xf32 + (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp : nullptr;
     hipLaunchKernelGGL(mur_pack_kernel, dim3(nb + ngb + 1), dim3(256), 0, E->stream, Bpart, bsplit,
                        (int64_t)E->kp * E->np, Gpart, gsplit, (int64_t)E->kp * E->kp, E->obj_part, nobj,
-                       E->xf32, E->xf64, nb, &E->state->flag, (const int*)nullptr);
+                       E->xf32, E->xf64, nb, &E->state->flag, (const int*)nullptr, tail, E->xrank, E->xworld);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

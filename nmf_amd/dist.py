@@ -105,6 +105,7 @@ class DeviceShard:
         self.xf32 = torch.zeros(n32, dtype=torch.float32, device=f"cuda:{device}")
         self.xf64 = torch.zeros(n64, dtype=torch.float64, device=f"cuda:{device}")
         torch.cuda.synchronize()
+        self._merged = None
         self.eng.set_exchange_buffers(self.xf32.data_ptr(), self.xf64.data_ptr())
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
         if v_local is not None:
@@ -115,6 +116,22 @@ class DeviceShard:
 
     def buffers(self):
         return self.xf32, self.xf64
+
+    def merge_objective(self):
+        """True once the engine carries this rank's objective partial inside the f32 exchange buffer (MUR, Euclidean loss,
+        split-bf16 epilogues; NMFX_DIST_MERGE=0 keeps the separate f64 all-reduce).  Decided once, identically on every rank:
+        it depends on the padded rank and the arithmetic mode only."""
+        if self._merged is None:
+            import os
+            import torch.distributed as tdist
+            self._merged = False
+            if os.environ.get("NMFX_DIST_MERGE", "1") != "0" and tdist.is_available() and tdist.is_initialized():
+                try:
+                    self.eng.set_exchange_rank(tdist.get_rank(), tdist.get_world_size())
+                    self._merged = True
+                except Exception:       # noqa: BLE001  (NmfxError: exact-f32 epilogues or more than 64 ranks)
+                    self._merged = False
+        return self._merged
 
     def phase_a(self, dist_code, lambda_w, j):
         self.eng.mur_phase_a(dist_code, lambda_w, j)
@@ -205,14 +222,19 @@ class DeviceShard:
         self.eng.close()
 
 
-def _mur_buffers(shard):
+def _mur_buffers(shard, dist_code=None):
+    """The exchange of one MUR iteration.  A device shard with the Euclidean loss carries its objective partial inside the f32
+    buffer (nmfx_set_exchange_rank: every rank's partial as exact 16-bit digits in its own slot), so ONE all-reduce
+    suffices; otherwise the f32 buffer and the head of the f64 buffer (its tail is the norm table of sharded AO-ADMM)."""
     x32, x64 = shard.buffers()
-    return x32, x64[:8]            # (the tail of the f64 buffer is the norm table of sharded AO-ADMM)
+    if dist_code == 0 and getattr(shard, "merge_objective", None) is not None and shard.merge_objective():
+        return (x32,)
+    return x32, x64[:8]
 
 
 def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
     """Queue `count` sharded outer iterations (no host sync)."""
-    bufs = _mur_buffers(shard)
+    bufs = _mur_buffers(shard, dist_code)
     for j in range(first, first + count):
         shard.phase_a(dist_code, lambda_w, j)
         comm.all_reduce(*bufs)
@@ -237,7 +259,7 @@ class GraphedIterations:
         self.shard, self.torch = shard, torch
         self.args = (dist_code, lambda_w, lambda_h, min_iter, tol1, tol2)
         self.graph = torch.cuda.CUDAGraph()
-        bufs = _mur_buffers(shard)
+        bufs = _mur_buffers(shard, dist_code)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         try:

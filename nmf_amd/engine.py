@@ -269,6 +269,11 @@ class Engine:
                                         float(tol2), int(first), int(count)))
 
     # -- exchange buffers (row-sharded runs) ---------------------------------
+    def set_exchange_rank(self, rank, world):
+        """The objective partial travels inside the f32 exchange buffer (one collective per MUR-Euclidean iteration);
+        world = 0 switches back.  Raises NmfxError where the engine's path does not support it."""
+        self._ck(self.lib.nmfx_set_exchange_rank(self.h, int(rank), int(world)))
+
     def exchange_sizes(self):
         a, b = C.c_int64(), C.c_int64()
         self._ck(self.lib.nmfx_exchange_sizes(self.h, C.byref(a), C.byref(b)))

@@ -75,6 +75,24 @@ def test_sharded_device_path(world, backend, k, tmp_path):
         np.testing.assert_array_equal(p["h"], h)        # replicated H is bit-identical on all ranks
 
 
+def test_sharded_device_path_with_the_separate_objective_exchange(tmp_path, monkeypatch):
+    """NMFX_DIST_MERGE=0: the f64 objective partial in its own all-reduce (the only form for the exact-f32 epilogues) instead of
+    inside the f32 buffer -- the same iterates bit for bit, the same stop index."""
+    import torch.multiprocessing as mp
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMFX_DIST_MERGE", mode)
+        d = tmp_path / mode
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), "gloo", str(d), 40), nprocs=2, join=True)
+        outs[mode] = [np.load(d / f"rank{r}.npz") for r in range(2)]
+    for r in range(2):
+        np.testing.assert_array_equal(outs["1"][r]["w"], outs["0"][r]["w"])
+        np.testing.assert_array_equal(outs["1"][r]["h"], outs["0"][r]["h"])
+        assert int(outs["1"][r]["i"]) == int(outs["0"][r]["i"])
+        np.testing.assert_allclose(outs["1"][r]["obj"], outs["0"][r]["obj"], rtol=1e-14)
+
+
 def _graph_worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
