@@ -300,10 +300,11 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             if cnt:
                 prof[kn] = {"us_per_launch": round(ms / cnt * 1e3, 2), "launches_per_iter": cnt / psteps}
         eng.profile_enable(False)
-        inner = None
+        inner = paths = None
         if admm_iter:
             inner = (eng.inner_counts(0, warmup + steps) & 0xFFFF).mean(axis=0).tolist()
             flops, nbytes = flops(inner), nbytes(inner)
+            paths = eng.inner_paths()
         dom = max((kn for kn in prof if kn in V_SIZED), key=lambda kn: prof[kn]["us_per_launch"])
         if repeat_dist is not None and dom in ("wphase", "hphase"):      # MUR: the same launch back to back (see main())
             prof[dom]["us_per_launch_with_event_per_launch"] = prof[dom]["us_per_launch"]
@@ -316,14 +317,14 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                 "dominant_kernel": {"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
                                     "algorithmic_bytes_per_launch": m * n * 4.0, "bound": "hbm",
                                     "achieved_gbs": m * n * 4.0 / dsec / 1e9, "frac": m * n * 4.0 / dsec / 1e9 / PEAK_HBM_GBS},
-                "mean_inner_rounds_h_w": inner, "objective_first_last": [float(obj[0]), float(obj[-1])],
+                "mean_inner_rounds_h_w": inner, "inner_first_leg_stood_cut_continued_both": paths, "objective_first_last": [float(obj[0]), float(obj[-1])],
                 "kernels": prof, "data": "synthetic, drawn on the device (torch generator, seed 0)",
                 "wall_s_incl_setup": round(time.perf_counter() - t_all, 1)}
     finally:
         eng.close()
 
 
-def other_configs(torch, dev):
+def other_configs(torch, dev, only=None):
     """Configs 3, 4 and 5-on-one-GPU of BASELINE.json, each a few seconds (the driver-visible numbers the
     round-1 review asked for).  A failure in one of them is reported in its slot, never hidden."""
     NEVER = 10 ** 12
@@ -356,6 +357,8 @@ def other_configs(torch, dev):
              flops=6.0 * 16384 * 8192 * 64, nbytes=3.0 * 16384 * 8192 * 4),
     ]
     for sp in specs:
+        if only and sp["name"] not in only:
+            continue
         try:
             out.append(other_config(torch, dev, **sp))
         except Exception as e:  # noqa: BLE001

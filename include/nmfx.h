@@ -115,6 +115,11 @@ int nmfx_get_diagnostics(nmfx_handle_t h, int64_t* nnls_evicted, int64_t* nnls_c
  * to the elimination kernels since the last nmfx_set_factors: single problems (complement larger than its workspace), and whole
  * half-steps (Gram matrix singular or too ill-conditioned for an explicit inverse).                                         */
 int nmfx_get_nnls_fallbacks(nmfx_handle_t h, int64_t* problems, int64_t* half_steps);
+/* AO-ADMM, fused inner rounds (nmf/ao_admm.py:58-66 run speculatively, DESIGN.md 4b "hinted speculation"): how many
+ * sub-problems since the last nmfx_set_factors had a first leg that [0] stood as it was, [1] was cut back to an earlier round, [2] had to be
+ * continued to admm_iter, [3] was continued and then cut back.  Cost diagnostics only: the rounds that count and their
+ * arithmetic are the reference's on every path.                                                                          */
+int nmfx_get_inner_paths(nmfx_handle_t h, int64_t out[4]);
 
 /* ---- MUR (replaces the loop body nmf/mur.py:119-131) -------------------- */
 /* Queue `count` outer iterations starting at iteration `first` (= number of

@@ -81,6 +81,7 @@ SIGNATURES = {
     "nmfx_anls_run": (_i32, [_vp, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_get_diagnostics": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "nmfx_get_nnls_fallbacks": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_get_inner_paths": (_i32, [_vp, C.POINTER(_i64)]),
     "nmfx_profile_enable": (_i32, [_vp, _i32]),
     "nmfx_profile_get": (_i32, [_vp, C.c_char_p, _pd, C.POINTER(_i64)]),
     "nmfx_profile_reset": (_i32, [_vp]),

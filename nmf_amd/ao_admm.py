@@ -81,6 +81,8 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
             raise
         w, h = eng.get_factors()
         inner = eng.inner_counts(0, i + 1) & 0xFFFF
+        paths = eng.inner_paths()
     res = Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)
     ao_admm.last_inner_counts = inner       # diagnostic: inner rounds per outer iteration (h, w)
+    ao_admm.last_inner_paths = paths        # diagnostic: how the speculative inner rounds went (Engine.inner_paths)
     return res

@@ -68,6 +68,8 @@ __global__ void init_state_kernel(DevState* st) {
     st->flag = 0; st->stop_i = -1; st->n_obj = 0; st->obj_prev = 0.0;
     st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0; st->j_base = 0;
     st->nnls_evicted = 0; st->nnls_capped = 0; st->nnls_fallback = 0; st->nnls_noinv = 0;
+    for (int i = 0; i < 4; ++i) { st->ao_hint[i >> 1][i & 1] = 0; st->ao_paths[i] = 0; }
+    st->ao_continued = 0;
 }
 
 __global__ void shift_iteration_base_kernel(DevState* st, long long delta) { st->j_base += delta; }
@@ -446,6 +448,14 @@ int nmfx_get_nnls_fallbacks(nmfx_handle_t E, int64_t* problems, int64_t* half_st
     if ((rc = read_state(E, &hs))) return rc;
     if (problems) *problems = hs.nnls_fallback;
     if (half_steps) *half_steps = hs.nnls_noinv;
+    return NMFX_OK;
+}
+
+int nmfx_get_inner_paths(nmfx_handle_t E, int64_t out[4]) {
+    if (!E || !out) return NMFX_E_ARG;
+    DevState hs; int rc;
+    if ((rc = read_state(E, &hs))) return rc;
+    for (int i = 0; i < 4; ++i) out[i] = hs.ao_paths[i];
     return NMFX_OK;
 }
 

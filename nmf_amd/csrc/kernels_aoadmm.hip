@@ -635,6 +635,57 @@ __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_round
     return count;
 }
 
+// What one launch of a fused sub-problem kernel has to do.  Hinted speculation (r2): the round at which `terminate` fires
+// hardly moves from one outer iteration to the next (config 3: 4, 4, 4, ... on the H side, 3, 3, 3, ... on the W side, of
+// admm_iter = 10), so the first launch runs only r1 = the previous sub-problem's count of rounds (DevState::ao_hint, written
+// by the LAST launch of that sub-problem into the slot of the other parity -- no launch reads a slot it writes).
+//   phase 0: rounds [0, r1) from the live X, U; start saved; norm partials stored.
+//   phase 1: decide over [0, r1).  Fired at the last of them (the usual case) or r1 = admm_iter without a stop: the result
+//            stands.  Fired earlier: rerun from the saved start.  Not fired and r1 < admm_iter: CONTINUE -- save the state at
+//            r1 and run [r1, admm_iter) speculatively.
+//   phase 2: nothing (one flag read) unless phase 1 continued: then decide over all rounds and rerun [r1, count) from the
+//            state saved at r1.  The launch that decides leaves the next hint.
+// Every path performs the reference's rounds 0 .. count-1 in order with the same arithmetic (states pass through memory as
+// the f32 values they are), so the hint changes the cost only.  hint_rd = nullptr: r1 = admm_iter, phases 0 and 1 are the
+// speculate / repair pair of round 1 (the row-sharded W sub-problem, whose decision comes from the all-reduced table).
+struct FusedPlan { int first, count; bool from_backup, save, norms; };
+__device__ __forceinline__ bool fused_plan(int phase, int admm_iter, const int* __restrict__ hint_rd, int* __restrict__ hint_wr,
+                                           const double* __restrict__ tab, int nblk, double* sh, DevState* __restrict__ st,
+                                           int32_t* __restrict__ slot, FusedPlan& p)
+{
+    if (phase == 2 && !st->ao_continued) return false;                 // (written by the lead thread of phase 1: a launch ago)
+    int r1 = admm_iter;
+    if (hint_rd) { const int h = *hint_rd; if (h > 0 && h < admm_iter) r1 = h; }
+    if (phase == 0) { p = FusedPlan{0, r1, false, true, true}; return true; }
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    int fired;
+    if (phase == 1) {
+        const int cnt = fused_decide(tab, nblk, r1, sh, &fired);
+        if (!fired && r1 < admm_iter) {                // no stop among the hinted rounds: go on to the end, phase 2 decides
+            if (lead) st->ao_continued = 1;
+            p = FusedPlan{r1, admm_iter - r1, false, true, true};
+            return true;
+        }
+        if (lead) {
+            st->inner_count = cnt; st->inner_stop = 0; *slot = cnt | (fired << 16);
+            st->ao_continued = 0; st->ao_paths[cnt >= r1 ? 0 : 1] += 1;
+            if (hint_wr) *hint_wr = fired ? cnt : admm_iter;
+        }
+        if (cnt >= r1) return false;                   // the speculative result stands
+        p = FusedPlan{0, cnt, true, false, false};
+        return true;
+    }
+    const int cnt = fused_decide(tab, nblk, admm_iter, sh, &fired);    // (rounds below r1 did not fire: the first hit is >= r1)
+    if (lead) {
+        st->inner_count = cnt; st->inner_stop = 0; *slot = cnt | (fired << 16);
+        st->ao_paths[cnt >= admm_iter ? 2 : 3] += 1;
+        if (hint_wr) *hint_wr = fired ? cnt : admm_iter;
+    }
+    if (cnt >= admm_iter) return false;
+    p = FusedPlan{r1, cnt - r1, true, false, false};
+    return true;
+}
+
 // ---- split-bf16 pieces for the inner product of the fused W-side rounds (k padded to 64 / 128) ----
 typedef __bf16 ao_bf16x8 __attribute__((ext_vector_type(8)));
 union AoFrag8 { uint4 u; ao_bf16x8 v; };
@@ -684,7 +735,8 @@ template <int KP, int CB>
 __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int64_t np, int prox, float lam, int admm_iter,
-    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot)
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int phase, int32_t* __restrict__ slot,
+    const int* __restrict__ hint_rd, int* __restrict__ hint_wr)
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -696,13 +748,8 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     double* sh = reinterpret_cast<double*>(ms + KP * LDM);
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
-    int rounds = admm_iter;
-    if (repair) {
-        int fired;
-        rounds = fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
-        if (blockIdx.x == 0 && tid == 0) { st->inner_count = rounds; st->inner_stop = 0; *slot = rounds | (fired << 16); }
-        if (rounds >= admm_iter) return;               // nothing to repair: the speculative result stands
-    }
+    FusedPlan plan;
+    if (!fused_plan(phase, admm_iter, hint_rd, hint_wr, nrm_rounds, nblk, sh, st, slot, plan)) return;
     const int64_t c0 = (int64_t)blockIdx.x * CB;
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
@@ -733,8 +780,8 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     }
     }
     float hx[ITW][4][NE], ux[ITW][4][NE], bx[ITW][4][NE];
-    const float* srcX = repair ? Xb : X;
-    const float* srcU = repair ? Ub : U;
+    const float* srcX = plan.from_backup ? Xb : X;
+    const float* srcU = plan.from_backup ? Ub : U;
 #pragma unroll
     for (int r = 0; r < ITW; ++r) {
         const int it = wave + 4 * r;
@@ -745,14 +792,14 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                 ldv<NE>(hx[r][g], srcX + idx);
                 ldv<NE>(ux[r][g], srcU + idx);
                 ldv<NE>(bx[r][g], Bsum + idx);
-                if (!repair) {
+                if (plan.save) {
                     stv<NE>(Xb + idx, hx[r][g]);
                     stv<NE>(Ub + idx, ux[r][g]);
                 }
             }
         }
     }
-    for (int rnd = 0; rnd < rounds; ++rnd) {
+    for (int rnd = plan.first; rnd < plan.first + plan.count; ++rnd) {
         // RHS = B + rho (X + U), every wave its own factor rows
 #pragma unroll
         for (int r = 0; r < ITW; ++r) {
@@ -861,7 +908,7 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                 }
             }
         }
-        if (!repair) block_store_norms<4>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
+        if (plan.norms) block_store_norms<4>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
         __syncthreads();                               // the RHS tile is rewritten next round
     }
 #pragma unroll
@@ -887,8 +934,9 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     const float* __restrict__ Asum, int asplit, int64_t astride,     // right-hand side = sum of asplit slabs (slab order)
     float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
-    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int repair, int32_t* __restrict__ slot,
-    const double* __restrict__ decide_tab)             // row-sharded runs: the ALL-REDUCED norm sums [admm_iter][4]
+    DevState* __restrict__ st, double* __restrict__ nrm_rounds, int phase, int32_t* __restrict__ slot,
+    const double* __restrict__ decide_tab,             // row-sharded runs: the ALL-REDUCED norm sums [admm_iter][4]
+    const int* __restrict__ hint_rd, int* __restrict__ hint_wr)
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -899,14 +947,9 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     double* sh = reinterpret_cast<double*>(rs + RB * LDR);
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
-    int rounds = admm_iter;
-    if (repair) {
-        int fired;
-        rounds = decide_tab ? fused_decide(decide_tab, 1, admm_iter, sh, &fired)
-                            : fused_decide(nrm_rounds, nblk, admm_iter, sh, &fired);
-        if (blockIdx.x == 0 && tid == 0) { st->inner_count = rounds; st->inner_stop = 0; *slot = rounds | (fired << 16); }
-        if (rounds >= admm_iter) return;
-    }
+    FusedPlan plan;
+    if (!fused_plan(phase, admm_iter, hint_rd, hint_wr, decide_tab ? decide_tab : nrm_rounds, decide_tab ? 1 : nblk, sh, st, slot, plan))
+        return;
     const float rho = (float)st->rho;
     const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
     // k padded to 64 / 128: the product of a round, aux = rhs M^-1 (16 x KP x KP per wave), runs on the bf16 matrix cores with
@@ -941,8 +984,8 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     float* myrs = rs + wave * 16 * LDR;
     // accumulator layout: [it][g] = row 4 q + g, column 16 it + x
     float wx[JT][4], dx[JT][4], ax0[JT][4];
-    const float* srcX = repair ? Xb : X;
-    const float* srcU = repair ? Ub : U;
+    const float* srcX = plan.from_backup ? Xb : X;
+    const float* srcU = plan.from_backup ? Ub : U;
 #pragma unroll
     for (int it = 0; it < JT; ++it)
 #pragma unroll
@@ -952,10 +995,10 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
             float av = Asum[idx];
             for (int p = 1; p < asplit; ++p) av += Asum[(int64_t)p * astride + idx];
             ax0[it][g] = av;
-            if (!repair) { Xb[idx] = wx[it][g]; Ub[idx] = dx[it][g]; }
+            if (plan.save) { Xb[idx] = wx[it][g]; Ub[idx] = dx[it][g]; }
         }
     __syncthreads();                                   // M^-1 is in place
-    for (int rnd = 0; rnd < rounds; ++rnd) {
+    for (int rnd = plan.first; rnd < plan.first + plan.count; ++rnd) {
 #pragma unroll
         for (int it = 0; it < JT; ++it)
 #pragma unroll
@@ -1017,7 +1060,7 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
                 wx[it][g] = wn; dx[it][g] = dn;
             }
         }
-        if (!repair) block_store_norms<RB / 16>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
+        if (plan.norms) block_store_norms<RB / 16>(n0, n1, n2, n3, nrm_rounds + ((int64_t)rnd * nblk + blockIdx.x) * 4, sh);
         __syncthreads();
     }
 #pragma unroll
@@ -1260,19 +1303,21 @@ static int ao_fused_alloc(nmfx_engine* E, int admm_iter) {
 static int ao_fused_cols_cb(const nmfx_engine* E) { return (E->np / 64 < (int64_t)E->ncu) ? 32 : 64; }
 
 template <int KP, int CB>
-static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
+static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int phase, int32_t* slot,
+                                const int* hint_rd, int* hint_wr) {
     const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
     auto kern = ao_fused_cols_kernel<KP, CB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
-                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot);
+                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, hint_rd, hint_wr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 template <int KP>
-static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter, int repair, int32_t* slot) {
-    return ao_fused_cols_cb(E) == 32 ? launch_fused_cols_cb<KP, 32>(E, prox, lam, admm_iter, repair, slot)
-                                     : launch_fused_cols_cb<KP, 64>(E, prox, lam, admm_iter, repair, slot);
+static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter, int phase, int32_t* slot,
+                             const int* hint_rd, int* hint_wr) {
+    return ao_fused_cols_cb(E) == 32 ? launch_fused_cols_cb<KP, 32>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr)
+                                     : launch_fused_cols_cb<KP, 64>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr);
 }
 
 // rows per block of the fused W-side kernel (also the granularity of its norm partials)
@@ -1283,8 +1328,8 @@ static int ao_fused_rows_rb(const nmfx_engine* E) {
 }
 
 template <int KP, int RB>
-static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
-                               const double* decide_tab) {
+static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int phase, int32_t* slot,
+                               const double* decide_tab, const int* hint_rd, int* hint_wr) {
     const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP, RB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
@@ -1292,25 +1337,26 @@ static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, i
     const bool slabs = E->ao_a_slabs > 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / RB)), dim3(RB * 4), shm, E->stream, slabs ? E->A_part : E->auxW,
                        slabs ? E->ao_a_slabs : 1, (int64_t)E->mp * E->kp, W, E->dualW, E->bkX, E->bkU,
-                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, repair, slot, decide_tab);
+                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, decide_tab, hint_rd, hint_wr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 template <int KP>
-static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
-                             const double* decide_tab = nullptr) {
+static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int phase, int32_t* slot,
+                             const double* decide_tab, const int* hint_rd, int* hint_wr) {
     if constexpr (KP >= 64) {
-        if (ao_fused_rows_rb(E) == 128) return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+        if (ao_fused_rows_rb(E) == 128)
+            return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
     }
-    return launch_fused_rows_rb<KP, 64>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+    return launch_fused_rows_rb<KP, 64>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
 }
-static int fused_rows_any(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int repair, int32_t* slot,
-                          const double* decide_tab = nullptr) {
+static int fused_rows_any(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int phase, int32_t* slot,
+                          const double* decide_tab = nullptr, const int* hint_rd = nullptr, int* hint_wr = nullptr) {
     switch (E->kp) {
-        case 16: return launch_fused_rows<16>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
-        case 32: return launch_fused_rows<32>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
-        case 64: return launch_fused_rows<64>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
-        default: return launch_fused_rows<128>(E, W, prox, lam, admm_iter, repair, slot, decide_tab);
+        case 16: return launch_fused_rows<16>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
+        case 32: return launch_fused_rows<32>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
+        case 64: return launch_fused_rows<64>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
+        default: return launch_fused_rows<128>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
     }
 }
 
@@ -1329,19 +1375,24 @@ __global__ __launch_bounds__(256) void nrm_table_kernel(const double* __restrict
     }
 }
 
-static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, float lam, int admm_iter, int32_t* slot) {
+// Two launches without the hint (speculate all rounds, decide + repair), three with it (see fused_plan; NMFX_AO_HINT=0
+// turns it off).  `parity` alternates between consecutive sub-problems of the same side: the hint slot read / written.
+static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, float lam, int admm_iter, int32_t* slot, int parity) {
+    static const bool hinted = !(getenv("NMFX_AO_HINT") && atoi(getenv("NMFX_AO_HINT")) == 0);
     int rc;
     if ((rc = ao_fused_alloc(E, admm_iter))) return rc;
-    for (int repair = 0; repair < 2; ++repair) {
+    const int* hint_rd = hinted ? &E->state->ao_hint[cols ? 0 : 1][parity & 1] : nullptr;
+    int* hint_wr = hinted ? &E->state->ao_hint[cols ? 0 : 1][(parity & 1) ^ 1] : nullptr;
+    for (int phase = 0; phase < (hinted ? 3 : 2); ++phase) {
         if (cols) {
             switch (E->kp) {
-                case 16: rc = launch_fused_cols<16>(E, prox, lam, admm_iter, repair, slot); break;
-                case 32: rc = launch_fused_cols<32>(E, prox, lam, admm_iter, repair, slot); break;
-                case 64: rc = launch_fused_cols<64>(E, prox, lam, admm_iter, repair, slot); break;
-                default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, repair, slot); break;
+                case 16: rc = launch_fused_cols<16>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr); break;
+                case 32: rc = launch_fused_cols<32>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr); break;
+                case 64: rc = launch_fused_cols<64>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr); break;
+                default: rc = launch_fused_cols<128>(E, prox, lam, admm_iter, phase, slot, hint_rd, hint_wr); break;
             }
         } else {
-            rc = fused_rows_any(E, W, prox, lam, admm_iter, repair, slot);
+            rc = fused_rows_any(E, W, prox, lam, admm_iter, phase, slot, nullptr, hint_rd, hint_wr);
         }
         if (rc) return rc;
     }
@@ -1355,7 +1406,7 @@ static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, i
     E->himg_both = false;                              // H changes below
     ProfScope ps(E, "inner_h");
     if (ao_fused_enabled(E, admm_iter))
-        return ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2);
+        return ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2, (int)(j & 1));
     for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
     return nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2);
 }
@@ -1394,7 +1445,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     if ((rc = ao_w_products(E, j, min_iter, tol1, tol2, !ao_fused_enabled(E, admm_iter)))) return rc;
     { ProfScope ps(E, "inner_w");
       if (ao_fused_enabled(E, admm_iter)) {
-          if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+          if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1, (int)(j & 1)))) return rc;
       } else {
           for (int r = 0; r < admm_iter; ++r) if ((rc = inner_rows(E, W, prox_w, (float)lam_w, r))) return rc;
           if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;

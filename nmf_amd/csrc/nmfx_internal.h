@@ -44,6 +44,12 @@ struct DevState {          // lives in device memory, written by kernels
     int nnls_capped;
     int nnls_fallback;     // problems the inverse + complement pass left to the elimination kernel (complement too large)
     int nnls_noinv;        // half-steps whose Gram matrix had no usable explicit inverse (all problems to the elimination kernel)
+    // AO-ADMM, hinted speculation of the fused inner rounds: [H side, W side][parity of the outer iteration] = the count of
+    // rounds of the side's previous sub-problem (0: none yet).  Only ever changes the cost of a sub-problem, not its result.
+    int ao_hint[2][2];
+    int ao_continued;      // the decide launch of the current sub-problem found no stop among the hinted rounds and went on
+    int pad2;
+    int ao_paths[4];       // sub-problems whose first leg stood / was cut back / was continued / was continued and cut back
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };

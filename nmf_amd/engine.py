@@ -264,6 +264,12 @@ class Engine:
         self._ck(self.lib.nmfx_get_nnls_fallbacks(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def inner_paths(self):
+        """AO-ADMM fused inner rounds: sub-problems whose first leg (stood, was cut back, was continued, was continued and cut back)."""
+        out = (C.c_int64 * 4)()
+        self._ck(self.lib.nmfx_get_inner_paths(self.h, out))
+        return tuple(int(v) for v in out)
+
     def anls_run(self, lam_w, lam_h, min_iter, tol1, tol2, first, count):
         self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
                                         float(tol2), int(first), int(count)))

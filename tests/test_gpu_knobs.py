@@ -99,3 +99,55 @@ def test_two_handles_from_two_threads_and_dropped_row_major_v(monkeypatch):
     assert not errs, errs
     assert out["a"][0] < 1e-4 and out["b"][0] < 1e-4, out
     np.testing.assert_allclose(out["b"][1], out["b"][2], rtol=1e-9)
+
+
+HINT_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+os.environ["NMF_AMD_QUIET"] = "1"
+import numpy as np
+from oracle import nmf_ref as R
+from nmf_amd.ao_admm import ao_admm
+m, n, k, T, it = (int(a) for a in sys.argv[1:6])
+v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+res = ao_admm(v.copy(), k, distance_type="eu", reg_w=(0.02, "l1n"), reg_h=(0, "nn"), min_iter=it, max_iter=it, admm_iter=T,
+              nndsvd_init=(True, "zero"))
+np.savez(sys.argv[6], w=res.w, h=res.h, obj=np.asarray(res.obj_history), inner=np.asarray(ao_admm.last_inner_counts),
+         paths=np.asarray(ao_admm.last_inner_paths))
+'''
+
+
+@pytest.mark.parametrize("shape,admm_iter,iters,expect", [
+    ((320, 448, 100), 16, 14, (1, 3)),      # first legs cut back, and continued + cut back (the count of rounds creeps up again)
+    ((320, 448, 100), 8, 14, (1, 2)),       # ... and continued to admm_iter with nothing to cut
+    ((300, 520, 24), 16, 30, (1, 3)),       # k padded to 32: the f32-MFMA form of the round kernels
+])
+def test_hinted_inner_rounds_are_the_unhinted_ones(shape, admm_iter, iters, expect, tmp_path):
+    """The first launch of a fused sub-problem runs only as many rounds as the side's previous sub-problem counted
+    (DevState::ao_hint).  Whatever path follows -- the leg stands, is cut back, is continued, is continued and cut back --
+    the rounds that count are the reference's: inner counts equal to the oracle's, and factors, objectives and counts
+    bit-identical to the run without the hint (NMFX_AO_HINT=0: all admm_iter rounds, then the cut)."""
+    from oracle import nmf_ref as R
+    m, n, k = shape
+    got = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"hint{mode}.npz")
+        run = subprocess.run([sys.executable, "-c", HINT_CHILD % {"root": ROOT}, str(m), str(n), str(k), str(admm_iter), str(iters), out],
+                             env=dict(os.environ, NMFX_AO_HINT=mode), capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        got[mode] = np.load(out)
+    for key in ("w", "h", "obj", "inner"):
+        np.testing.assert_array_equal(got["1"][key], got["0"][key], err_msg=key)
+    paths = got["1"]["paths"]
+    assert paths[0] > 0 and all(paths[i] > 0 for i in expect), paths
+    assert got["0"]["paths"][2] == 0 and got["0"]["paths"][3] == 0                     # (without the hint nothing is ever continued)
+    v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+    ref = R.ao_admm(v.astype(np.float64), k, distance_type="eu", reg_w=(0.02, "l1n"), reg_h=(0, "nn"), min_iter=iters, max_iter=iters,
+                    admm_iter=admm_iter, nndsvd_init=(True, "zero"))
+    assert [tuple(r) for r in got["1"]["inner"]] == [tuple(t) for t in ref.trace["inner"]]
+    # (H is not regularised here so that the counts move: the sub-problems are as ill-conditioned as W^T W, and the f32 state of
+    # the iterates alone puts every product form at 0.5 - 1.2e-4 on this problem -- exact-f32 products 5.9e-5 / 1.06e-4, four
+    # split terms 8.8e-5 / 9.2e-5, the default three 1.15e-4 / 4.9e-5 for admm_iter = 16 / 8 (tools/lab/ao_terms.py); the
+    # well-conditioned cases of test_gpu_aoadmm.py sit at 3e-6 -- hence twice the usual bar)
+    err = float(np.linalg.norm(got["1"]["w"] @ got["1"]["h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)))
+    assert err < 2e-4, err

@@ -57,8 +57,9 @@ def run(name, m, n, k, queue, finish=None, steps=20, warmup=3, init="random", fl
         if cnt:
             prof[kn] = {"us": round(ms / cnt * 1e3, 1), "per_iter": cnt / 5}
     inner = None
-    if "admm" in name:
+    if "admm" in name.lower():
         inner = (eng.inner_counts(0, warmup + steps) & 0xFFFF).mean(axis=0).tolist()
+        note = (note + "; " if note else "") + "inner paths (stood, cut back, continued, continued + cut back) = %s" % (eng.inner_paths(),)
     out = {"config": name, "shape": [m, n, k], "iter_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3,
            "algorithmic_gflop_per_iter": flops / 1e9 if flops else None,
            "tflops": flops / dt / 1e12 if flops else None, "stop_rule": rule,
