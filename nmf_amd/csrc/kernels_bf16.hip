@@ -1240,6 +1240,116 @@ __global__ __launch_bounds__(256) void split_images_kernel(
     }
 }
 
+// MUR-KL epilogues with the images and the sums the next products need (end of r2: the update, the image pass and the
+// first stage of the column / row sums were three launches per factor -- 55 us of small kernels in a 1.1 ms iteration of
+// config 4).  One 64 x 64 tile per block, as in split_images_kernel; the arithmetic of the update is that of
+// kl_w_update_kernel / kl_h_update_kernel (kernels_kl.hip), expression for expression.
+//   W (mur.py:26-27):  a = W * sum of the A slabs, b = rowsum_H[factor];  W_new = 2a / (b + sqrt(b^2 + 4 lam a));
+//                      part[tile row][factor] = column sums of the tile (d = W^T 1 of the H update, finished by col_sums_final)
+__global__ __launch_bounds__(256) void kl_w_epilogue_kernel(
+    const float* __restrict__ Apart, int wsplit, int64_t count, int kp, int k, const float* __restrict__ Wold,
+    const float* __restrict__ rowsum, float lam, float* __restrict__ Wnew, int64_t mp,
+    unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, unsigned short* __restrict__ thi,
+    unsigned short* __restrict__ tlo, float* __restrict__ part, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    __shared__ unsigned short sh[64][66], sl[64][66];
+    __shared__ float cs[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int f = (int)c0 + tx;
+    const float b = f < k ? rowsum[f] : 0.f;
+    float colacc = 0.f;
+    float sv[16], wv[16];                              // every load of the tile in flight before the first store
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int64_t i = (r0 + ty + 4 * u) * kp + f;
+        float s = 0.f;
+        if (f < k) {
+            s = Apart[i];
+            for (int p = 1; p < wsplit; ++p) s += Apart[(int64_t)p * count + i];
+        }
+        sv[u] = s; wv[u] = f < k ? Wold[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = ty + 4 * u;
+        const int64_t i = (r0 + r) * kp + f;
+        float v = 0.f;                                 // padded factors: 0/0 must stay out
+        if (f < k) {
+            const float a = wv[u] * sv[u];
+            v = 2.f * a / (b + sqrtf(b * b + 4.f * lam * a));
+        }
+        Wnew[i] = v;
+        colacc += v;
+        unsigned h, l;
+        split2(v, 0.f, h, l);
+        hi[i] = (unsigned short)h; lo[i] = (unsigned short)l;
+        sh[r][tx] = (unsigned short)h; sl[r][tx] = (unsigned short)l;
+    }
+    cs[ty][tx] = colacc;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        thi[(c0 + c) * mp + r0 + tx] = sh[tx][c];
+        tlo[(c0 + c) * mp + r0 + tx] = sl[tx][c];
+    }
+    if (ty == 0) part[(int64_t)blockIdx.y * kp + f] = (cs[0][tx] + cs[1][tx]) + (cs[2][tx] + cs[3][tx]);
+}
+
+//   H (mur.py:41-43):  c = H * B, d = colsum_W[factor];  H_new = 2c / (d + sqrt(d^2 + 4 lam c)), after the objective
+//                      bookkeeping / convergence test (same protocol as MUR-eu); xf32 = [B (kp x np) | d];
+//                      part[tile column][factor] = row sums of the tile (b = 1 H^T of the next W update)
+__global__ __launch_bounds__(256) void kl_h_epilogue_kernel(
+    const float* __restrict__ xf32, const double* __restrict__ xf64, float* __restrict__ H, int64_t np, int kp, int k,
+    float lam, long long j, long long min_iter, double tol1, double tol2, DevState* __restrict__ st,
+    double* __restrict__ obj_hist, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, float* __restrict__ part)
+{
+    if (st->flag) return;
+    const int rule = nmfx_record_objective(st, obj_hist, xf64[0], j, min_iter, tol1, tol2,
+                                           blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
+    if (rule) return;
+    __shared__ unsigned short sh[64][66], sl[64][66];
+    __shared__ float rsum[64][4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;      // factor rows, columns
+    const int64_t count = (int64_t)kp * np;
+    float hv[16], bv[16], dv[16];                      // every load of the tile in flight before the first store to H
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = ty + 4 * u;
+        const int64_t i = (r0 + r) * np + c0 + tx;
+        const bool live = r0 + r < k;
+        hv[u] = live ? H[i] : 0.f; bv[u] = live ? xf32[i] : 0.f; dv[u] = live ? xf32[count + r0 + r] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = ty + 4 * u;
+        const int64_t i = (r0 + r) * np + c0 + tx;
+        float v = 0.f;                                 // padded factor rows stay zero
+        if (r0 + r < k) {
+            const float d = dv[u];
+            const float c = hv[u] * bv[u];
+            v = 2.f * c / (d + sqrtf(d * d + 4.f * lam * c));
+            H[i] = v;
+        }
+        unsigned h, l;
+        split2(v, 0.f, h, l);
+        hi[i] = (unsigned short)h; lo[i] = (unsigned short)l;
+        sh[r][tx] = (unsigned short)h; sl[r][tx] = (unsigned short)l;
+        float t = v;                                   // row sum over the tile's 64 columns: one wave holds the row
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (tx == 0) rsum[r][0] = t;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        thi[(c0 + c) * kp + r0 + tx] = sh[tx][c];
+        tlo[(c0 + c) * kp + r0 + tx] = sl[tx][c];
+    }
+    if (ty == 0) part[(int64_t)blockIdx.x * kp + r0 + tx] = rsum[tx][0];
+}
+
 // ---------------------------------------------------------------------------
 // W epilogue (nmf/mur.py:29): W_new = W * A / (W (H H^T) + lam W + 1e-9), plus the bf16 images
 // of the new W: row-major (next iteration's residual) and transposed (this iteration's H
@@ -1660,6 +1770,38 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
     return obj ? NMFX_XYT(128, true, false) : NMFX_XYT(128, false, false);
 #undef NMFX_XYT2
 #undef NMFX_XYT
+}
+
+static int kl_part_alloc(nmfx_engine* E) {
+    return lazy_alloc(E, &E->kl_part, (int64_t)(E->np / 64 + E->mp / 64) * E->kp);
+}
+
+// W_new, its images in both layouts (buffer `nxt`), and the column-sum partials kl_part[np/64 ..][kp] (mp / 64 of them)
+int nmfx_bf16_kl_w_epilogue(nmfx_engine* E, const float* Wold, float* Wnew, int nxt, float lam, const float* rowsum) {
+    ProfScope ps(E, "w_update");
+    int rc;
+    if ((rc = kl_part_alloc(E))) return rc;
+    hipLaunchKernelGGL(kl_w_epilogue_kernel, dim3((unsigned)(E->kp / 64), (unsigned)(E->mp / 64)), dim3(256), 0, E->stream,
+                       E->A_part, E->bf_wsplit, E->mp * E->kp, E->kp, E->k, Wold, rowsum, lam, Wnew, E->mp, E->Whi[nxt],
+                       E->Wlo[nxt], E->WThi, E->WTlo, E->kl_part + (int64_t)(E->np / 64) * E->kp, &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// H_new from the exchange buffers, its images in both layouts, and the row-sum partials kl_part[0 .. np/64)[kp]
+int nmfx_bf16_kl_h_epilogue(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2) {
+    ProfScope ps(E, "h_update");
+    int rc;
+    if ((rc = kl_part_alloc(E))) return rc;
+    if ((rc = lazy_alloc(E, &E->HThi, (int64_t)E->kp * E->np))) return rc;
+    if ((rc = lazy_alloc(E, &E->HTlo, (int64_t)E->kp * E->np))) return rc;
+    hipLaunchKernelGGL(kl_h_epilogue_kernel, dim3((unsigned)(E->np / 64), (unsigned)(E->kp / 64)), dim3(256), 0, E->stream,
+                       E->xf32, E->xf64, E->H, E->np, E->kp, E->k, lam, (long long)j, (long long)min_iter, tol1, tol2,
+                       E->state, E->obj_hist, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->kl_part);
+    NMFX_HIP(hipGetLastError());
+    E->himg_both = true;
+    E->kl_h_iter = j;
+    return NMFX_OK;
 }
 
 // Allocate the bf16 state and build V^T and the images of the initial factors.

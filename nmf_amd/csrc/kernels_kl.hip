@@ -371,32 +371,31 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const int cur = (int)(j & 1), nxt = cur ^ 1;
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
-    if (!E->ht_ready) { if ((rc = nmfx_bf16_images_h(E, true))) return rc; E->ht_ready = true; }
-    if ((rc = launch_h_row_sums(E))) return rc;      // b = 1 H^T  (HHt is unused by KL; its first kp floats hold the sums)
+    // the images of H in both layouts and b = 1 H^T (HHt is unused by KL; its first kp floats hold the sums): left by the
+    // H epilogue of iteration j - 1 (images as they are, the sums as partials: one small launch), or built from H itself
+    // (first iteration, new factors, another solver in between)
+    const bool fresh = E->kl_part && E->kl_h_iter == j - 1;
+    if (!fresh && (rc = nmfx_bf16_images_h(E, true))) return rc;
+    if (fresh) {
+        ProfScope ps(E, "row_sums");
+        hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream, E->kl_part,
+                           (int)(E->np / 64), E->kp, E->HHt, &E->state->flag);
+        NMFX_HIP(hipGetLastError());
+    } else if ((rc = launch_h_row_sums(E))) return rc;
     if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", true, 3))) return rc;
-    { ProfScope ps(E, "w_update");
-      const int64_t count = E->mp * E->kp;
-      hipLaunchKernelGGL(kl_w_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, E->stream,
-                         E->A_part, E->bf_wsplit, count, E->kp, E->k, Wold, E->HHt, (float)lambda_w, Wnew,
-                         &E->state->flag);
-      NMFX_HIP(hipGetLastError()); }
-    if ((rc = nmfx_bf16_images_w(E, Wnew, nxt))) return rc;
+    // W_new + its images + the column-sum partials in one launch (kl_w_epilogue_kernel)
+    if ((rc = nmfx_bf16_kl_w_epilogue(E, Wold, Wnew, nxt, (float)lambda_w, E->HHt))) return rc;
     if ((rc = nmfx_bf16_vtw(E, false, "hphase", true, 3))) return rc;
-    { ProfScope ps(E, "row_sums");        // d = W^T 1 into the first kp floats of G_part, slabs behind it
-      const int nblk = (int)(E->mp / 128);
-      float* part = E->B_part;                                   // scratch: the exact-f32 H phase's slabs are unused here
-      hipLaunchKernelGGL(col_sums_part_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, Wnew, E->kp, part,
-                         &E->state->flag);
-      hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream, part, nblk, E->kp,
-                         E->G_part, &E->state->flag);
+    { ProfScope ps(E, "row_sums");        // d = W^T 1 into the first kp floats of G_part
+      hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream,
+                         E->kl_part + (int64_t)(E->np / 64) * E->kp, (int)(E->mp / 64), E->kp, E->G_part, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
     return nmfx_bf16_pack_t(E, E->G_part, 1, (int64_t)(E->mp / 128) * E->bf_wsplit);
 }
 
 int nmfx_mur_kl_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
-    int rc;
-    if ((rc = nmfx_mur_kl_phase_b(E, lambda_h, min_iter, tol1, tol2, j))) return rc;
-    return nmfx_bf16_images_h(E, true);                          // Hhi/Hlo (next W phase) and H^T images (next H phase)
+    // H_new + Hhi/Hlo (next W phase) + H^T images (next H phase) + the row-sum partials of the next W update in one launch
+    return nmfx_bf16_kl_h_epilogue(E, (float)lambda_h, j, min_iter, tol1, tol2);
 }
 
 int nmfx_mur_kl_finish_a(nmfx_engine* E, int64_t j) {

@@ -68,6 +68,8 @@ struct nmfx_engine {
     float* HHt_part = nullptr;     // [gram_splits][kp][kp]
     float* G_part = nullptr;       // [gram_splits][kp][kp]
     float* G_big = nullptr;        // [<= 256][kp][kp]: row-split slabs of the image-based Gram kernel (k padded to 128), folded into G_part
+    float* kl_part = nullptr;      // MUR-KL, split-bf16: [np/64][kp] row-sum partials of H | [mp/64][kp] column-sum partials of W (the fused epilogues)
+    int64_t kl_h_iter = -2;        // outer iteration whose H epilogue wrote the H partials and the H / H^T images (valid for iteration + 1 only)
     float* A_part = nullptr;       // [wsplit][mp][kp]
     float* B_part = nullptr;       // [hsplit][kp][np]
     double* obj_part = nullptr;    // [max blocks]
@@ -92,7 +94,6 @@ struct nmfx_engine {
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
-    bool ht_ready = false;         // H^T images are current (KL split-bf16 path)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     bool himg_both = false;        // Hhi/Hlo AND HThi/HTlo are the images of the current H (AO-ADMM skips a rebuild)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
@@ -165,6 +166,8 @@ inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
+int nmfx_bf16_kl_w_epilogue(nmfx_engine* E, const float* Wold, float* Wnew, int nxt, float lam, const float* rowsum);
+int nmfx_bf16_kl_h_epilogue(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2);
 int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl = false, int terms = 4);   // terms: kernels_bf16.hip, top
 int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl = false, int terms = 4);
 int nmfx_bf16_objective(nmfx_engine* E, int zbuf, const char* name);
