@@ -17,7 +17,7 @@ def test_admm_eu_matches_reference(name):
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors(name, admm) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-3 if "kl" in name else 5e-4)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-4 if "kl" in name else 5e-4)
     assert res.experiment.rho == meta["kwargs"]["rho"]
 
 
@@ -48,3 +48,25 @@ def test_admm_eu_k64_k128_both_precisions_vs_oracle(precision, shape, reg_h, mon
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
     assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+
+
+@pytest.mark.parametrize("shape,reg_w,reg_h,rho,iters", [
+    ((200, 160, 12), (0.05, "l1n"), (0.05, "l1n"), 1.0, 12),
+    ((320, 256, 40), (0, "nn"), (0.05, "l1n"), 2.0, 10),           # k padded to 64
+    ((256, 384, 100), (0.05, "l2n"), (0, "nn"), 1.0, 8),           # k padded to 128, the l2n operator on W
+])
+def test_admm_kl_vs_oracle(shape, reg_w, reg_h, rho, iters):
+    """ADMM with the KL loss (admm.py: v_aux and its dual next to the factor auxiliaries) beyond the one golden fixture:
+    the three prox operators of W, k padded to 16 / 64 / 128, against the oracle.  (Measured: WH 9e-7 .. 3e-6, objective
+    3e-6 .. 4.3e-5.)"""
+    from oracle import nmf_ref as R
+    from nmf_amd.admm import admm
+    m, n, k = shape
+    v = R.planted_matrix(m, n, min(k, 32), seed=m + n + k, dtype=np.float32)
+    kw = dict(rho=rho, distance_type="kl", reg_w=reg_w, reg_h=reg_h, min_iter=iters, max_iter=iters, nndsvd_init=(True, "zero"))
+    with np.errstate(all="ignore"):
+        ref = R.admm(v.astype(np.float64), k, **kw)
+    res = admm(v.copy(), k, **kw)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < 2e-5
+    assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)

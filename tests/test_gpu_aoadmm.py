@@ -61,8 +61,32 @@ def test_aoadmm_kl_matches_reference():
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors("aoadmm_kl_nn", ao_admm) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-3)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-4)
     assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])
+
+
+@pytest.mark.parametrize("shape,reg_w,reg_h,admm_iter,iters", [
+    ((200, 160, 12), (0.05, "l1n"), (0.05, "l1n"), 8, 6),
+    ((320, 256, 40), (0.05, "l1n"), (0, "nn"), 6, 5),          # k padded to 64
+    ((256, 384, 100), (0, "nn"), (0.05, "l1n"), 5, 4),         # k padded to 128
+])
+def test_aoadmm_kl_vs_oracle(shape, reg_w, reg_h, admm_iter, iters):
+    """AO-ADMM with the KL loss (ao_admm.py:71-101: the m x n auxiliaries and their duals inside the inner rounds) beyond the
+    one golden fixture: both prox operators, k padded to 16 / 64 / 128, against the oracle -- WH, objective history and the
+    inner counts of every sub-problem.  (Measured: WH 4e-7 .. 1.4e-6, objective 6e-7 .. 4e-6.)"""
+    from oracle import nmf_ref as R
+    from nmf_amd.ao_admm import ao_admm
+    m, n, k = shape
+    v = R.planted_matrix(m, n, min(k, 32), seed=m + n + k, dtype=np.float32)
+    kw = dict(distance_type="kl", reg_w=reg_w, reg_h=reg_h, min_iter=iters, max_iter=iters, admm_iter=admm_iter,
+              nndsvd_init=(True, "zero"))
+    with np.errstate(all="ignore"):
+        ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    res = ao_admm(v.copy(), k, **kw)
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < 1e-5
+    assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-5)
+    assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])

@@ -232,7 +232,7 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
         assert any(t[1] < 10 for t in ref.trace["inner"]), "case must exercise the repair launch of the W sub-problem"
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-3 if solver in ("admm_kl", "ao_admm_kl") else 5e-4)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-4 if solver in ("admm_kl", "ao_admm_kl") else 5e-4)
         np.testing.assert_array_equal(p["h"], h)
         if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
