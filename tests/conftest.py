@@ -43,3 +43,26 @@ def fix_kwargs(kw):
 @pytest.fixture(scope="session")
 def golden_loader():
     return load_golden
+
+
+# NMFX_RECORD_BARS=<file>: every np.testing.assert_allclose of the run appends (test id, rtol asked, largest relative
+# difference seen) to the file -- how far inside its bar each comparison sits (used to set the bars).
+_BARS = os.environ.get("NMFX_RECORD_BARS")
+if _BARS:
+    _orig_allclose = np.testing.assert_allclose
+
+    def _recording_allclose(actual, desired, rtol=1e-7, atol=0, *args, **kwargs):
+        try:
+            a, d = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+            if a.shape == d.shape and a.size:
+                with np.errstate(all="ignore"):
+                    rel = np.abs(a - d) / np.maximum(np.abs(d), 1e-300)
+                worst = float(np.nanmax(np.where(np.abs(d) > 0, rel, 0.0)))
+                test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+                with open(_BARS, "a") as fh:
+                    fh.write(json.dumps({"test": test, "rtol": rtol, "atol": atol, "worst_rel": worst, "n": int(a.size)}) + "\n")
+        except Exception:  # noqa: BLE001  (a diagnostic must never change a test's outcome)
+            pass
+        return _orig_allclose(actual, desired, rtol=rtol, atol=atol, *args, **kwargs)
+
+    np.testing.assert_allclose = _recording_allclose

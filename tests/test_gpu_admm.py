@@ -17,7 +17,7 @@ def test_admm_eu_matches_reference(name):
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors(name, admm) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-4 if "kl" in name else 5e-4)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=5e-5 if "kl" in name else 1e-4)      # (measured: 6.8e-6 / 1.2e-5)
     assert res.experiment.rho == meta["kwargs"]["rho"]
 
 

@@ -16,7 +16,7 @@ def test_anls_matches_reference(name):
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors(name, anls) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=1e-3)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=1e-5)      # (measured: 7.5e-7)
     assert (res.w >= 0).all() and (res.h >= 0).all()
     # exact zeros of the active set are exact zeros here too (NNLS, not a projection)
     assert ((z["h"] == 0) == (res.h == 0)).mean() > 0.97
@@ -97,7 +97,7 @@ def test_anls_rank_deficient_passive_set_at_lambda_zero(k, case):
     if case == "dead":
         ref = R.anls(vd, k, lambda_w=0, lambda_h=0, min_iter=iters, max_iter=iters, w0=w0, h0=h0)
         assert wh_error(w, h, ref.w, ref.h, v) < WH_TOL
-        np.testing.assert_allclose(obj, ref.obj_history, rtol=1e-3)
+        np.testing.assert_allclose(obj, ref.obj_history, rtol=1e-5)      # (measured: 5e-7)
         assert not w[:, 2].any() and not h[2].any()          # the component stays dead, as in the reference
     else:
         y = (w.T @ w) @ h - w.T @ vd                         # duals of the H sub-problem for the returned W

@@ -6,7 +6,7 @@ from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
 
 pytestmark = pytest.mark.gpu
 
-OBJ_RTOL = 5e-4
+OBJ_RTOL = 5e-5      # (measured on the goldens: 6.4e-6)
 
 CASES = ["aoadmm_eu_nn_planted", "aoadmm_eu_l1n_planted", "aoadmm_eu_nn_uniform", "aoadmm_eu_l1n_uniform"]
 
@@ -61,7 +61,7 @@ def test_aoadmm_kl_matches_reference():
     err = wh_error(res.w, res.h, z["w"], z["h"], v)
     snaps = snapshot_errors("aoadmm_kl_nn", ao_admm) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-4)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-5)      # (measured: 1.9e-6)
     assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])
 
 
@@ -106,7 +106,7 @@ def test_aoadmm_eu_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypa
     res = ao_admm(v.copy(), k, **kw)
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
     assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)      # (measured: 1.3e-5)
     assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
 
 

@@ -71,7 +71,7 @@ def test_sharded_device_path(world, backend, k, tmp_path):
     assert err < 1e-4, err
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-4)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-5)      # (measured: 1.7e-6)
         np.testing.assert_array_equal(p["h"], h)        # replicated H is bit-identical on all ranks
 
 
@@ -232,7 +232,7 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
         assert any(t[1] < 10 for t in ref.trace["inner"]), "case must exercise the repair launch of the W sub-problem"
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-4 if solver in ("admm_kl", "ao_admm_kl") else 5e-4)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-5 if solver in ("admm_kl", "ao_admm_kl") else 3e-4)      # (measured: 3.5e-6 / 6.1e-5, the ANLS cases)
         np.testing.assert_array_equal(p["h"], h)
         if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
@@ -273,10 +273,10 @@ def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
     ref = R.mur(v.astype(np.float64), 12, distance_type="eu", min_iter=10, max_iter=10)
     assert z["mur_w"].shape == (600, 12)
     assert np.linalg.norm(z["mur_w"] @ z["mur_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
-    np.testing.assert_allclose(z["mur_obj"], ref.obj_history, rtol=2e-4)
+    np.testing.assert_allclose(z["mur_obj"], ref.obj_history, rtol=1e-6)      # (measured: 1.7e-8)
     ref = R.ao_admm(v.astype(np.float64), 12, reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)
     assert np.linalg.norm(z["ao_w"] @ z["ao_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
-    np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=2e-5)      # (measured: 1.2e-6)
 
 
 def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs():

@@ -32,7 +32,7 @@ def test_config2_mur_eu_16384x8192_k64_vs_oracle():
     print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-5)      # (measured: 1.5e-6)
     direct = direct_objective(v, res.w, res.h, "eu")
     assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
     assert np.all(np.diff(res.obj_history) < 0)
@@ -53,7 +53,7 @@ def test_config4_mur_kl_32768x16384_k64_vs_oracle():
     print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-3)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-5)      # (measured: 1.8e-6)
     direct = direct_objective(v, res.w, res.h, "kl")
     assert abs(direct - res.obj_history[-1]) <= 1e-4 * abs(direct)
 
@@ -80,7 +80,7 @@ def test_config3_aoadmm_l1n_16384x8192_k128_vs_oracle():
     print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)      # (measured: 1.4e-5)
     direct = direct_objective(v, res.w, res.h, "eu")
     assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
 
@@ -100,7 +100,7 @@ def test_config5_shard_mur_eu_16384x16384_k128_vs_oracle():
     print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-6)      # (measured: 3.6e-9)
     direct = direct_objective(v, res.w, res.h, "eu")
     assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
 
@@ -121,7 +121,7 @@ def test_admm_fixed_rho_8192x4096_k64_vs_oracle():
     print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
           f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-6)      # (measured: 1.7e-8)
 
 
 def test_anls_16384x8192_k64_kkt_of_both_half_steps():

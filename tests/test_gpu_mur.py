@@ -8,7 +8,7 @@ from oracle import nmf_ref as R
 
 pytestmark = pytest.mark.gpu
 
-OBJ_RTOL = 2e-4   # f32 MFMA factors vs the f64 reference, objective summed in f64
+OBJ_RTOL = 4e-5   # f32 MFMA factors vs the f64 reference, objective summed in f64 (measured: 1e-7 on the goldens, 3.8e-6 at most)
 
 EU = ["mur_eu_cfg1_random", "mur_eu_cfg1_nndsvdz", "mur_eu_lambda", "mur_eu_f32v",
       "mur_eu_signed", "mur_eu_ragged"]
@@ -83,7 +83,7 @@ def test_mur_kl_matches_reference(name):
     snaps = snapshot_errors(name, mur) if err >= WH_TOL else {}
     assert err < WH_TOL, f"WH error {err:.3e}; per-snapshot {snaps}"
     # KL objective: sum of v log(v/wh) - v + wh with cancellation between terms; f32 log
-    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=1e-3)
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=2e-6)      # (measured: 9.5e-8)
 
 
 def test_mur_kl_default_distance_is_kl_like_reference():
@@ -132,7 +132,7 @@ def test_mur_kl_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch
     ref = R.mur(v.astype(np.float64), k, **kw)
     err = wh_error(res.w, res.h, ref.w, ref.h, v)
     assert err < WH_TOL, err
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-3)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)      # (measured: 3.6e-6 split-bf16, 3.6e-7 exact-f32 products)
 
 
 def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):

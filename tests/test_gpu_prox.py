@@ -83,7 +83,7 @@ def test_admm_with_l1inf_follows_the_reference_over_the_first_iterations(name, c
         res = admm(v, meta["k"], **kw)
     finally:
         U.QUIET = quiet
-    np.testing.assert_allclose(res.obj_history[:3], z["obj_history"][:3], rtol=1e-3)
+    np.testing.assert_allclose(res.obj_history[:3], z["obj_history"][:3], rtol=2e-5)      # (measured: 1.3e-6)
     out = capsys.readouterr().out
     if name.endswith("_t"):                # the reference's print inside the transposed branch (admm.py:190), H then W
         assert out.count("will go 96") == 3 and out.count("will go 128") == 3

@@ -82,4 +82,4 @@ def test_solver_with_device_nndsvd_matches_oracle(monkeypatch):
     err = np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
     assert err < 1e-4, err
     assert res.i == ref.i
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-5)      # (measured: 9.8e-7)
