@@ -210,3 +210,31 @@ def test_signed_data_with_a_resident_engine_is_lifted_on_the_device_too():
     np.random.seed(4)
     ref = R.mur(x.copy(), 5, distance_type="eu", min_iter=8, max_iter=8)
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=OBJ_RTOL)
+
+
+def test_mur_kl_after_another_solver_touched_h_on_the_same_handle():
+    """The fused MUR-KL epilogues leave the row sums of H (as partials) and the images of H for the NEXT iteration
+    (kl_h_epilogue_kernel); they are only trusted for the iteration right behind the one that wrote them.  A Euclidean
+    iteration in between changes H: the KL iterations that follow must give what a fresh handle started from the same
+    factors gives, bit for bit."""
+    from nmf_amd.engine import Engine
+    m, n, k = 384, 320, 40
+    v = R.planted_matrix(m, n, k, seed=5, dtype=np.float32)
+    rs = np.random.RandomState(1)
+    w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+    NEVER = 10 ** 9
+    with Engine(m, n, k) as a:
+        a.upload_v(v)
+        a.set_factors(w0, h0)
+        a.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 0, 3)          # KL, iterations 0..2
+        a.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 3, 1)            # one Euclidean iteration: H changes behind the KL path's back
+        w1, h1 = a.get_factors()
+        a.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 4, 3)          # KL again, iterations 4..6
+        wa, ha = a.get_factors()
+    with Engine(m, n, k) as b:
+        b.upload_v(v)
+        b.set_factors(w1, h1)
+        b.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 0, 3)
+        wb, hb = b.get_factors()
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(ha, hb)
