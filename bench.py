@@ -243,7 +243,7 @@ def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup
                 "objective_decreasing": ok, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
                 "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
-                "all_reduce_bytes": 4.0 * (k * n + k * k) + 64.0,
+                "all_reduce_bytes": float(shard.xf32.numel() * 4 if shard.merge_objective() else shard.xf32.numel() * 4 + 64),
                 "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
     finally:
         shard.eng.close()
