@@ -144,6 +144,19 @@ int nmfx_mur_finish(nmfx_handle_t h, int distance, int64_t min_iter, double tol1
 int nmfx_mur_phase_a(nmfx_handle_t h, int distance, double lambda_w, int64_t j);
 int nmfx_mur_phase_b(nmfx_handle_t h, int distance, double lambda_h,
                      int64_t min_iter, double tol1, double tol2, int64_t j);
+/* Phase A in pieces, so that the exchange can overlap with the H-side product (the all-reduce of one column chunk of V runs
+ * while the next chunk is computed).  Euclidean loss on the split-bf16 path only: nmfx_mur_chunk_info returns
+ * unit = 128 (0: not available for this handle / distance), the padded n and the padded k.  The f32 exchange buffer is
+ * [column][factor]: after nmfx_mur_phase_a_cols(h, d, c0, c1) the range xf32[c0 * k_padded, c1 * k_padded) holds this
+ * rank's part of (W^T V)[:, c0:c1] and may be reduced; the call whose c1 is the padded n also packs what lies behind the
+ * k n part (W^T W, the objective partial), so its range extends to the end of the buffer.  c0, c1: multiples of `unit`,
+ * at least 512 columns per call, ascending and without gaps:
+ *     nmfx_mur_phase_a_head(j);  for each chunk: nmfx_mur_phase_a_cols(c0, c1), all-reduce of the range (asynchronously);
+ *     wait for the reductions;  nmfx_mur_phase_b(j).
+ * Results differ from nmfx_mur_phase_a by the summation order of the product's splits only.                            */
+int nmfx_mur_chunk_info(nmfx_handle_t h, int distance, int64_t* unit, int64_t* n_padded, int64_t* k_padded);
+int nmfx_mur_phase_a_head(nmfx_handle_t h, int distance, double lambda_w, int64_t j);
+int nmfx_mur_phase_a_cols(nmfx_handle_t h, int distance, int64_t c0, int64_t c1);
 int nmfx_mur_finish_a(nmfx_handle_t h, int distance, int64_t j);
 int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
 

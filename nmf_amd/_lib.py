@@ -82,6 +82,9 @@ SIGNATURES = {
     "nmfx_get_diagnostics": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "nmfx_get_nnls_fallbacks": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "nmfx_get_inner_paths": (_i32, [_vp, C.POINTER(_i64)]),
+    "nmfx_mur_chunk_info": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_mur_phase_a_head": (_i32, [_vp, _i32, _dbl, _i64]),
+    "nmfx_mur_phase_a_cols": (_i32, [_vp, _i32, _i64, _i64]),
     "nmfx_profile_enable": (_i32, [_vp, _i32]),
     "nmfx_profile_get": (_i32, [_vp, C.c_char_p, _pd, C.POINTER(_i64)]),
     "nmfx_profile_reset": (_i32, [_vp]),

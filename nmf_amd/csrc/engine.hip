@@ -219,7 +219,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
-                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part};
+                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -547,6 +547,32 @@ int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) 
         return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_kl_phase_a_bf16(E, lambda_w, j)
                                                              : nmfx_mur_kl_phase_a(E, lambda_w, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;
+}
+
+// Phase A in pieces (chunked exchange; Euclidean loss on the split-bf16 path only -- nmfx_mur_chunk_info says whether)
+static bool mur_chunkable(nmfx_engine* E, int distance) {
+    return distance == NMFX_EU && E->precision == 1 && nmfx_bf16_supported(E);
+}
+int nmfx_mur_chunk_info(nmfx_handle_t E, int distance, int64_t* unit, int64_t* n_padded, int64_t* k_padded) {
+    if (!E) return NMFX_E_ARG;
+    const bool ok = mur_chunkable(E, distance);
+    if (unit) *unit = ok ? 128 : 0;
+    if (n_padded) *n_padded = E->np;
+    if (k_padded) *k_padded = E->kp;
+    return NMFX_OK;
+}
+int nmfx_mur_phase_a_head(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
+    if (!E) return NMFX_E_ARG;
+    E->himg_both = false;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    if (!mur_chunkable(E, distance)) { E->err = "phase_a_head: Euclidean loss on the split-bf16 path only (nmfx_mur_chunk_info)"; return NMFX_E_ARG; }
+    return nmfx_mur_eu_phase_a_head_bf16(E, lambda_w, j);
+}
+int nmfx_mur_phase_a_cols(nmfx_handle_t E, int distance, int64_t c0, int64_t c1) {
+    if (!E) return NMFX_E_ARG;
+    if (!mur_chunkable(E, distance)) { E->err = "phase_a_cols: Euclidean loss on the split-bf16 path only (nmfx_mur_chunk_info)"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    return nmfx_mur_eu_phase_a_cols_bf16(E, c0, c1);
 }
 
 int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min_iter, double tol1,

@@ -2151,5 +2151,108 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
     return launch_h_update_bf16<64>(E, E->fused_pack, (float)lambda_h, j, min_iter, tol1, tol2);
 }
 
+// ---- phase A in pieces: an exchange that overlaps with the H-side product ("column chunks") ----------------
+// The exchange buffer of the split-bf16 path is [column][factor], so the columns [c0, c1) of V are the contiguous range
+// xf32[c0 kp, c1 kp): the caller can hand that range to the collective while the product of the next range runs.
+//   head:  everything of phase A in front of the H-side product (W phase, W epilogue; k = 128: W^T W from the images)
+//   cols:  B^T = V[:, c0:c1]^T W -- a row range of the V^T copy, i.e. a launch of the same product kernel with fewer row
+//          blocks and MORE reduction splits (so that the grid still fills the CUs), its slabs in a buffer of their own --
+//          and the pack of that range; the range that ends at the padded n also packs W^T W, the objective and the tail.
+// Results differ from the one-piece phase A by the summation order of the splits only.
+__global__ __launch_bounds__(256) void mur_pack_cols_kernel(
+    const float* __restrict__ Bpart, int bsplit, int64_t bcount, float* __restrict__ bout,
+    const float* __restrict__ Gpart, int gsplit, int64_t gcount, float* __restrict__ gout,
+    const double* __restrict__ objpart, int64_t nobj, double* __restrict__ xf64, int nb, int with_g,
+    const int* __restrict__ flag, float* __restrict__ xtail, int xrank, int xworld)
+{
+    if (*flag) return;
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    if (b < nb) {
+        for (int64_t i4 = (int64_t)b * 256 + threadIdx.x; i4 * 4 < bcount; i4 += (int64_t)nb * 256) {
+            float4 s = *reinterpret_cast<const float4*>(Bpart + i4 * 4);
+            for (int p = 1; p < bsplit; ++p) {
+                const float4 t = *reinterpret_cast<const float4*>(Bpart + (int64_t)p * bcount + i4 * 4);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            *reinterpret_cast<float4*>(bout + i4 * 4) = s;
+        }
+    } else if (!with_g) {
+        return;
+    } else if (b < nb + (int)((gcount + 255) / 256)) {
+        const int64_t i = (int64_t)(b - nb) * 256 + threadIdx.x;
+        if (i < gcount) {
+            float s = Gpart[i];
+            for (int p = 1; p < gsplit; ++p) s += Gpart[(int64_t)p * gcount + i];
+            gout[i] = s;
+        }
+    } else {
+        double t = 0.0;
+        for (int64_t i = threadIdx.x; i < nobj; i += 256) t += objpart[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+        __syncthreads();
+        t = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        if (threadIdx.x == 0) xf64[0] = t;
+        if (xtail) {                                   // NMFX_XTAIL: own slot = the four 16-bit digits of t, zeros elsewhere
+            const unsigned long long tbits = (unsigned long long)__double_as_longlong(t);
+            for (int i = threadIdx.x; i < 4 * xworld; i += blockDim.x)
+                xtail[i] = (i >> 2) == xrank ? (float)((tbits >> (16 * (i & 3))) & 0xffffull) : 0.f;
+        }
+    }
+}
+
+int nmfx_mur_eu_phase_a_head_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
+    int rc;
+    if (!E->bf_ready) E->wsel = (int)(j & 1);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    const int cur = (int)(j & 1), nxt = cur ^ 1;
+    if (E->kp != 64) {
+        { ProfScope ps(E, "sum_hht");
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, (int64_t)E->kp * E->kp, E->HHt))) return rc; }
+        if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", false, 3))) return rc;
+        if ((rc = launch_w_update_bf16<128>(E, E->W[cur], E->W[nxt], nxt, E->HHt, 1, (float)lambda_w))) return rc;
+        E->chunk_gslabs = E->gsplit;
+        return nmfx_bf16_gram_tn(E, &E->chunk_gslabs);
+    }
+    if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3))) return rc;
+    return launch_w_update_bf16<64>(E, E->W[cur], E->W[nxt], nxt, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w);
+}
+
+int nmfx_mur_eu_phase_a_cols_bf16(nmfx_engine* E, int64_t c0, int64_t c1) {
+    int rc;
+    if (!E->bf_ready) { E->err = "phase_a_cols: call nmfx_mur_phase_a_head first"; return NMFX_E_STATE; }
+    if (c0 < 0 || c1 <= c0 || c1 > E->np || c0 % 128 || c1 % 128 || (c0 > 0 && c1 - c0 < 512 && c1 - c0 < E->np)) {
+        E->err = "phase_a_cols: column range must be a multiple of 128 inside the padded n (at least 512 columns)"; return NMFX_E_ARG; }
+    const int64_t R = c1 - c0, rblocks = R / 128, mgroups = E->mp / 64;
+    // reduction splits of this launch: enough blocks for the CUs, at least 4 groups of 64 rows per block
+    int64_t S = std::max<int64_t>(E->bt_split, ((int64_t)E->ncu + rblocks / 2) / rblocks);
+    S = std::max<int64_t>(1, std::min<int64_t>(S, std::max<int64_t>(1, mgroups / 4)));
+    const int64_t need = S * R * E->kp;
+    if (need > E->Bt_chunk_cap) {
+        if (E->Bt_chunk) { NMFX_HIP(hipStreamSynchronize(E->stream)); NMFX_HIP(hipFree(E->Bt_chunk)); E->Bt_chunk = nullptr; }
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Bt_chunk), (size_t)need * sizeof(float)));
+        E->Bt_chunk_cap = need;
+    }
+    const float* X = E->Vt + (c0 / 128) * mgroups * 8192;             // tile-major V^T: row block c0 / 128
+    const int ng = (E->kp == 64 && c0 == 0) ? (int)std::min<int64_t>(E->gram_ng_h, rblocks) : 0;
+    if ((rc = launch_xyt(E, false, X, true, E->mp, R, (int)mgroups, (int)S, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
+                         E->Bt_chunk, E->kp == 64 ? E->G_part : nullptr, "hphase", false, ng, 3))) return rc;
+    if (E->kp == 64 && c0 == 0) E->chunk_gslabs = ng * (int)S;
+    ProfScope ps(E, "pack");
+    const bool last = c1 == E->np;
+    const int nb = (int)std::min<int64_t>(256, (R * E->kp / 4 + 255) / 256);
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    float* tail = E->xworld > 0 ? E->xf32 + (int64_t)E->kp * E->np + kk + E->kp : nullptr;
+    hipLaunchKernelGGL(mur_pack_cols_kernel, dim3((unsigned)(nb + (last ? (int)((kk + 255) / 256) + 1 : 0))), dim3(256), 0, E->stream,
+                       E->Bt_chunk, (int)S, R * E->kp, E->xf32 + c0 * E->kp, E->G_part, E->chunk_gslabs, kk,
+                       E->xf32 + (int64_t)E->kp * E->np, E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->xf64, nb,
+                       last ? 1 : 0, &E->state->flag, tail, E->xrank, E->xworld);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // (nmfx_create: forces this translation unit's code object onto the device under the library's start-up lock)
 int nmfx_preload_bf16() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(transpose_tiled_kernel)) == hipSuccess ? 0 : -1; }

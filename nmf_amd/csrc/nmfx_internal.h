@@ -68,6 +68,9 @@ struct nmfx_engine {
     float* HHt_part = nullptr;     // [gram_splits][kp][kp]
     float* G_part = nullptr;       // [gram_splits][kp][kp]
     float* G_big = nullptr;        // [<= 256][kp][kp]: row-split slabs of the image-based Gram kernel (k padded to 128), folded into G_part
+    float* Bt_chunk = nullptr;     // chunked exchange (nmfx_mur_phase_a_cols): the slabs of ONE column chunk of the H-side product
+    int64_t Bt_chunk_cap = 0;
+    int chunk_gslabs = 0;          // ... and the number of W^T W slabs its first chunk / the Gram kernel left
     float* kl_part = nullptr;      // MUR-KL, split-bf16: [np/64][kp] row-sum partials of H | [mp/64][kp] column-sum partials of W (the fused epilogues)
     int64_t kl_h_iter = -2;        // outer iteration whose H epilogue wrote the H partials and the H / H^T images (valid for iteration + 1 only)
     float* A_part = nullptr;       // [wsplit][mp][kp]
@@ -166,6 +169,8 @@ inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
+int nmfx_mur_eu_phase_a_head_bf16(nmfx_engine* E, double lambda_w, int64_t j);
+int nmfx_mur_eu_phase_a_cols_bf16(nmfx_engine* E, int64_t c0, int64_t c1);
 int nmfx_bf16_kl_w_epilogue(nmfx_engine* E, const float* Wold, float* Wnew, int nxt, float lam, const float* rowsum);
 int nmfx_bf16_kl_h_epilogue(nmfx_engine* E, float lam, int64_t j, int64_t min_iter, double tol1, double tol2);
 int nmfx_bf16_vht(nmfx_engine* E, bool obj, int zbuf, const char* name, bool kl = false, int terms = 4);   // terms: kernels_bf16.hip, top

@@ -83,6 +83,15 @@ class TorchComm:
             else:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_async(self, tensor):
+        """Start the sum-all-reduce of `tensor` and return a handle with wait(): on RCCL the collective runs on the process
+        group's own stream behind what the current stream holds so far, and wait() makes the current stream wait for it --
+        the kernels queued in between overlap with it.  Host-staged (tests): reduced at once."""
+        if self.stage or not tensor.is_cuda:
+            self.all_reduce(tensor)
+            return None
+        return self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def barrier(self):
         self.dist.barrier(group=self.group)
 
@@ -138,6 +147,27 @@ class DeviceShard:
 
     def phase_b(self, dist_code, lambda_h, min_iter, tol1, tol2, j):
         self.eng.mur_phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+
+    def chunk_ranges(self, dist_code, chunks):
+        """Column ranges [(c0, c1, first element, end element of the f32 exchange buffer)] of a phase A in `chunks` pieces,
+        or None where the engine has no chunked phase A for this loss / arithmetic or the matrix is too narrow."""
+        unit, npad, kpad = self.eng.mur_chunk_info(dist_code)
+        if not unit or chunks < 2:
+            return None
+        step = max(512, -(-npad // chunks) // unit * unit)
+        edges = list(range(0, npad, step)) + [npad]
+        if len(edges) > 2 and edges[-1] - edges[-2] < 512:          # a short last piece joins its neighbour
+            del edges[-2]
+        if len(edges) < 3:
+            return None
+        total = self.xf32.numel()
+        return [(c0, c1, c0 * kpad, c1 * kpad if c1 < npad else total) for c0, c1 in zip(edges[:-1], edges[1:])]
+
+    def phase_a_head(self, dist_code, lambda_w, j):
+        self.eng.mur_phase_a_head(dist_code, lambda_w, j)
+
+    def phase_a_cols(self, dist_code, c0, c1):
+        self.eng.mur_phase_a_cols(dist_code, c0, c1)
 
     def finish_a(self, dist_code, j):
         self.eng.mur_finish_a(dist_code, j)
@@ -232,12 +262,42 @@ def _mur_buffers(shard, dist_code=None):
     return x32, x64[:8]
 
 
-def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
+def _exchange_chunks():
+    """NMFX_DIST_CHUNKS=n (default 1 = off): phase A of sharded MUR-eu in n column chunks, the all-reduce of each chunk
+    running while the next one is computed.  Opt-in: what it gains depends on how many CUs the collective needs beside a
+    product kernel that fills all of them, which only a multi-GPU box can settle."""
+    import os
+    try:
+        return max(1, int(os.environ.get("NMFX_DIST_CHUNKS", "1")))
+    except ValueError:
+        return 1
+
+
+def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count, chunks=None):
     """Queue `count` sharded outer iterations (no host sync)."""
     bufs = _mur_buffers(shard, dist_code)
+    chunks = _exchange_chunks() if chunks is None else chunks
+    ranges = None
+    if chunks > 1 and dist_code == 0 and getattr(shard, "chunk_ranges", None) is not None and hasattr(comm, "all_reduce_async"):
+        ranges = shard.chunk_ranges(dist_code, chunks)
+    if ranges is None:
+        for j in range(first, first + count):
+            shard.phase_a(dist_code, lambda_w, j)
+            comm.all_reduce(*bufs)
+            shard.phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+        return
+    x32 = bufs[0]
     for j in range(first, first + count):
-        shard.phase_a(dist_code, lambda_w, j)
-        comm.all_reduce(*bufs)
+        shard.phase_a_head(dist_code, lambda_w, j)
+        pending = []
+        for c0, c1, e0, e1 in ranges:
+            shard.phase_a_cols(dist_code, c0, c1)
+            pending.append(comm.all_reduce_async(x32[e0:e1]))
+        if len(bufs) > 1:                                            # (the objective partial when it is not inside the f32 buffer)
+            comm.all_reduce(*bufs[1:])
+        for work in pending:
+            if work is not None:
+                work.wait()
         shard.phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
 
 

@@ -148,6 +148,18 @@ class Engine:
     def mur_phase_a(self, dist, lambda_w, j):
         self._ck(self.lib.nmfx_mur_phase_a(self.h, dist, float(lambda_w), int(j)))
 
+    def mur_chunk_info(self, dist):
+        """(unit, padded n, padded k) of the chunked phase A; unit = 0: not available for this handle / distance."""
+        u, n, k = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_mur_chunk_info(self.h, int(dist), C.byref(u), C.byref(n), C.byref(k)))
+        return u.value, n.value, k.value
+
+    def mur_phase_a_head(self, dist, lambda_w, j):
+        self._ck(self.lib.nmfx_mur_phase_a_head(self.h, int(dist), float(lambda_w), int(j)))
+
+    def mur_phase_a_cols(self, dist, c0, c1):
+        self._ck(self.lib.nmfx_mur_phase_a_cols(self.h, int(dist), int(c0), int(c1)))
+
     def mur_phase_b(self, dist, lambda_h, min_iter, tol1, tol2, j):
         self._ck(self.lib.nmfx_mur_phase_b(self.h, dist, float(lambda_h), int(min_iter), float(tol1),
                                            float(tol2), int(j)))

@@ -30,10 +30,18 @@ def _case(k=12):
     return m, n, k, v, np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
 
 
+def _case_wide(k):
+    from oracle import nmf_ref as R
+    m, n = 520, 1400                       # padded n = 1408: two column chunks of at least 512
+    v = R.planted_matrix(m, n, min(k, 32), seed=23, dtype=np.float32)
+    rs = np.random.RandomState(24)
+    return m, n, k, v, np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+
+
 KW = dict(distance_type="eu", min_iter=14, max_iter=14, lambda_w=0.01, lambda_h=0.02)
 
 
-def _worker(rank, world, port, backend, outdir, k=12):
+def _worker(rank, world, port, backend, outdir, k=12, wide=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
@@ -45,12 +53,14 @@ def _worker(rank, world, port, backend, outdir, k=12):
     torch.cuda.set_device(0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     from nmf_amd import dist as nd
-    m, n, k, v, w0, h0 = _case(k)
+    m, n, k, v, w0, h0 = (_case_wide if wide else _case)(k)
     r0, r1 = nd.row_range(m, rank, world)
     shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
     comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
+    pieces = shard.chunk_ranges(0, nd._exchange_chunks())
     res = nd.mur_sharded(shard, comm, batch=5, **KW)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
+             pieces=len(pieces) if pieces else 1)
     shard.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -73,6 +83,30 @@ def test_sharded_device_path(world, backend, k, tmp_path):
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-5)      # (measured: 1.7e-6)
         np.testing.assert_array_equal(p["h"], h)        # replicated H is bit-identical on all ranks
+
+
+@pytest.mark.parametrize("k", [40, 100])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, tmp_path, monkeypatch):
+    """NMFX_DIST_CHUNKS=2: phase A in two column chunks (nmfx_mur_phase_a_head / _cols), each chunk's range of the exchange
+    buffer reduced on its own -- over RCCL asynchronously, behind the product of the next chunk.  Same bars as the
+    one-piece exchange (the chunks only change the summation order of the product's splits); H bit-identical on all ranks."""
+    import torch.multiprocessing as mp
+    from oracle import nmf_ref as R
+    monkeypatch.setenv("NMFX_DIST_CHUNKS", "2")
+    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), k, True), nprocs=world, join=True)
+    m, n, k, v, w0, h0 = _case_wide(k)
+    ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert all(int(p["pieces"]) == 2 for p in parts)
+    w = np.concatenate([p["w"] for p in parts])
+    h = parts[0]["h"]
+    err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
+    assert err < 1e-4, err
+    for p in parts:
+        assert int(p["i"]) == ref.i
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-5)
+        np.testing.assert_array_equal(p["h"], h)
 
 
 def test_sharded_device_path_with_the_separate_objective_exchange(tmp_path, monkeypatch):
