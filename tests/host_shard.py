@@ -392,3 +392,58 @@ class HostShard:
 
     def get_factors(self):
         return self.w, self.h
+
+
+class ChunkedHostShard(HostShard):
+    """HostShard with the exchange buffer of the device's split-bf16 path -- [column][factor] -- and phase A in pieces
+    (phase_a_head / phase_a_cols, Euclidean loss), so that dist.run_iterations' chunked loop runs on the CPU."""
+    unit = 8                                           # column granularity of the stand-in
+
+    def chunk_ranges(self, kind, chunks):
+        n, k = self.v.shape[1], self.k
+        if kind != 0 or chunks < 2 or n < 2 * self.unit:
+            return None
+        step = max(self.unit, -(-n // chunks) // self.unit * self.unit)
+        edges = list(range(0, n, step)) + [n]
+        if len(edges) > 2 and edges[-1] - edges[-2] < self.unit:
+            del edges[-2]
+        total = self.x32.numel()
+        return [(c0, c1, c0 * k, c1 * k if c1 < n else total) for c0, c1 in zip(edges[:-1], edges[1:])]
+
+    def phase_a_head(self, kind, lambda_w, j):
+        assert kind == 0
+        self.cols_seen = []
+        if self.flag:
+            return
+        self.x64.zero_()
+        self.x64[0] = self._local_objective(kind)
+        self.w_new = R.mur_w_step("eu", self.v, self.w, self.h, self.w @ self.h, lambda_w)
+        self.x32.zero_()
+
+    def phase_a_cols(self, kind, c0, c1):
+        self.cols_seen.append((c0, c1))
+        if self.flag:
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        x[c0 * k:c1 * k] = (self.v[:, c0:c1].T @ self.w_new).ravel()          # [column][factor]
+        if c1 == n:
+            x[k * n:k * n + k * k] = (self.w_new.T @ self.w_new).ravel()
+
+    def phase_a(self, kind, lambda_w, j):
+        if kind != 0:
+            return super().phase_a(kind, lambda_w, j)
+        self.phase_a_head(kind, lambda_w, j)
+        self.phase_a_cols(kind, 0, self.v.shape[1])
+
+    def phase_b(self, kind, lambda_h, min_iter, tol1, tol2, j):
+        if kind != 0:
+            return super().phase_b(kind, lambda_h, min_iter, tol1, tol2, j)
+        if self.flag or self._record(min_iter, tol1, tol2, j):
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        b = x[:k * n].reshape(n, k).T
+        g = x[k * n:k * n + k * k].reshape(k, k)
+        self.w = self.w_new
+        self.h = self.h * b / (g @ self.h + lambda_h * self.h + R.EPS)

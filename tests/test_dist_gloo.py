@@ -36,10 +36,15 @@ def _worker(rank, world, port, case, outdir):
     rs = np.random.RandomState(case["seed"] + 1)
     w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
     r0, r1 = nd.row_range(m, rank, world)
-    shard = HostShard(v[r0:r1], k, w0[r0:r1], h0)
+    if case.get("chunks"):
+        from host_shard import ChunkedHostShard
+        os.environ["NMFX_DIST_CHUNKS"] = str(case["chunks"])
+        shard = ChunkedHostShard(v[r0:r1], k, w0[r0:r1], h0)
+    else:
+        shard = HostShard(v[r0:r1], k, w0[r0:r1], h0)
     res = nd.mur_sharded(shard, nd.TorchComm(), batch=case["batch"], **case["kw"])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i,
-             obj=np.asarray(res.obj_history), r0=r0, r1=r1)
+             obj=np.asarray(res.obj_history), r0=r0, r1=r1, pieces=len(getattr(shard, "cols_seen", [0])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,10 +56,15 @@ CASES = [
          kw=dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-9, tol2=2e-4)),
     dict(m=96, n=64, k=3, seed=5, batch=5,
          kw=dict(distance_type="kl", min_iter=9, max_iter=9, lambda_w=0.0, lambda_h=0.02)),
+    # NMFX_DIST_CHUNKS: phase A in column chunks, every chunk's range of the [column][factor] buffer reduced on its own
+    dict(m=150, n=90, k=5, seed=3, batch=7, chunks=3,
+         kw=dict(distance_type="eu", min_iter=12, max_iter=12, lambda_w=0.05, lambda_h=0.1)),
+    dict(m=131, n=77, k=4, seed=4, batch=16, chunks=2,
+         kw=dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-9, tol2=2e-4)),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=["eu_lambda", "eu_converge", "kl"])
+@pytest.mark.parametrize("case", CASES, ids=["eu_lambda", "eu_converge", "kl", "eu_lambda_3_chunks", "eu_converge_2_chunks"])
 def test_sharded_mur_equals_single_process_oracle(case, tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
@@ -67,6 +77,8 @@ def test_sharded_mur_equals_single_process_oracle(case, tmp_path):
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     w = np.concatenate([p["w"] for p in parts])
     assert [(int(p["r0"]), int(p["r1"])) for p in parts] == [(0, m // 2), (m // 2, m)]
+    if case.get("chunks"):
+        assert all(int(p["pieces"]) >= 2 for p in parts)          # (the last iteration's phase A came in pieces)
     for p in parts:
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=1e-10)
