@@ -514,15 +514,15 @@ __global__ __launch_bounds__(256) void nnls_inverse_kernel(const float* __restri
 // the whole remaining LDS as its workspace (complements up to 56): at k = 128 a fifth of the problems of the first
 // iterations have complements above 36, and the elimination kernel needs ~280 us for each of them.
 template <int KP, bool SECOND = false>
-__global__ __launch_bounds__(SECOND ? 64 : (KP <= 64 ? 256 : 128)) void nnls_cinv_kernel(
+__global__ __launch_bounds__(SECOND ? 64 : (KP <= 64 ? 384 : 128)) void nnls_cinv_kernel(
     const double* __restrict__ Ginv, const int* __restrict__ inv_bad, const float* __restrict__ R, float* __restrict__ X,
     int64_t sj, int64_t sc, int64_t nprob, int k, DevState* __restrict__ st, int* __restrict__ todo)
 {
     if (st->flag) return;
     if (*inv_bad) { if (!SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st->nnls_noinv, 1); return; }
     constexpr int NV = KP <= 64 ? 1 : KP / 64;          // variables per lane
-    constexpr int NW = SECOND ? 1 : (KP <= 64 ? 4 : 2); // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
-    constexpr int MC = SECOND ? 56 : (KP <= 64 ? 32 : 36);   // largest complement solved here
+    constexpr int NW = SECOND ? 1 : (KP <= 64 ? 6 : 2); // waves per block (k = 128: G^-1 alone takes 128 KiB of LDS)
+    constexpr int MC = SECOND ? 56 : (KP <= 64 ? 28 : 36);   // largest complement solved here
     constexpr int LDS_ = MC + 1;
     constexpr int WSZ = MC * LDS_ + MC + KP;            // per wave: S [MC][MC + 1] | z [MC] | r broadcast [KP]
     extern __shared__ __attribute__((aligned(16))) double cinv_lds[];
@@ -724,7 +724,7 @@ static int launch_nnls_cinv(nmfx_engine* E, const float* G, float diag_add, cons
         NMFX_HIP(hipGetLastError());
     }
     {
-        constexpr int NW = KP <= 64 ? 4 : 2, MC = KP <= 64 ? 32 : 36;
+        constexpr int NW = KP <= 64 ? 6 : 2, MC = KP <= 64 ? 28 : 36;
         const size_t shm = (size_t)(KP * KP + NW * (MC * (MC + 1) + MC + KP)) * sizeof(double);
         auto kern = nnls_cinv_kernel<KP>;
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
