@@ -1923,7 +1923,15 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
     } else if (b < nbb + KP * KP / 256) {
         const int64_t i = (int64_t)(b - nbb) * 256 + tid;
         float s2 = 0.f;
-        for (int p = 0; p < gsplit; ++p) s2 += Gpart[(int64_t)p * KP * KP + i];
+        int p = 0;
+        for (; p + 8 <= gsplit; p += 8) {               // eight slabs in flight together, added in slab order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = Gpart[(int64_t)(p + u) * KP * KP + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s2 += t[u];
+        }
+        for (; p < gsplit; ++p) s2 += Gpart[(int64_t)p * KP * KP + i];
         xf32[bcount + i] = s2;
     } else {
         double t = 0.0;

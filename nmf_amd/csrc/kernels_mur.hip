@@ -13,7 +13,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= count) return;
     float4 s = *reinterpret_cast<const float4*>(part + i4 * 4);
-    for (int p = 1; p < splits; ++p) {
+    int p = 1;
+    for (; p + 8 <= splits; p += 8) {                  // eight slabs in flight together (a Gram sum is 16 blocks: pure latency), added in slab order
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(part + (int64_t)(p + u) * count + i4 * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+    }
+    for (; p < splits; ++p) {
         const float4 t = *reinterpret_cast<const float4*>(part + (int64_t)p * count + i4 * 4);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
