@@ -1912,11 +1912,21 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
     const int64_t bcount = (int64_t)KP * np;
     if (b < nbb) {
         const int64_t c0 = (int64_t)b * 64;
-        for (int e = tid; e < 64 * (KP / 4); e += 256) {
-            const int c = e / (KP / 4), j4 = e % (KP / 4);
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int p = 0; p < bsplit; ++p) add4(v, Btpart + (int64_t)p * bcount + (c0 + c) * KP + 4 * j4);
-            tile[c][4 * j4] = v[0]; tile[c][4 * j4 + 1] = v[1]; tile[c][4 * j4 + 2] = v[2]; tile[c][4 * j4 + 3] = v[3];
+        constexpr int NE = 64 * (KP / 4) / 256;        // 16-byte pieces of the tile per thread: all their slab loads in flight together
+        float v[NE][4];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) { v[u][0] = 0.f; v[u][1] = 0.f; v[u][2] = 0.f; v[u][3] = 0.f; }
+        for (int p = 0; p < bsplit; ++p) {             // (slab order per element, as before)
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = tid + 256 * u, c = e / (KP / 4), j4 = e % (KP / 4);
+                add4(v[u], Btpart + (int64_t)p * bcount + (c0 + c) * KP + 4 * j4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + 256 * u, c = e / (KP / 4), j4 = e % (KP / 4);
+            tile[c][4 * j4] = v[u][0]; tile[c][4 * j4 + 1] = v[u][1]; tile[c][4 * j4 + 2] = v[u][2]; tile[c][4 * j4 + 3] = v[u][3];
         }
         __syncthreads();
         for (int e = tid; e < KP * 64; e += 256) xf32[(int64_t)(e >> 6) * np + c0 + (e & 63)] = tile[e & 63][e >> 6];
