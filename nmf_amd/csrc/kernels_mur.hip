@@ -68,7 +68,15 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
         const int64_t i = (int64_t)(b - nb) * 256 + threadIdx.x;
         if (i < gcount) {
             float s = Gpart[i];
-            for (int p = 1; p < gsplit; ++p) s += Gpart[(int64_t)p * gcount + i];
+            int p = 1;
+            for (; p + 8 <= gsplit; p += 8) {           // eight slabs in flight together, added in slab order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = Gpart[(int64_t)(p + u) * gcount + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; p < gsplit; ++p) s += Gpart[(int64_t)p * gcount + i];
             xf32[bcount + i] = s;
         }
     } else {
