@@ -1326,7 +1326,7 @@ static int ao_h_products(nmfx_engine* E) {
         if ((rc = ao_bf16_objective_product(E))) return rc;
         const int64_t nobj = (int64_t)(E->np / 128) * E->bt_split;
         if (E->kp == 64) return nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj);     // W^T W: by-product slabs
-        int gslabs = E->gsplit;                        // W^T W from the transposed images ao_bf16_objective_product has just built
+        int gslabs = 64;                               // W^T W from the transposed images ao_bf16_objective_product has just built (up to 64 slabs: the pack sums them, no fold launch)
         if ((rc = nmfx_bf16_gram_tn(E, &gslabs))) return rc;
         return nmfx_bf16_pack_t(E, E->G_part, gslabs, nobj);
     }

@@ -2105,7 +2105,8 @@ int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs) {
     const size_t shm = (size_t)2 * 2 * KP * 128;
     auto kern = gram_tn_bf16_kernel<KP>;
     if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
-    const bool fold = S > E->gsplit;
+    const int keep = std::max(*slabs, 1);              // in: the most slabs the consumer wants to sum itself; out: what it gets
+    const bool fold = S > keep;
     float* dst = E->G_part;
     if (fold) {
         if ((rc = lazy_alloc(E, &E->G_big, (int64_t)256 * kk))) return rc;
@@ -2114,10 +2115,11 @@ int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs) {
     hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(KP * 4), shm, E->stream, E->WThi, E->WTlo, E->mp, nsteps, dst, &E->state->flag);
     NMFX_HIP(hipGetLastError());
     if (fold) {
-        hipLaunchKernelGGL(fold_slabs_kernel, dim3((unsigned)((kk / 4 + 255) / 256), (unsigned)E->gsplit), dim3(256), 0, E->stream,
-                           E->G_big, S, kk, E->gsplit, E->G_part, &E->state->flag);
+        const int F = std::min(keep, E->gsplit);
+        hipLaunchKernelGGL(fold_slabs_kernel, dim3((unsigned)((kk / 4 + 255) / 256), (unsigned)F), dim3(256), 0, E->stream,
+                           E->G_big, S, kk, F, E->G_part, &E->state->flag);
         NMFX_HIP(hipGetLastError());
-        S = E->gsplit;
+        S = F;
     }
     *slabs = S;
     return NMFX_OK;
