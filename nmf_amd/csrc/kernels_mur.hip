@@ -56,7 +56,25 @@ __global__ __launch_bounds__(256) void mur_pack_kernel(
     __shared__ double sh[4];
     const int b = blockIdx.x;
     if (b < nb) {
-        for (int64_t i4 = (int64_t)b * 256 + threadIdx.x; i4 * 4 < bcount; i4 += (int64_t)nb * 256) {
+        // four grid strides per trip, every slab load of the four in flight together (k = 128 at n = 16384: eight strides per
+        // thread, i.e. eight dependent round trips otherwise); slab order per element as before
+        const int64_t stride = (int64_t)nb * 256, n4 = bcount / 4;
+        int64_t i4 = (int64_t)b * 256 + threadIdx.x;
+        for (; i4 + 3 * stride < n4; i4 += 4 * stride) {
+            float4 s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = *reinterpret_cast<const float4*>(Bpart + (i4 + u * stride) * 4);
+            for (int p = 1; p < hsplit; ++p) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(Bpart + (int64_t)p * bcount + (i4 + u * stride) * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s[u].x += t[u].x; s[u].y += t[u].y; s[u].z += t[u].z; s[u].w += t[u].w; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(xf32 + (i4 + u * stride) * 4) = s[u];
+        }
+        for (; i4 < n4; i4 += stride) {
             float4 s = *reinterpret_cast<const float4*>(Bpart + i4 * 4);
             for (int p = 1; p < hsplit; ++p) {
                 const float4 t = *reinterpret_cast<const float4*>(Bpart + (int64_t)p * bcount + i4 * 4);
