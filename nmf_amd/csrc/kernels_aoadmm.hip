@@ -1497,9 +1497,10 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
         if ((rc = nmfx_bf16_images_h(E, true))) return rc;   // the H the sub-problem above produced; H^T images for the next H-side product
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj", false, 3))) return rc;      // kp = 64: H H^T slabs as a by-product
         const bool byprod = E->kp == 64;
-        if (!byprod && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+        int hslabs = E->gsplit;                        // k = 128: H H^T from the images just built (four-term split products, like W^T W)
+        if (!byprod && (rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;
         { ProfScope ps(E, "sums");
-          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : E->gsplit, kk, E->HHt))) return rc;
+          if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, byprod ? nmfx_bf16_hht_slabs(E) : hslabs, kk, E->HHt))) return rc;
           if (sum_a) { if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->auxW))) return rc; }
           else E->ao_a_slabs = E->bf_wsplit; }          // the fused W-side kernel adds the slabs itself
         return nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0);

@@ -2095,29 +2095,43 @@ __global__ __launch_bounds__(256) void fold_slabs_kernel(const float* __restrict
     *reinterpret_cast<float4*>(out + (int64_t)f * count + i4 * 4) = a;
 }
 
+// (hi, lo: bf16 images [kp][ld] of a factor with `ld` rows / columns; out: the slab buffer of its Gram matrix)
+static int bf16_gram_images(nmfx_engine* E, const unsigned short* hi, const unsigned short* lo, int64_t ld, float* out, int* slabs);
+
 int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs) {
     ProfScope ps(E, "gram_tn");
-    if (E->kp != 128) { E->err = "bf16_gram_tn: k padded to 128 only"; return NMFX_E_ARG; }
+    return bf16_gram_images(E, E->WThi, E->WTlo, E->mp, E->G_part, slabs);
+}
+
+// H H^T from the images of H (k padded to 128), into HHt_part: the same kernel -- Hhi / Hlo are laid out like the transposed
+// images of W
+int nmfx_bf16_gram_h(nmfx_engine* E, int* slabs) {
+    ProfScope ps(E, "gram_nt");
+    return bf16_gram_images(E, E->Hhi, E->Hlo, E->np, E->HHt_part, slabs);
+}
+
+static int bf16_gram_images(nmfx_engine* E, const unsigned short* hi, const unsigned short* lo, int64_t ld, float* out, int* slabs) {
+    if (E->kp != 128) { E->err = "bf16_gram: k padded to 128 only"; return NMFX_E_ARG; }
     constexpr int KP = 128;
     int rc;
-    const int64_t nsteps = E->mp / 64, kk = (int64_t)KP * KP;
+    const int64_t nsteps = ld / 64, kk = (int64_t)KP * KP;
     int S = (int)std::min<int64_t>(256, std::max<int64_t>(1, nsteps / 4));
     const size_t shm = (size_t)2 * 2 * KP * 128;
     auto kern = gram_tn_bf16_kernel<KP>;
     if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
     const int keep = std::max(*slabs, 1);              // in: the most slabs the consumer wants to sum itself; out: what it gets
     const bool fold = S > keep;
-    float* dst = E->G_part;
+    float* dst = out;
     if (fold) {
         if ((rc = lazy_alloc(E, &E->G_big, (int64_t)256 * kk))) return rc;
         dst = E->G_big;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(KP * 4), shm, E->stream, E->WThi, E->WTlo, E->mp, nsteps, dst, &E->state->flag);
+    hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(KP * 4), shm, E->stream, hi, lo, ld, nsteps, dst, &E->state->flag);
     NMFX_HIP(hipGetLastError());
     if (fold) {
         const int F = std::min(keep, E->gsplit);
         hipLaunchKernelGGL(fold_slabs_kernel, dim3((unsigned)((kk / 4 + 255) / 256), (unsigned)F), dim3(256), 0, E->stream,
-                           E->G_big, S, kk, F, E->G_part, &E->state->flag);
+                           E->G_big, S, kk, F, out, &E->state->flag);
         NMFX_HIP(hipGetLastError());
         S = F;
     }

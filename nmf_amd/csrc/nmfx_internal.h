@@ -142,6 +142,7 @@ struct nmfx_engine {
 int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_obj, bool kl = false,
                        const float* Hsrc = nullptr, const float* Vsrc = nullptr, const int* flag2 = nullptr);
 int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs);   // W^T W from the transposed bf16 images of W (fresh after a W epilogue): G_part[*slabs][kp][kp]
+int nmfx_bf16_gram_h(nmfx_engine* E, int* slabs);
 int nmfx_launch_inverse64(nmfx_engine* E, const float* src, double diag_add, double* out64, int* soft_bad);   // f64 (src + diag_add I)^-1, kp 64 / 128
 int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2 = nullptr);
 // B_part[sr] = W^T V over the rows of split sr.
