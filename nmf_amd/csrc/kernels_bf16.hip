@@ -2156,7 +2156,11 @@ static int mur_eu_phase_a_bf16_k128(nmfx_engine* E, double lambda_w, int64_t j) 
 static int mur_eu_phase_b_bf16_k128(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     if ((rc = launch_h_update_bf16<128>(E, false, (float)lambda_h, j, min_iter, tol1, tol2))) return rc;
-    return nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit);
+    int hslabs = E->gsplit;                            // H H^T from the images the epilogue above has just written (sum_hht adds gsplit slabs)
+    if ((rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;
+    if (hslabs < E->gsplit)                            // (short H: fewer slabs than sum_hht reads -- the rest must be zero)
+        NMFX_HIP(hipMemsetAsync(E->HHt_part + (int64_t)hslabs * E->kp * E->kp, 0, (size_t)(E->gsplit - hslabs) * E->kp * E->kp * sizeof(float), E->stream));
+    return NMFX_OK;
 }
 
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
