@@ -716,7 +716,7 @@ __device__ __forceinline__ int fused_decide(const double* __restrict__ nrm_round
 // What one launch of a fused sub-problem kernel has to do.  Hinted speculation (r2): the round at which `terminate` fires
 // hardly moves from one outer iteration to the next (config 3: 4, 4, 4, ... on the H side, 3, 3, 3, ... on the W side, of
 // admm_iter = 10), so the first launch runs only r1 = the previous sub-problem's count of rounds (DevState::ao_hint, written
-// by the LAST launch of that sub-problem into the slot of the other parity -- no launch reads a slot it writes).
+// by the launch of that sub-problem that DECIDED, into the slot of the other parity -- no launch reads a slot it writes).
 //   phase 0: rounds [0, r1) from the live X, U; start saved; norm partials stored.
 //   phase 1: decide over [0, r1).  Fired at the last of them (the usual case) or r1 = admm_iter without a stop: the result
 //            stands.  Fired earlier: rerun from the saved start.  Not fired and r1 < admm_iter: CONTINUE -- save the state at
