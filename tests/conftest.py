@@ -66,3 +66,30 @@ if _BARS:
         return _orig_allclose(actual, desired, rtol=rtol, atol=atol, *args, **kwargs)
 
     np.testing.assert_allclose = _recording_allclose
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(worker, args, nprocs, tries=4):
+    """torch.multiprocessing.spawn of `worker(rank, *args)` with a fresh rendezvous port in args[1] (pass None there).
+    A port that was free when probed can be gone by the time rank 0 listens on it -- an outgoing connection of an earlier
+    test's process group, a socket in TIME_WAIT -- and the rendezvous then dies with EADDRINUSE before any rank has done
+    anything: that one failure is retried with another port (seen once in ~2000 spawns on the GPU box)."""
+    import torch.multiprocessing as mp
+    last = None
+    for _ in range(tries):
+        a = list(args)
+        a[1] = free_port()
+        try:
+            mp.spawn(worker, args=tuple(a), nprocs=nprocs, join=True)
+            return
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e).lower():
+                raise
+            last = e
+    raise last

@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import spawn_ranks
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -67,7 +69,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=["eu_lambda", "eu_converge", "kl", "eu_lambda_3_chunks", "eu_converge_2_chunks"])
 def test_sharded_mur_equals_single_process_oracle(case, tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_worker, (world, None, case, str(tmp_path)), world)
     from oracle import nmf_ref as R
     m, n, k = case["m"], case["n"], case["k"]
     v = R.planted_matrix(m, n, k, seed=case["seed"], dtype=np.float64)
@@ -150,7 +152,7 @@ def test_sharded_aoadmm_anls_equal_single_process_oracle(case, tmp_path):
     objective history, stop index, inner-iteration counts (the `terminate` norms span both
     shards) and factors."""
     world = 2
-    mp.spawn(_solver_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_solver_worker, (world, None, case, str(tmp_path)), world)
     from oracle import nmf_ref as R
     v, w0, h0 = _solver_inputs(case)
     ref = (R.ao_admm if case["solver"] == "ao_admm" else R.anls)(v, case["k"], w0=w0, h0=h0, **case["kw"])
@@ -217,7 +219,7 @@ GENERIC_CASES = [
                                                      "ao_admm_kl", "ao_admm_kl_long_inner"])
 def test_sharded_admm_and_unfused_aoadmm_equal_single_process_oracle(case, tmp_path):
     world = 2
-    mp.spawn(_generic_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_generic_worker, (world, None, case, str(tmp_path)), world)
     from oracle import nmf_ref as R
     v, w0, h0 = _solver_inputs(case)
     ref = {"ao_admm": R.ao_admm, "admm": R.admm}[case["solver"]](v, case["k"], w0=w0, h0=h0, **case["kw"])
@@ -247,7 +249,7 @@ def test_factorize_api_over_two_ranks_matches_the_single_process_reference_seman
     """nmf_amd.dist.factorize: reference keyword names / defaults per method, the global numpy RNG consumed in the
     reference's order on every rank, NNDSVD from rank 0 broadcast, rank 0 returns the gathered m x k factor."""
     world = 2
-    mp.spawn(_generic_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_generic_worker, (world, None, case, str(tmp_path)), world)
     from oracle import nmf_ref as R
     v, _, _ = _solver_inputs(case)
     np.random.seed(case["seed"])

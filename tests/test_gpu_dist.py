@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import spawn_ranks
+
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -71,7 +73,7 @@ def _worker(rank, world, port, backend, outdir, k=12, wide=False):
 def test_sharded_device_path(world, backend, k, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
-    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), k), nprocs=world, join=True)
+    spawn_ranks(_worker, (world, None, backend, str(tmp_path), k), world)
     m, n, k, v, w0, h0 = _case(k)
     ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
@@ -94,7 +96,7 @@ def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, tmp_path
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
     monkeypatch.setenv("NMFX_DIST_CHUNKS", "2")
-    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), k, True), nprocs=world, join=True)
+    spawn_ranks(_worker, (world, None, backend, str(tmp_path), k, True), world)
     m, n, k, v, w0, h0 = _case_wide(k)
     ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
@@ -118,7 +120,7 @@ def test_sharded_device_path_with_the_separate_objective_exchange(tmp_path, monk
         monkeypatch.setenv("NMFX_DIST_MERGE", mode)
         d = tmp_path / mode
         d.mkdir()
-        mp.spawn(_worker, args=(2, _free_port(), "gloo", str(d), 40), nprocs=2, join=True)
+        spawn_ranks(_worker, (2, None, "gloo", str(d), 40), 2)
         outs[mode] = [np.load(d / f"rank{r}.npz") for r in range(2)]
     for r in range(2):
         np.testing.assert_array_equal(outs["1"][r]["w"], outs["0"][r]["w"])
@@ -173,7 +175,7 @@ def test_graphed_loop_equals_eager_loop(tmp_path):
     """hipGraph replays of the sharded iteration (RCCL all-reduce captured inside) give the very
     same iterates, objective history and stop index as the Python-driven loop."""
     import torch.multiprocessing as mp
-    mp.spawn(_graph_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    spawn_ranks(_graph_worker, (1, None, str(tmp_path)), 1)
     z = np.load(tmp_path / "graph.npz")
     for name in ("stop", "full", "kl"):
         assert str(z[f"{name}_graph_mode"]) == "hipgraph" and str(z[f"{name}_eager_mode"]) == "eager"
@@ -253,7 +255,7 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
-    mp.spawn(_solver_gpu_worker, args=(world, _free_port(), backend, solver, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_solver_gpu_worker, (world, None, backend, solver, str(tmp_path)), world)
     m, n, k, v, w0, h0, kw = _solver_case(solver)
     oracle = R.ao_admm if solver.startswith("ao_admm") else R.admm if solver.startswith("admm") else R.anls
     ref = oracle(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
@@ -300,7 +302,7 @@ def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
     rank 0, gathered W on rank 0 (two ranks share the GPU: exchange staged through the host over gloo)."""
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
-    mp.spawn(_api_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_api_worker, (2, None, str(tmp_path)), 2)
     v = R.planted_matrix(600, 260, 12, seed=41, dtype=np.float32)
     z = np.load(tmp_path / "rank0.npz")
     np.random.seed(7)
@@ -323,10 +325,13 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NMFX_BENCH_BACKEND="gloo", NMFX_BENCH_CFG5_SHAPE="2048x1024x128", NMFX_BENCH_SHAPE="1024x512x64",
                NMF_AMD_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic",
-           "--tol-max-iter", "0"]
-    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    for _ in range(4):                                   # (a probed port can be taken by the time the rendezvous binds it: conftest.spawn_ranks)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+               "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic", "--tol-max-iter", "0"]
+        p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
