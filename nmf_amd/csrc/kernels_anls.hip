@@ -729,7 +729,8 @@ static int launch_nnls_cinv(nmfx_engine* E, const float* G, float diag_add, cons
         auto kern = nnls_cinv_kernel<KP>;
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
         const int64_t blocks_needed = (nprob + NW - 1) / NW;
-        const unsigned grid = (unsigned)(blocks_needed < 1024 ? blocks_needed : 1024);     // waves loop over the problems
+        const int64_t resident = (int64_t)E->ncu * (KP <= 64 ? 2 : 1);                     // blocks the LDS lets a CU hold
+        const unsigned grid = (unsigned)(blocks_needed < resident ? blocks_needed : resident);   // one resident round: waves loop over the problems
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, E->stream, E->nnls_ginv, inv_bad, R, X, sj, sc, nprob, E->k,
                            E->state, E->nnls_todo);
         NMFX_HIP(hipGetLastError());
