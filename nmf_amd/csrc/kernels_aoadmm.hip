@@ -777,6 +777,22 @@ __device__ __forceinline__ void ao_split8(const float4& p, const float4& q, AoFr
     ao_split2(p.x, p.y, hi.u.x, lo.u.x); ao_split2(p.z, p.w, hi.u.y, lo.u.y);
     ao_split2(q.x, q.y, hi.u.z, lo.u.z); ao_split2(q.z, q.w, hi.u.w, lo.u.w);
 }
+// Three images: x = hi + mid + lo EXACTLY (3 x 8 significant bits = the 24 of an f32; every remainder is exact in f32).
+// The inner product of a round takes them with the six terms hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid (what is dropped
+// is below 2^-24 of |x||y|): r3 -- with two images (16 bits, four terms) the error of aux = M^-1 rhs, amplified by the
+// cancellation in that product (cond(G + rho I) up to k + 1), put ||WH - W_ref H_ref|| / ||V|| at 1.1e-4 on a k = 100
+// problem whose H sub-problem is unregularised (tools/lab/ao_f32_state.py models it: 5.4e-5 -> 4.3e-6 with these six terms).
+__device__ __forceinline__ void ao_split2x3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(mid) : "v"(ra), "v"(rb));
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(sa), "v"(sb));
+}
+__device__ __forceinline__ void ao_split8x3(const float4& p, const float4& q, AoFrag8& hi, AoFrag8& mid, AoFrag8& lo) {
+    ao_split2x3(p.x, p.y, hi.u.x, mid.u.x, lo.u.x); ao_split2x3(p.z, p.w, hi.u.y, mid.u.y, lo.u.y);
+    ao_split2x3(q.x, q.y, hi.u.z, mid.u.z, lo.u.z); ao_split2x3(q.z, q.w, hi.u.w, mid.u.w, lo.u.w);
+}
 
 // ---- all rounds of a sub-problem in ONE launch ------------------------------
 // A round only couples the blocks through `terminate` (four global norms, ao_admm.py:33-43).
@@ -823,7 +839,7 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     constexpr int NE = CB / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [KP][CB] | M^-1 [KP][LDM] | 32 doubles
     float* ms = lds + KP * CB;
-    double* sh = reinterpret_cast<double*>(ms + KP * LDM);
+    double* sh = reinterpret_cast<double*>(ms + ((KP >= 64 && CB == 32) ? (3 * KP * KP) / 2 : KP * LDM));    // (split form: three bf16 images)
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     FusedPlan plan;
@@ -838,17 +854,19 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     constexpr bool SPLIT = KP >= 64 && CB == 32;
     constexpr int KS = KP / 32;
     unsigned short* mhi = reinterpret_cast<unsigned short*>(ms);
-    unsigned short* mlo = mhi + KP * KP;
+    unsigned short* mmd = mhi + KP * KP;
+    unsigned short* mlo = mmd + KP * KP;
     auto swzm = [](int r) { return KP == 128 ? (r & 15) : ((r & 15) >> 1); };
     if (SPLIT) {
         for (int i = tid; i < KP * (KP / 8); i += 256) {
             const int r = i / (KP / 8), c8 = i % (KP / 8);
             const float4 a4 = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8);
             const float4 b4 = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8 + 4);
-            AoFrag8 h, l;
-            ao_split8(a4, b4, h, l);
+            AoFrag8 h, md, l;
+            ao_split8x3(a4, b4, h, md, l);
             const int pos = c8 ^ swzm(r);
             *reinterpret_cast<uint4*>(mhi + r * KP + 8 * pos) = h.u;
+            *reinterpret_cast<uint4*>(mmd + r * KP + 8 * pos) = md.u;
             *reinterpret_cast<uint4*>(mlo + r * KP + 8 * pos) = l.u;
         }
     } else {
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
         // round and shared by its row tiles; read inside the MFMA loop they cost one LDS latency per k-step
         constexpr bool PRE = (CB == 32) && !SPLIT;
         float rball[PRE ? JT : 1][4][NE];
-        AoFrag8 bh[SPLIT ? KS : 1][NE], bl[SPLIT ? KS : 1][NE];
+        AoFrag8 bh[SPLIT ? KS : 1][NE], bm[SPLIT ? KS : 1][NE], bl[SPLIT ? KS : 1][NE];
         if (SPLIT) {                                   // B operands of the whole tile, once per round: column NE x + e, k block q of k-step u
 #pragma unroll
             for (int u = 0; u < KS; ++u)
@@ -919,7 +937,7 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                     const float* row = lds + (NE * x + e) * KP;
                     const float4 p0 = *reinterpret_cast<const float4*>(row + 4 * ((8 * u + 2 * q) ^ x));
                     const float4 p1 = *reinterpret_cast<const float4*>(row + 4 * ((8 * u + 2 * q + 1) ^ x));
-                    ao_split8(p0, p1, bh[SPLIT ? u : 0][e], bl[SPLIT ? u : 0][e]);
+                    ao_split8x3(p0, p1, bh[SPLIT ? u : 0][e], bm[SPLIT ? u : 0][e], bl[SPLIT ? u : 0][e]);
                 }
         }
         if (PRE) {
@@ -939,17 +957,22 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
 #pragma unroll
                     for (int u = 0; u < KS; ++u) {     // A operand: M^-1 row 16 it + x, k block q of k-step u
                         const int off = (16 * it + x) * KP + 8 * ((4 * u + q) ^ swzm(x));
-                        AoFrag8 ah, al;
+                        AoFrag8 ah, am, al;
                         ah.u = *reinterpret_cast<const uint4*>(mhi + off);
+                        am.u = *reinterpret_cast<const uint4*>(mmd + off);
                         al.u = *reinterpret_cast<const uint4*>(mlo + off);
 #pragma unroll
                         for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(ah, bh[SPLIT ? u : 0][e], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(am, bh[SPLIT ? u : 0][e], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(ah, bm[SPLIT ? u : 0][e], acc[e]);
 #pragma unroll
                         for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(al, bh[SPLIT ? u : 0][e], acc[e]);
 #pragma unroll
                         for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(ah, bl[SPLIT ? u : 0][e], acc[e]);
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(al, bl[SPLIT ? u : 0][e], acc[e]);
+                        for (int e = 0; e < NE; ++e) acc[e] = AO_MFMA_BF16(am, bm[SPLIT ? u : 0][e], acc[e]);
                     }
                 }
                 float4 mfa[SPLIT ? 1 : JT];
@@ -1020,9 +1043,11 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     constexpr int JT = KP / 16;
     constexpr int LDM = KP + 4;
     constexpr int LDR = KP + 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // M^-1 [KP][LDM] | RHS RB/16 x [16][LDR] | 32 doubles
-    float* rs = lds + KP * LDM;
-    double* sh = reinterpret_cast<double*>(rs + RB * LDR);
+    // f32 form: M^-1 [KP][LDM] | RHS RB/16 x [16][LDR] | 32 doubles;  split form (KP >= 64): three bf16 images of M^-1
+    // [3][KP][KP] | RHS RB/16 x [16][KP] | 32 doubles
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rs = lds + (KP >= 64 ? (3 * KP * KP) / 2 : KP * LDM);
+    double* sh = reinterpret_cast<double*>(rs + RB * (KP >= 64 ? KP : LDR));
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     FusedPlan plan;
@@ -1039,17 +1064,19 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     constexpr bool SPLIT = KP >= 64;
     constexpr int KS = KP / 32;                        // k-steps of 32
     unsigned short* mhi = reinterpret_cast<unsigned short*>(lds);
-    unsigned short* mlo = mhi + KP * KP;
+    unsigned short* mmd = mhi + KP * KP;
+    unsigned short* mlo = mmd + KP * KP;
     auto swzm = [](int r) { return KP == 128 ? (r & 15) : ((r & 15) >> 1); };
     if (SPLIT) {
         for (int i = tid; i < KP * (KP / 8); i += RB * 4) {
             const int r = i / (KP / 8), c8 = i % (KP / 8);
             const float4 a = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8);
             const float4 b = *reinterpret_cast<const float4*>(Minv + (int64_t)r * KP + 8 * c8 + 4);
-            AoFrag8 h, l;
-            ao_split8(a, b, h, l);
+            AoFrag8 h, md, l;
+            ao_split8x3(a, b, h, md, l);
             const int pos = c8 ^ swzm(r);
             *reinterpret_cast<uint4*>(mhi + r * KP + 8 * pos) = h.u;
+            *reinterpret_cast<uint4*>(mmd + r * KP + 8 * pos) = md.u;
             *reinterpret_cast<uint4*>(mlo + r * KP + 8 * pos) = l.u;
         }
     } else {
@@ -1059,7 +1086,7 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     }
     }
     const int64_t r0 = (int64_t)blockIdx.x * RB + wave * 16;
-    float* myrs = rs + wave * 16 * LDR;
+    float* myrs = rs + wave * 16 * (KP >= 64 ? KP : LDR);
     // accumulator layout: [it][g] = row 4 q + g, column 16 it + x
     float wx[JT][4], dx[JT][4], ax0[JT][4];
     const float* srcX = plan.from_backup ? Xb : X;
@@ -1087,13 +1114,13 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
             }
         __syncthreads();
         float4 xf[SPLIT ? 1 : JT];
-        AoFrag8 ah[SPLIT ? KS : 1], al[SPLIT ? KS : 1];
+        AoFrag8 ah[SPLIT ? KS : 1], am[SPLIT ? KS : 1], al[SPLIT ? KS : 1];
         if (SPLIT) {                                   // A operand: row x of the tile, k block q of k-step u (8 consecutive factors)
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 const float4 p0 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q) ^ x));
                 const float4 p1 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q + 1) ^ x));
-                ao_split8(p0, p1, ah[u], al[u]);
+                ao_split8x3(p0, p1, ah[u], am[u], al[u]);
             }
         } else {
 #pragma unroll
@@ -1108,13 +1135,16 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
 #pragma unroll
                 for (int u = 0; u < KS; ++u) {         // B operand: M^-1 row 16 it + x (= column, by symmetry of the convention), k block q
                     const int off = (16 * it + x) * KP + 8 * ((4 * u + q) ^ swzm(x));
-                    AoFrag8 bh, bl;
+                    AoFrag8 bh, bm, bl;
                     bh.u = *reinterpret_cast<const uint4*>(mhi + off);
+                    bm.u = *reinterpret_cast<const uint4*>(mmd + off);
                     bl.u = *reinterpret_cast<const uint4*>(mlo + off);
                     acc = AO_MFMA_BF16(ah[u], bh, acc);
+                    acc2 = AO_MFMA_BF16(am[u], bh, acc2);
+                    acc = AO_MFMA_BF16(ah[u], bm, acc);
                     acc2 = AO_MFMA_BF16(al[u], bh, acc2);
                     acc = AO_MFMA_BF16(ah[u], bl, acc);
-                    acc2 = AO_MFMA_BF16(al[u], bl, acc2);
+                    acc2 = AO_MFMA_BF16(am[u], bm, acc2);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] += acc2[g];
@@ -1383,7 +1413,9 @@ static int ao_fused_cols_cb(const nmfx_engine* E) { return (E->np / 64 < (int64_
 template <int KP, int CB>
 static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_iter, int phase, int32_t* slot,
                                 const int* hint_rd, int* hint_wr) {
-    const size_t shm = (size_t)(KP * CB + KP * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
+    constexpr bool split = KP >= 64 && CB == 32;       // three bf16 images of M^-1 instead of the f32 copy
+    const size_t shm = (size_t)(KP * CB) * sizeof(float) + (split ? (size_t)3 * KP * KP * 2 : (size_t)KP * (KP + 4) * sizeof(float)) +
+                       64 * sizeof(double);
     auto kern = ao_fused_cols_kernel<KP, CB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
@@ -1401,14 +1433,16 @@ static int launch_fused_cols(nmfx_engine* E, int prox, float lam, int admm_iter,
 // rows per block of the fused W-side kernel (also the granularity of its norm partials)
 static int ao_fused_rows_rb(const nmfx_engine* E) {
     static const int forced = getenv("NMFX_AO_ROWS_RB") ? atoi(getenv("NMFX_AO_ROWS_RB")) : 0;
-    if (forced == 64 || (forced == 128 && E->mp % 128 == 0)) return forced;
-    return (E->kp >= 64 && E->mp % 128 == 0 && E->mp / 128 >= (int64_t)E->ncu) ? 128 : 64;
+    if (forced == 64 || (forced == 128 && E->mp % 128 == 0 && E->kp == 64)) return forced;
+    // (k padded to 128: three images of M^-1 + the tiles of eight waves would need all 160 KiB and 512 bytes more)
+    return (E->kp == 64 && E->mp % 128 == 0 && E->mp / 128 >= (int64_t)E->ncu) ? 128 : 64;
 }
 
 template <int KP, int RB>
 static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int phase, int32_t* slot,
                                const double* decide_tab, const int* hint_rd, int* hint_wr) {
-    const size_t shm = (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float) + 64 * sizeof(double);
+    const size_t shm = (KP >= 64 ? (size_t)3 * KP * KP * 2 + (size_t)RB * KP * sizeof(float)
+                                 : (size_t)(KP * (KP + 4) + RB * (KP + 4)) * sizeof(float)) + 64 * sizeof(double);
     auto kern = ao_fused_rows_kernel<KP, RB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     // ao_a_slabs > 0: the W-side product's slabs are added here instead of by a sum_partials launch
@@ -1422,7 +1456,7 @@ static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, i
 template <int KP>
 static int launch_fused_rows(nmfx_engine* E, float* W, int prox, float lam, int admm_iter, int phase, int32_t* slot,
                              const double* decide_tab, const int* hint_rd, int* hint_wr) {
-    if constexpr (KP >= 64) {
+    if constexpr (KP == 64) {
         if (ao_fused_rows_rb(E) == 128)
             return launch_fused_rows_rb<KP, 128>(E, W, prox, lam, admm_iter, phase, slot, decide_tab, hint_rd, hint_wr);
     }

@@ -150,4 +150,4 @@ def test_hinted_inner_rounds_are_the_unhinted_ones(shape, admm_iter, iters, expe
     # split terms 8.8e-5 / 9.2e-5, the default three 1.15e-4 / 4.9e-5 for admm_iter = 16 / 8 (tools/lab/ao_terms.py); the
     # well-conditioned cases of test_gpu_aoadmm.py sit at 3e-6 -- hence twice the usual bar)
     err = float(np.linalg.norm(got["1"]["w"] @ got["1"]["h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)))
-    assert err < 2e-4, err
+    assert err < 1e-4, err
