@@ -7,8 +7,19 @@ from oracle import nmf_ref as R
 WH_TOL = 1e-4     # north_star: ||W_g H_g - W_r H_r||_F / ||V||_F < 1e-4
 
 
+def _record_wh(err):
+    """NMFX_RECORD_BARS=<file> (tests/conftest.py): the WH errors go to the same file as the assert_allclose records."""
+    import json
+    import os
+    path = os.environ.get("NMFX_RECORD_BARS")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "wh": float(err)}) + "\n")
+    return err
+
+
 def wh_error(w, h, w_ref, h_ref, v):
-    return np.linalg.norm(w @ h - w_ref @ h_ref) / np.linalg.norm(np.asarray(v, dtype=np.float64))
+    return _record_wh(np.linalg.norm(w @ h - w_ref @ h_ref) / np.linalg.norm(np.asarray(v, dtype=np.float64)))
 
 
 def run_fixture(name, solver, **override):
@@ -46,7 +57,7 @@ def wh_error_blocked(w, h, w_ref, h_ref, v, block=2048):
         num += float(np.sum(d * d))
         vb = np.asarray(v[a:b], dtype=np.float64)
         den += float(np.sum(vb * vb))
-    return np.sqrt(num / den)
+    return _record_wh(np.sqrt(num / den))
 
 
 def direct_objective(v, w, h, kind="eu", block=2048):

@@ -145,9 +145,9 @@ def test_hinted_inner_rounds_are_the_unhinted_ones(shape, admm_iter, iters, expe
     ref = R.ao_admm(v.astype(np.float64), k, distance_type="eu", reg_w=(0.02, "l1n"), reg_h=(0, "nn"), min_iter=iters, max_iter=iters,
                     admm_iter=admm_iter, nndsvd_init=(True, "zero"))
     assert [tuple(r) for r in got["1"]["inner"]] == [tuple(t) for t in ref.trace["inner"]]
-    # (H is not regularised here so that the counts move: the sub-problems are as ill-conditioned as W^T W, and the f32 state of
-    # the iterates alone puts every product form at 0.5 - 1.2e-4 on this problem -- exact-f32 products 5.9e-5 / 1.06e-4, four
-    # split terms 8.8e-5 / 9.2e-5, the default three 1.15e-4 / 4.9e-5 for admm_iter = 16 / 8 (tools/lab/ao_terms.py); the
-    # well-conditioned cases of test_gpu_aoadmm.py sit at 3e-6 -- hence twice the usual bar)
+    # (H is not regularised here so that the counts move: the sub-problems are as ill-conditioned as W^T W.  Round 2 had this case at
+    # 1.15e-4: the inner product aux = M^-1 rhs ran on two bf16 images per operand (16 bits), and the cancellation in that product
+    # amplifies the operand error by cond(G + rho I) <= k + 1.  With three images and six terms (f32-grade; kernels_aoadmm.hip,
+    # modelled on the CPU by tools/lab/ao_f32_state.py) it is 5e-6 in every product mode.)
     err = float(np.linalg.norm(got["1"]["w"] @ got["1"]["h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)))
     assert err < 1e-4, err
