@@ -180,7 +180,34 @@ def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192, rows=None):
     torch.cuda.empty_cache()
 
 
-def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup=2):
+def make_sharded(torch, dist, nd, rank, world, local_rank, build):
+    """This rank's shard and its exchange.  On RCCL ("nccl") the exchange runs BEHIND the C ABI (nd.NativeShard / nd.NativeComm:
+    nmfx_comm_init_rank + nmfx_mur_run_sharded, no torch on the data path); torch.distributed's collectives between the phase calls
+    remain as the rehearsal rig (NMFX_BENCH_BACKEND=gloo: several ranks on ONE GPU) and as the fall-back when RCCL cannot be bound
+    on every rank (NMFX_DIST_NATIVE=0 forces it).  `build(cls)` makes the shard.  Every rank takes the same branch: the choice is
+    all-reduced before any data-path collective.  Returns (shard, comm, name of the loop)."""
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device(f"cuda:{local_rank}")
+    want = on_gpu and os.environ.get("NMFX_DIST_NATIVE", "1") != "0"
+    if want:
+        ok = 1
+        try:
+            from nmf_amd.engine import Engine
+            Engine.comm_unique_id()                     # binds RCCL (dlopen) or raises
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"rank {rank}: RCCL behind the C ABI is not available ({e}); torch.distributed's collectives instead\n")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        want = int(flag.item()) == 1
+    if want:
+        shard = build(nd.NativeShard)
+        return shard, nd.NativeComm.create(shard), "native (nmfx_mur_run_sharded: RCCL behind the C ABI)"
+    shard = build(nd.DeviceShard)
+    return shard, nd.TorchComm(stage_through_host=not on_gpu), "torch.distributed collectives between the phase calls"
+
+
+def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
     """BASELINE.json's config 5 as it is meant: MUR Euclidean, V = 131072 x 16384 f32, k = 128, rows of V and W sharded over
     the `world` GPUs, one RCCL all-reduce of [W^T V | W^T W | objective] per iteration (nmf_amd.dist.run_iterations).  The same
     global matrix as other_configs' cfg5_on_1_gpu (device_planted draws any row range of it), so that
@@ -194,20 +221,25 @@ def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup
     h0 = np.abs(rs.randn(k, n))
     dev = torch.device(f"cuda:{local_rank}")
     on_gpu = dist.get_backend() == "nccl"
-    shard, err = None, None
-    try:
-        shard = nd.DeviceShard(None, k, w0, h0, local_rank, shape=(r1 - r0, n),
-                               fill=lambda e: device_planted(e, torch, m, n, k, 0, dev, rows=(r0, r1)))
-    except Exception as e:  # noqa: BLE001
-        err = e
-    # every rank learns whether EVERY rank is set up before the first data-path collective: a rank that failed alone
-    # (out of memory, ...) must not leave the others waiting in an all-reduce
-    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if on_gpu else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        if shard is not None:
-            shard.eng.close()
-        raise RuntimeError(f"config-5 shard could not be set up on every rank (rank {rank}: {err!r})")
+    shard, err, comm, loop = None, None, None, "?"
+    made = []
+
+    def build(cls):
+        try:
+            made.append(cls(None, k, w0, h0, local_rank, shape=(r1 - r0, n),
+                            fill=lambda e: device_planted(e, torch, m, n, k, 0, dev, rows=(r0, r1))))
+        except Exception as e:  # noqa: BLE001
+            made.append(e)
+        # every rank learns whether EVERY rank is set up before the first data-path collective (the communicator's own start-up
+        # included): a rank that failed alone (out of memory, ...) must not leave the others waiting
+        flag = torch.tensor([0 if isinstance(made[-1], Exception) else 1], dtype=torch.int32, device=dev if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if not isinstance(made[-1], Exception):
+                made[-1].eng.close()
+            raise RuntimeError(f"config-5 shard could not be set up on every rank (rank {rank}: {made[-1]!r})")
+        return made[-1]
+    shard, comm, loop = make_sharded(torch, dist, nd, rank, world, local_rank, build)
     try:
         def fence():
             shard.eng.synchronize()
@@ -215,8 +247,7 @@ def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup
             dist.barrier()
             torch.cuda.synchronize()
 
-        def run(first, count):
-            nd.run_iterations(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, first, count)
+        run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 2 * (warmup + steps) + 8)
 
         run(0, warmup + steps)                          # untimed rehearsal (lazy allocations, pools), then from the start again
         fence()
@@ -239,11 +270,12 @@ def cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank, steps=5, warmup
                                               "[W^T V | W^T W | objective] per iteration, |randn| start, objective every iteration",
                 "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
                 "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
-                "precision": shard.eng.precision(), "loop": "eager", "objective_first_last": [float(obj[0]), float(obj[-1])],
+                "precision": shard.eng.precision(), "loop": loop + " / " + run.mode, "objective_first_last": [float(obj[0]), float(obj[-1])],
                 "objective_decreasing": ok, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
                 "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
                 "all_reduce_bytes": float(shard.xf32.numel() * 4 if shard.merge_objective() else shard.xf32.numel() * 4 + 64),
+                "collectives_per_iteration": 1 if shard.merge_objective() else 2,
                 "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
     finally:
         shard.eng.close()
@@ -367,8 +399,47 @@ def other_configs(torch, dev, only=None):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torchrun: become the launcher.  Nothing has touched the GPU yet (torch is
+    not even imported), so starting `python -m torch.distributed.run ... bench.py <same arguments>` as a child process is safe; its
+    rank 0 writes the one JSON line to the stdout it inherits from us, and we leave with its exit code.  The rendezvous port is
+    probed here and bound by the child a moment later: if that one step loses the port (EADDRINUSE before any rank has started),
+    the launch -- not the benchmark -- is repeated with another port."""
+    import socket
+    import subprocess
+    import threading
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = 1
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} without WORLD_SIZE: launching torch.distributed.run (port {port})\n")
+        sys.stderr.flush()
+        child = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+        seen = []
+
+        def relay():
+            for ln in child.stderr:
+                seen.append(ln)
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        rc = child.wait()
+        th.join(timeout=10)
+        if rc == 0 or not any("EADDRINUSE" in ln or "address already in use" in ln.lower() for ln in seen):
+            break
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # the contract is ONE JSON line on stdout: RCCL prints a version banner to stdout when the
     # communicator comes up, so everything but the final line is sent to stderr at the fd level
     sys.stdout.flush()
@@ -378,8 +449,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: running with the world the launcher made\n")
     import torch
     import torch.distributed as dist
     limit_blas_threads(HOST_THREADS)              # (torch's OpenMP pool too, now that it is loaded)
@@ -407,9 +477,7 @@ def main():
                                     device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-        comm = nd.TorchComm(stage_through_host=(backend != "nccl"))
-    else:
-        comm = None
+    comm, loop = None, "library"
 
     r0, r1 = nd.row_range(m, rank, world)
     v_local = planted_matrix(m, n, k, seed=0, dtype=np.float32, rows=(r0, r1))
@@ -419,7 +487,7 @@ def main():
 
     NEVER = 10 ** 12          # min_iter: the stop rule is evaluated but cannot fire
     if sharded:
-        shard = nd.DeviceShard(v_local, k, w0, h0, local_rank)
+        shard, comm, loop = make_sharded(torch, dist, nd, rank, world, local_rank, lambda cls: cls(v_local, k, w0, h0, local_rank))
 
         run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5,
                         args.warmup + args.steps + args.profile_steps + 8)
@@ -451,13 +519,17 @@ def main():
     if sharded:
         run.ensure_graph(args.warmup)      # a capture still pending must not land in the timed region
     fence()
-    if sharded and run.mode == "hipgraph" and args.warmup >= 4:
+    if sharded and run.mode in ("hipgraph", "native-hipgraph") and args.warmup >= 4:
         # the replayed loop must have produced a sane history; if not, start over with the eager loop
         _, _, n_obj = eng.state()
         hist = eng.objectives(0, n_obj)
         if n_obj != args.warmup or not np.all(np.isfinite(hist)) or not hist[-1] < hist[0]:
             sys.stderr.write(f"rank {rank}: graphed loop gave a bad objective history, falling back to eager\n")
-            run.graph, run.mode, run.want_graph = None, "eager", False
+            if run.mode == "native-hipgraph":
+                eng.comm_set_graph(False)
+                run.mode = "native"
+            else:
+                run.graph, run.mode, run.want_graph = None, "eager", False
             eng.set_factors(w0, h0)
             run(0, args.warmup)
             fence()
@@ -565,7 +637,7 @@ def main():
         # config 5 proper (the 8-GPU config of BASELINE.json), sharded over this run's ranks: every rank takes part
         eng.close()
         try:
-            others = [cfg5_sharded(torch, dist, nd, comm, rank, world, local_rank)]
+            others = [cfg5_sharded(torch, dist, nd, rank, world, local_rank)]
         except Exception as e:  # noqa: BLE001  (reported in its slot, never hidden; a rank that failed alone would hang the others'
             others = [{"config": "cfg5", "error": f"{type(e).__name__}: {e}"}]          # collectives -- the driver's timeout ends that)
     if rank == 0 and world == 1 and not sharded and not args.no_others and (m, n, k) == (M, N, K):
@@ -598,12 +670,17 @@ def main():
             "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "preheat_iterations": args.preheat,
+            "strong_scaling_quoted_on": ("`value` = config 2 (V=16384x8192, k=64), the fixed matrix row-sharded over n_gpus ranks: a 0.22 ms "
+                                         "iteration on one GPU, so its curve is bound by launch + all-reduce latency, not bandwidth.  The "
+                                         "bandwidth-bound strong-scaling figure (north_star's >= 6x at 8 GPUs) is config 5 (V=131072x16384, "
+                                         "k=128): other_configs[config == 'cfg5'].iter_per_s of the N-GPU line over "
+                                         "other_configs[config == 'cfg5_on_1_gpu'] of the N = 1 line (same matrix)"),
             "dtype": "bf16 hi+lo split MFMA (3 terms), f32 accumulate, f64 objective" if precision == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
                                    "|randn| init, objective every iteration",
                        "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}",
-                       "loop": (run.mode if sharded else "library")},
+                       "loop": (loop + " / " + run.mode if sharded else "library")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,

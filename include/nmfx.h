@@ -41,7 +41,8 @@ enum {
     NMFX_E_HIP = -2,     /* HIP runtime error, no device                          */
     NMFX_E_NOTPD = -3,   /* Gram + rho I not positive definite (scipy LinAlgError, nmf/ao_admm.py:55) */
     NMFX_E_STATE = -4,   /* call sequence error (no V uploaded, no factors set)   */
-    NMFX_E_NOMEM = -5
+    NMFX_E_NOMEM = -5,
+    NMFX_E_RCCL = -6     /* RCCL not found (dlopen) or a collective / communicator call failed */
 };
 
 enum { NMFX_F32 = 0, NMFX_F64 = 1 };                 /* host dtype of V          */
@@ -181,8 +182,42 @@ int nmfx_shift_iteration_base(nmfx_handle_t h, int64_t delta);
  * rank's partial bit for bit; phase B adds them in rank order.  nmfx_exchange_sizes already includes the tail (64 ranks).
  * world = 0 switches back to the separate all-reduce of the f64 buffer.  NMFX_E_STATE when the split-bf16 epilogues are not in use. */
 int nmfx_set_exchange_rank(nmfx_handle_t h, int rank, int world);
-int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, void* dev_f64);
+/* n_f32 / n_f64: the sizes (elements) of the caller's allocations, checked against nmfx_exchange_sizes -- which grew in round 2
+ * (f64: 8 -> 8 + 4 * 64 doubles; f32: a tail of 256 floats): a caller that still allocates the old sizes gets NMFX_E_ARG instead of
+ * out-of-bounds device writes.  ABI change of version 300 (the two size arguments are new).                                */
+int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, int64_t n_f32, void* dev_f64, int64_t n_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
+
+/* ---- the exchange step behind the C ABI: RCCL over xGMI, one process per GPU -----------------------------------------------
+ * north_star: "shard rows of V and W across the 8 GPUs of one node with an RCCL all-reduce over xGMI of the k x k Gram W^T W and
+ * the k x n product W^T V each outer iteration" (nmf/mur.py:45 needs w.T @ x and w.T @ w over ALL rows).  RCCL is bound at run
+ * time (dlopen librccl.so.1; NMFX_RCCL_LIB overrides the name): NMFX_E_RCCL when it is missing or a call fails.
+ *   rank 0:     nmfx_comm_unique_id(id)            -> 128 bytes, handed to the other ranks by the launcher's own means
+ *   every rank: nmfx_comm_init_rank(h, id, rank, world)        (h = the handle of this rank's row shard; collective call)
+ *               nmfx_comm_negotiate(h)             -> all ranks agree on what fixes the sequence of collectives: the objective
+ *                                                     partial inside the f32 buffer (one all-reduce per MUR-eu iteration), the
+ *                                                     chunk unit, the arithmetic mode (NMFX_E_STATE if the modes differ)
+ *               nmfx_mur_run_sharded(...)          -> `count` outer iterations, each  phase A . all-reduce . phase B  queued on
+ *                                                     the handle's stream in ONE call (nmf/mur.py:119-131 for a row shard)
+ *               nmfx_mur_finish_sharded(...)       -> objective of the last pair + final stop test (as nmfx_mur_finish)
+ * nmfx_comm_all_reduce: in-place SUM over [first, first + count) of the f32 (which = 0) or f64 (which = 1) exchange buffer on the
+ * handle's stream -- the exchange of the other solvers' phase entry points (nmfx_aoadmm_phase_*, nmfx_admm_phase_*,
+ * nmfx_anls_phase_*).  nmfx_comm_all_min: MIN over the ranks of up to 64 host integers (blocking).
+ * nmfx_comm_set_graph(h, 1): nmfx_mur_run_sharded replays pairs of iterations (collectives included) as ONE hipGraph after the
+ * first eager pair; a capture that fails leaves the eager loop in charge.  NMFX_DIST_CHUNKS=n: phase A in n column chunks, each
+ * chunk's all-reduce on a side stream behind the next chunk's product.                                                       */
+int nmfx_comm_unique_id(void* id128);
+int nmfx_comm_init_rank(nmfx_handle_t h, const void* id128, int rank, int world);
+int nmfx_comm_destroy(nmfx_handle_t h);
+int nmfx_comm_info(nmfx_handle_t h, int* rank, int* world, int* merged, int* rccl_version);
+int nmfx_comm_negotiate(nmfx_handle_t h);
+int nmfx_comm_all_reduce(nmfx_handle_t h, int which, int64_t first, int64_t count);
+int nmfx_comm_all_min(nmfx_handle_t h, int64_t* vals, int n);
+int nmfx_comm_set_graph(nmfx_handle_t h, int enable);
+int nmfx_comm_graph_replays(nmfx_handle_t h, int64_t* replays);
+int nmfx_mur_run_sharded(nmfx_handle_t h, int distance, double lambda_w, double lambda_h, int64_t min_iter,
+                         double tol1, double tol2, int64_t first, int64_t count);
+int nmfx_mur_finish_sharded(nmfx_handle_t h, int distance, int64_t min_iter, double tol1, double tol2, int64_t iters_done);
 
 /* ---- initialisation: leading singular triplets of the uploaded V ------------------------
  * Replaces `numpy.linalg.svd(x, full_matrices=False)` in nmf/utils.py:50 for what NNDSVD uses of

@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMFX_LIB") or os.path.join(_HERE, "lib", "libnmfx.so")     # NMFX_LIB: an experiment build (A/B runs on one box)
 
-NMFX_OK, NMFX_E_ARG, NMFX_E_HIP, NMFX_E_NOTPD, NMFX_E_STATE, NMFX_E_NOMEM = 0, -1, -2, -3, -4, -5
+NMFX_OK, NMFX_E_ARG, NMFX_E_HIP, NMFX_E_NOTPD, NMFX_E_STATE, NMFX_E_NOMEM, NMFX_E_RCCL = 0, -1, -2, -3, -4, -5, -6
 F32, F64 = 0, 1
 EU, KL = 0, 1
 PROX = {"nn": 0, "l1n": 1, "l2n": 2, "l1inf": 3, "l1inf_transpose": 4}
@@ -67,7 +67,18 @@ SIGNATURES = {
     "nmfx_topk_svd": (_i32, [_vp, _i32, _i32, _dbl, _i32, C.c_uint64, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_dbl)]),
     "nmfx_reserve_objectives": (_i32, [_vp, _i64]),
     "nmfx_shift_iteration_base": (_i32, [_vp, _i64]),
-    "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _vp]),
+    "nmfx_set_exchange_buffers": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "nmfx_comm_unique_id": (_i32, [_vp]),
+    "nmfx_comm_init_rank": (_i32, [_vp, _vp, _i32, _i32]),
+    "nmfx_comm_destroy": (_i32, [_vp]),
+    "nmfx_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "nmfx_comm_negotiate": (_i32, [_vp]),
+    "nmfx_comm_all_reduce": (_i32, [_vp, _i32, _i64, _i64]),
+    "nmfx_comm_all_min": (_i32, [_vp, C.POINTER(_i64), _i32]),
+    "nmfx_comm_set_graph": (_i32, [_vp, _i32]),
+    "nmfx_comm_graph_replays": (_i32, [_vp, C.POINTER(_i64)]),
+    "nmfx_mur_run_sharded": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
+    "nmfx_mur_finish_sharded": (_i32, [_vp, _i32, _i64, _dbl, _dbl, _i64]),
     "nmfx_set_exchange_rank": (_i32, [_vp, _i32, _i32]),
     "nmfx_get_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nmfx_aoadmm_run": (_i32, [_vp, _i32, _i32, _dbl, _i32, _dbl, _i32, _i64, _dbl, _dbl, _i64, _i64]),

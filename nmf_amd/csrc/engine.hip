@@ -119,7 +119,7 @@ int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need) {
 
 extern "C" {
 
-int nmfx_version(void) { return 100; }
+int nmfx_version(void) { return 300; }      // round 3: nmfx_set_exchange_buffers takes sizes; nmfx_comm_*; k <= 256
 
 int nmfx_device_count(void) {
     int n = 0;
@@ -213,6 +213,7 @@ int nmfx_destroy(nmfx_handle_t E) {
     if (!E) return NMFX_OK;
     hipSetDevice(E->device);
     if (E->stream) hipStreamSynchronize(E->stream);
+    nmfx_comm_free(E);
     for (auto& t : E->prof_pending) { hipEventDestroy(std::get<1>(t)); hipEventDestroy(std::get<2>(t)); }
     void* bufs[] = {E->V, E->W[0], E->W[1], E->H, E->HHt, E->HHt_part, E->G_part, E->A_part, E->B_part,
                     E->obj_part, E->own_x ? (void*)E->xf32 : nullptr, E->own_x ? (void*)E->xf64 : nullptr,
@@ -365,6 +366,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->have_f = true;
     E->bf_ready = false;
     E->kl_h_iter = -2;
+    E->family = 0;
     E->himg_both = false;
     E->lazy_objective = false;
     E->anls_a_ready = false;
@@ -496,8 +498,15 @@ int nmfx_set_exchange_rank(nmfx_handle_t E, int rank, int world) {
     return NMFX_OK;
 }
 
-int nmfx_set_exchange_buffers(nmfx_handle_t E, void* f32, void* f64) {
+int nmfx_set_exchange_buffers(nmfx_handle_t E, void* f32, int64_t n_f32, void* f64, int64_t n_f64) {
     if (!E || !f32 || !f64) return NMFX_E_ARG;
+    int64_t need32, need64;
+    nmfx_exchange_sizes(E, &need32, &need64);
+    if (n_f32 < need32 || n_f64 < need64) {
+        E->err = "set_exchange_buffers: allocations smaller than nmfx_exchange_sizes (the buffers grew in round 2: f64 tail of 4 x 64 "
+                 "norm sums, f32 tail of 256 floats)";
+        return NMFX_E_ARG;
+    }
     NMFX_HIP(hipSetDevice(E->device));
     NMFX_HIP(hipStreamSynchronize(E->stream));
     if (E->own_x) { hipFree(E->xf32); hipFree(E->xf64); }
@@ -531,14 +540,19 @@ int nmfx_shift_iteration_base(nmfx_handle_t E, int64_t delta) {
 static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
     E->anls_a_ready = false;                           // (another solver's products overwrite A_part)
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    { int rc_ = nmfx_enter_family(E, 1); if (rc_) return rc_; }
     if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     return nmfx_ensure_obj_capacity(E, first + count + 2);
 }
 
+// (kl_h_iter: the H images and row-sum partials the KL H epilogue of iteration j leaves for the KL W phase of iteration j + 1 are
+// only good if NOTHING else has written H or those buffers in between -- every entry point of another solver, and the
+// Euclidean MUR phases, void them; ADVICE r2: only nmfx_set_factors did)
 int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
     if (E) E->himg_both = false;
     if (!E) return NMFX_E_ARG;
+    if (distance != NMFX_KL) E->kl_h_iter = -2;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     if (distance == NMFX_EU)
         return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_eu_phase_a_bf16(E, lambda_w, j)
@@ -564,6 +578,7 @@ int nmfx_mur_chunk_info(nmfx_handle_t E, int distance, int64_t* unit, int64_t* n
 int nmfx_mur_phase_a_head(nmfx_handle_t E, int distance, double lambda_w, int64_t j) {
     if (!E) return NMFX_E_ARG;
     E->himg_both = false;
+    E->kl_h_iter = -2;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     if (!mur_chunkable(E, distance)) { E->err = "phase_a_head: Euclidean loss on the split-bf16 path only (nmfx_mur_chunk_info)"; return NMFX_E_ARG; }
     return nmfx_mur_eu_phase_a_head_bf16(E, lambda_w, j);
@@ -579,6 +594,7 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
                      double tol2, int64_t j) {
     if (E) E->himg_both = false;
     if (!E) return NMFX_E_ARG;
+    if (distance != NMFX_KL) E->kl_h_iter = -2;
     int rc = check_ready(E, j, 1); if (rc) return rc;
     E->wsel = (int)((j + 1) & 1);
     E->w_in_place = false;

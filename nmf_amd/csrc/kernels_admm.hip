@@ -197,7 +197,7 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
 // argument checks, allocations and (for the first iteration) the start state w_aux = w, h_aux = h (admm.py:27-28)
 // with the objective partials of the initial pair (admm.py:289)
 static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count) {
-    if (E) E->anls_a_ready = false;
+    if (E) E->anls_a_ready = false; E->kl_h_iter = -2;
     if (!E) return NMFX_E_ARG;
     E->himg_both = false;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
@@ -209,6 +209,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
     if (first < 0 || count < 0 || !(rho >= 0.0)) { E->err = "negative iteration range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_enter_family(E, 3))) return rc;
     if ((rc = admm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
     if ((prox_w == NMFX_PROX_L2N && !E->Pw) || (prox_h == NMFX_PROX_L2N && !E->Ph)) {

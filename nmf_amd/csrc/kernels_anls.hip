@@ -866,6 +866,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0 || lam < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
+    { int rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
     NMFX_HIP(hipSetDevice(E->device));
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
@@ -879,7 +880,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
 // ---- row-sharded form: objective partial -> [all-reduce f64] -> phase_w -> [all-reduce f32]
 // -> phase_h ----
 extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
-    if (E) E->himg_both = false;
+    if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, 0.0); if (rc) return rc;
     if (j == 0 && (rc = anls_objective(E))) return rc;   // obj[0] partials
     return nmfx_launch_obj_reduce(E);
@@ -887,13 +888,13 @@ extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
 
 extern "C" int nmfx_anls_phase_w(nmfx_handle_t E, double lambda_w, int64_t min_iter, double tol1, double tol2,
                                  int64_t j) {
-    if (E) E->himg_both = false;
+    if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, lambda_w); if (rc) return rc;
     return anls_w_and_products(E, lambda_w, min_iter, tol1, tol2, j);
 }
 
 extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
-    if (E) E->himg_both = false;
+    if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, lambda_h); if (rc) return rc;
     return anls_h(E, lambda_h);
 }
@@ -907,12 +908,13 @@ extern "C" int nmfx_anls_set_distance(nmfx_handle_t E, int distance) {
 
 extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, int64_t min_iter, double tol1,
                              double tol2, int64_t first, int64_t count) {
-    if (E) E->himg_both = false;
+    if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (first < 0 || count < 0 || lambda_w < 0 || lambda_h < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_enter_family(E, 4))) return rc;
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
         NMFX_HIP(hipMemsetAsync(E->Asum, 0, (size_t)E->mp * E->kp * sizeof(float), E->stream));

@@ -1612,8 +1612,9 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
         E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
-    E->anls_a_ready = false;
+    E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
+    if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, first + count + 1))) return rc;
@@ -1639,8 +1640,9 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
-    E->anls_a_ready = false;
+    E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
+    if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;
     if ((rc = nmfx_ensure_obj_capacity(E, j + 3))) return rc;

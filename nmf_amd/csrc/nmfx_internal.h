@@ -79,6 +79,7 @@ struct nmfx_engine {
     float* xf32 = nullptr;         // exchange: [kp*np | kp*kp | kp]
     double* xf64 = nullptr;        // exchange: [8] = objective partial, 4 inner-loop norm sums, 3 spare
     bool own_x = true;
+    struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
     DevState* state = nullptr;
@@ -122,6 +123,7 @@ struct nmfx_engine {
     int anls_dist = NMFX_EU;       // objective ANLS reports (anls.py:108,118): the iterates are least-squares either way
     bool anls_a_ready = false;    // ANLS: A_part / H H^T slabs of the CURRENT (W, H) are valid (produced by the fused objective pass)
     int wsel = 0;                  // W buffer holding the current iterate
+    int family = 0;                // solver family that has run since nmfx_set_factors (0 none, 1 MUR eu/kl, 2 AO-ADMM, 3 ADMM, 4 ANLS): nmfx_enter_family
     bool w_in_place = false;       // solver updates W[0] in place (all but MUR, which ping-pongs)
     // profiling
     bool prof = false;
@@ -183,7 +185,20 @@ int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nob
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
+// One solver family per set of factors: the families keep different device state next to W and H (MUR: W ping-pong and bf16 images of
+// both factors; AO-ADMM / ADMM: duals and auxiliaries; ANLS: warm-start supports), and a family that starts in the middle of another's
+// run would read leftovers.  A second family on the same handle needs nmfx_get_factors -> nmfx_set_factors first (NMFX_E_STATE otherwise).
+inline int nmfx_enter_family(nmfx_engine* E, int fam) {
+    if (E->family && E->family != fam) {
+        E->err = "another solver has run on this handle since nmfx_set_factors: read the factors back and set them again "
+                 "(nmfx_get_factors, nmfx_set_factors) before a different solver continues from them";
+        return NMFX_E_STATE;
+    }
+    E->family = fam;
+    return NMFX_OK;
+}
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
+void nmfx_comm_free(nmfx_engine* E);      // comm.hip
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
 
 // AO-ADMM / ADMM building blocks (kernels_aoadmm.hip)

@@ -114,8 +114,10 @@ class DeviceShard:
         self.xf32 = torch.zeros(n32, dtype=torch.float32, device=f"cuda:{device}")
         self.xf64 = torch.zeros(n64, dtype=torch.float64, device=f"cuda:{device}")
         torch.cuda.synchronize()
-        self._merged = None
-        self.eng.set_exchange_buffers(self.xf32.data_ptr(), self.xf64.data_ptr())
+        self._merged = False          # negotiate(comm) settles these two with the other ranks
+        self._chunk_unit = 0
+        self._negotiated = None
+        self.eng.set_exchange_buffers(self.xf32.data_ptr(), n32, self.xf64.data_ptr(), n64)
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
         if v_local is not None:
             self.eng.upload_v(v_local)
@@ -126,21 +128,45 @@ class DeviceShard:
     def buffers(self):
         return self.xf32, self.xf64
 
+    def negotiate(self, comm):
+        """Agree with the other ranks of `comm` on everything that fixes the SEQUENCE of collectives: whether the
+        objective partial travels inside the f32 buffer (one all-reduce per MUR-eu iteration instead of two), the column unit of
+        the chunked exchange, and the arithmetic mode.  An engine falls back to the exact-f32 kernels on its own when its GPU
+        is short of memory for the tile-major copies (nmfx_get_note): such a rank would otherwise send one collective more
+        than its peers, or chunks of another size -- a hang or mis-paired reductions.  Every rank offers what IT can do, the
+        minimum over the group wins, and ranks whose arithmetic modes differ fail loudly.  Once per (shard, group)."""
+        key = id(comm)
+        if self._negotiated == key:
+            return
+        import os
+        torch = self.torch
+        rank, world = getattr(comm, "rank", 0), getattr(comm, "world", 1)
+        bf16 = 1 if self.eng.precision() == "bf16" else 0
+        merge = 0
+        if os.environ.get("NMFX_DIST_MERGE", "1") != "0" and bf16 and world <= 64:
+            merge = 1
+        unit = int(self.eng.mur_chunk_info(0)[0] or 0)
+        offer = [merge, unit, bf16, -bf16]              # MIN over ranks: [all can merge, smallest unit, all bf16, -(any bf16)]
+        if world > 1:
+            staged = getattr(comm, "stage", False) or comm.dist.get_backend(comm.group) != "nccl"
+            t = torch.tensor(offer, dtype=torch.int64, device="cpu" if staged else self.xf32.device)
+            comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MIN, group=comm.group)
+            offer = [int(x) for x in t.tolist()]
+        if offer[2] != -offer[3]:
+            raise RuntimeError("row-sharded run: the ranks run different arithmetic modes (a rank fell back to the exact-f32 kernels: "
+                               f"{self.eng.note() or 'NMFX_PRECISION differs'}); set NMFX_PRECISION=f32 on every rank or free its memory")
+        self._merged = bool(offer[0])
+        self._chunk_unit = offer[1]
+        if self._merged:
+            self.eng.set_exchange_rank(rank, world)     # (cannot fail: every rank has just said it runs the split-bf16 epilogues)
+        else:
+            self.eng.set_exchange_rank(0, 0)
+        self._negotiated = key
+
     def merge_objective(self):
-        """True once the engine carries this rank's objective partial inside the f32 exchange buffer (MUR, Euclidean loss,
-        split-bf16 epilogues; NMFX_DIST_MERGE=0 keeps the separate f64 all-reduce).  Decided once, identically on every rank:
-        it depends on the padded rank and the arithmetic mode only."""
-        if self._merged is None:
-            import os
-            import torch.distributed as tdist
-            self._merged = False
-            if os.environ.get("NMFX_DIST_MERGE", "1") != "0" and tdist.is_available() and tdist.is_initialized():
-                try:
-                    self.eng.set_exchange_rank(tdist.get_rank(), tdist.get_world_size())
-                    self._merged = True
-                except Exception:       # noqa: BLE001  (NmfxError: exact-f32 epilogues or more than 64 ranks)
-                    self._merged = False
-        return self._merged
+        """True when the objective partial of MUR-eu travels inside the f32 exchange buffer (split-bf16 epilogues on EVERY rank, at
+        most 64 ranks; NMFX_DIST_MERGE=0 keeps the separate f64 all-reduce).  Settled by negotiate()."""
+        return bool(self._merged)
 
     def phase_a(self, dist_code, lambda_w, j):
         self.eng.mur_phase_a(dist_code, lambda_w, j)
@@ -152,6 +178,7 @@ class DeviceShard:
         """Column ranges [(c0, c1, first element, end element of the f32 exchange buffer)] of a phase A in `chunks` pieces,
         or None where the engine has no chunked phase A for this loss / arithmetic or the matrix is too narrow."""
         unit, npad, kpad = self.eng.mur_chunk_info(dist_code)
+        unit = min(unit, self._chunk_unit) if unit else 0           # (negotiate(): 0 unless every rank has the chunked phase A)
         if not unit or chunks < 2:
             return None
         step = max(512, -(-npad // chunks) // unit * unit)
@@ -252,6 +279,90 @@ class DeviceShard:
         self.eng.close()
 
 
+class ExRef:
+    """A range of one of the engine's exchange buffers (which = 0: f32, 1: f64) -- what NativeComm reduces.  Slices like the torch
+    tensors the torch path hands around (`x64[:8]`, `x32[e0:e1]`)."""
+
+    def __init__(self, which, first, count):
+        self.which, self.first, self.count = which, first, count
+
+    def __getitem__(self, sl):
+        a, b, step = sl.indices(self.count)
+        if step != 1:
+            raise ValueError("contiguous ranges only")
+        return ExRef(self.which, self.first + a, max(0, b - a))
+
+    def numel(self):
+        return self.count
+
+
+class NativeShard(DeviceShard):
+    """One row shard whose exchange runs BEHIND the C ABI (comm.hip): library-owned exchange buffers, an RCCL communicator on
+    the engine's own stream, the sharded MUR loop as one C call (nmfx_mur_run_sharded) -- no torch tensor, stream or collective on
+    the data path.  torch.distributed is only the launcher's means of handing rank 0's 128-byte RCCL id to the other ranks
+    (`NativeComm.create`)."""
+
+    def __init__(self, v_local, k, w0_local, h0, device, shape=None, fill=None):
+        from .engine import Engine
+        self.torch = None
+        rows, n = v_local.shape if v_local is not None else shape
+        self.eng = Engine(rows, n, k, device=device)
+        n32, n64 = self.eng.exchange_sizes()
+        self.xf32, self.xf64 = ExRef(0, 0, n32), ExRef(1, 0, n64)
+        self._merged, self._chunk_unit, self._negotiated = False, 0, None
+        if v_local is not None:
+            self.eng.upload_v(v_local)
+        else:
+            fill(self.eng)
+        self.eng.set_factors(w0_local, h0)
+
+    def negotiate(self, comm):
+        if self._negotiated == id(comm):
+            return
+        self.eng.comm_negotiate()            # NmfxError (NMFX_E_STATE) when the ranks' arithmetic modes differ
+        self._merged = self.eng.comm_info()[2]
+        self._chunk_unit = int(self.eng.mur_chunk_info(0)[0] or 0)       # (the library keeps the negotiated unit itself)
+        self._negotiated = id(comm)
+
+
+class NativeComm:
+    """The exchange of a NativeShard: nmfx_comm_* (RCCL through the C ABI) on the engine's stream."""
+    stage = False
+
+    def __init__(self, shard, rank, world, uid):
+        self.eng, self.rank, self.world = shard.eng, rank, world
+        self.eng.comm_init_rank(uid, rank, world)
+
+    @classmethod
+    def create(cls, shard, group=None):
+        """Collective over the torch.distributed job: rank 0 draws the RCCL id, everybody receives it, every rank joins."""
+        import torch.distributed as tdist
+        rank, world = tdist.get_rank(group), tdist.get_world_size(group)
+        box = [shard.eng.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            tdist.broadcast_object_list(box, src=0, group=group)
+        return cls(shard, rank, world, box[0])
+
+    def all_reduce(self, *refs):
+        for r in refs:
+            self.eng.comm_all_reduce(r.which, r.first, r.count)
+
+    def all_reduce_async(self, ref):
+        self.all_reduce(ref)
+        return None
+
+    def barrier(self):
+        self.eng.comm_all_min([0])
+
+    def close(self):
+        self.eng.comm_destroy()
+
+
+def _negotiate(shard, comm):
+    if comm is not None and getattr(shard, "negotiate", None) is not None:
+        shard.negotiate(comm)
+
+
 def _mur_buffers(shard, dist_code=None):
     """The exchange of one MUR iteration.  A device shard with the Euclidean loss carries its objective partial inside the f32
     buffer (nmfx_set_exchange_rank: every rank's partial as exact 16-bit digits in its own slot), so ONE all-reduce
@@ -275,6 +386,7 @@ def _exchange_chunks():
 
 def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count, chunks=None):
     """Queue `count` sharded outer iterations (no host sync)."""
+    _negotiate(shard, comm)
     bufs = _mur_buffers(shard, dist_code)
     chunks = _exchange_chunks() if chunks is None else chunks
     ranges = None
@@ -319,6 +431,7 @@ class GraphedIterations:
         self.shard, self.torch = shard, torch
         self.args = (dist_code, lambda_w, lambda_h, min_iter, tol1, tol2)
         self.graph = torch.cuda.CUDAGraph()
+        _negotiate(shard, comm)
         bufs = _mur_buffers(shard, dist_code)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -356,6 +469,16 @@ class Runner:
         import os
         self.shard, self.comm = shard, comm
         self.args = (dist_code, lambda_w, lambda_h, min_iter, tol1, tol2)
+        self.native = isinstance(comm, NativeComm)
+        if self.native:
+            # the whole loop is one C call per batch (nmfx_mur_run_sharded); hipGraph replay is the library's business too
+            if graph is None:
+                graph = os.environ.get("NMFX_DIST_GRAPH", "0") == "1"
+            shard.negotiate(comm)
+            shard.eng.comm_set_graph(bool(graph) and max_iter >= 4)
+            self.want_graph, self.graph = False, None
+            self.mode = "native-hipgraph" if (graph and max_iter >= 4) else "native"
+            return
         if graph is None:
             # opt-in: capturing RCCL collectives of a multi-rank world cannot be rehearsed on a one-GPU
             # box, and the replay only removes launch gaps (5 % at 2048 rows per rank) -- the eager loop
@@ -370,6 +493,11 @@ class Runner:
 
     def eager(self, first, count):
         d, lw, lh, mi, t1, t2 = self.args
+        if self.native:
+            self.shard.eng.comm_set_graph(False)
+            self.shard.eng.mur_run_sharded(d, lw, lh, mi, t1, t2, first, count)
+            self.shard.eng.comm_set_graph(self.mode == "native-hipgraph")
+            return
         run_iterations(self.shard, self.comm, d, lw, lh, mi, t1, t2, first, count)
 
     def _capture(self):
@@ -389,6 +517,10 @@ class Runner:
             self._capture()
 
     def __call__(self, first, count):
+        if self.native:
+            d, lw, lh, mi, t1, t2 = self.args
+            self.shard.eng.mur_run_sharded(d, lw, lh, mi, t1, t2, first, count)
+            return
         if self.want_graph and first < 2:
             head = min(count, 2 - first)
             self.eager(first, head)
@@ -410,6 +542,9 @@ class Runner:
 
 
 def finish(shard, comm, dist_code, min_iter, tol1, tol2, done):
+    if isinstance(comm, NativeComm):
+        shard.eng.mur_finish_sharded(dist_code, min_iter, tol1, tol2, done)
+        return
     shard.finish_a(dist_code, done)
     comm.all_reduce(_mur_buffers(shard)[1])
     shard.finish_b(min_iter, tol1, tol2, done)
@@ -451,6 +586,7 @@ def mur_sharded(shard, comm, *, distance_type='eu', min_iter=100, max_iter=10000
 def _sharded_loop(shard, comm, queue, finish_run, *, max_iter, tol1, tol2, batch, experiment):
     """The reference's outer loop shape (obj_history, `[i]: objective` lines, stop bookkeeping)
     around `queue(first, count)`, which only queues device work and collectives."""
+    _negotiate(shard, comm)
     if max_iter <= 0:
         raise UnboundLocalError("local variable 'i' referenced before assignment")
     digits = utils.tol_digits(tol1, tol2)
@@ -671,15 +807,18 @@ def init_process_group(backend=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        # NMFX_DIST_INIT_METHOD: a torch.distributed init_method URL (e.g. file:///shared/path) instead of the MASTER_* variables
+        method = os.environ.get("NMFX_DIST_INIT_METHOD") or None
+        if method is None:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", init_method=method, rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, init_method=method, rank=rank, world_size=world)
     return dist.get_rank(), dist.get_world_size(), local
 
 
@@ -753,8 +892,16 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
             a[...] = t.cpu().numpy()
     else:
         w0, h0 = utils.initial_factors(_Shape(m, n), k, nndsvd_init, uniform=(method == 'anls'))
-    make = shard_factory or (lambda v, kk, w, h: DeviceShard(v, kk, w, h, dev.index or 0))
-    shard = make(v_local, k, w0[r0:r1], h0)
+    # on RCCL the exchange runs behind the C ABI (NativeShard / NativeComm: the engine's own communicator and stream, the MUR loop as
+    # one C call); NMFX_DIST_NATIVE=0 keeps torch.distributed's collectives on torch's stream between the phase calls
+    import os
+    native = shard_factory is None and on_gpu and os.environ.get("NMFX_DIST_NATIVE", "1") != "0"
+    if native:
+        shard = NativeShard(v_local, k, w0[r0:r1], h0, dev.index or 0)
+        comm = NativeComm.create(shard)
+    else:
+        make = shard_factory or (lambda v, kk, w, h: DeviceShard(v, kk, w, h, dev.index or 0))
+        shard = make(v_local, k, w0[r0:r1], h0)
     run_kw = {key: val for key, val in kw.items()
               if key not in ('nndsvd_init', 'use_fcnnls')}
     try:

@@ -60,6 +60,11 @@ class Engine:
     def precision(self):
         return "bf16" if self.lib.nmfx_get_precision(self.h) == 1 else "f32"
 
+    def note(self):
+        """What nmfx_create had to say (e.g. the fall back to the exact-f32 kernels for lack of memory), or ''."""
+        n = self.lib.nmfx_get_note(self.h)
+        return n.decode() if n else ""
+
     def reset_stream(self):
         self._ck(self.lib.nmfx_reset_stream(self.h))
 
@@ -297,8 +302,54 @@ class Engine:
         self._ck(self.lib.nmfx_exchange_sizes(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def set_exchange_buffers(self, f32_ptr, f64_ptr):
-        self._ck(self.lib.nmfx_set_exchange_buffers(self.h, C.c_void_p(f32_ptr), C.c_void_p(f64_ptr)))
+    def set_exchange_buffers(self, f32_ptr, n_f32, f64_ptr, n_f64):
+        self._ck(self.lib.nmfx_set_exchange_buffers(self.h, C.c_void_p(f32_ptr), int(n_f32), C.c_void_p(f64_ptr), int(n_f64)))
+
+    # -- the exchange step behind the C ABI (RCCL, comm.hip) -------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        L.check(L.load().nmfx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, uid, rank, world):
+        self._ck(self.lib.nmfx_comm_init_rank(self.h, C.c_char_p(bytes(uid)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.nmfx_comm_destroy(self.h))
+
+    def comm_info(self):
+        """(rank, world, objective partial merged into the f32 exchange, RCCL version code)"""
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.nmfx_comm_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, bool(c.value), d.value
+
+    def comm_negotiate(self):
+        self._ck(self.lib.nmfx_comm_negotiate(self.h))
+
+    def comm_all_reduce(self, which, first, count):
+        self._ck(self.lib.nmfx_comm_all_reduce(self.h, int(which), int(first), int(count)))
+
+    def comm_all_min(self, values):
+        arr = (C.c_int64 * len(values))(*[int(v) for v in values])
+        self._ck(self.lib.nmfx_comm_all_min(self.h, arr, len(values)))
+        return list(arr)
+
+    def comm_set_graph(self, enable):
+        self._ck(self.lib.nmfx_comm_set_graph(self.h, 1 if enable else 0))
+
+    def comm_graph_replays(self):
+        n = C.c_int64()
+        self._ck(self.lib.nmfx_comm_graph_replays(self.h, C.byref(n)))
+        return n.value
+
+    def mur_run_sharded(self, dist, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
+        self._ck(self.lib.nmfx_mur_run_sharded(self.h, int(dist), float(lambda_w), float(lambda_h), int(min_iter), float(tol1),
+                                               float(tol2), int(first), int(count)))
+
+    def mur_finish_sharded(self, dist, min_iter, tol1, tol2, done):
+        self._ck(self.lib.nmfx_mur_finish_sharded(self.h, int(dist), int(min_iter), float(tol1), float(tol2), int(done)))
 
     # -- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

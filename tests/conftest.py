@@ -75,21 +75,17 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(worker, args, nprocs, tries=4):
-    """torch.multiprocessing.spawn of `worker(rank, *args)` with a fresh rendezvous port in args[1] (pass None there).
-    A port that was free when probed can be gone by the time rank 0 listens on it -- an outgoing connection of an earlier
-    test's process group, a socket in TIME_WAIT -- and the rendezvous then dies with EADDRINUSE before any rank has done
-    anything: that one failure is retried with another port (seen once in ~2000 spawns on the GPU box)."""
+def spawn_ranks(worker, args, nprocs):
+    """torch.multiprocessing.spawn of `worker(rank, *args)`; args[1] (pass None there) becomes the rendezvous: a `file://`
+    init_method in a fresh temporary directory.  (Round 2 probed a free TCP port in the parent and let rank 0 bind it later;
+    one run in ~2000 lost the port in between and died with EADDRINUSE.  A FileStore has no such window.)"""
+    import shutil
+    import tempfile
     import torch.multiprocessing as mp
-    last = None
-    for _ in range(tries):
+    d = tempfile.mkdtemp(prefix="nmfx_rdzv_")
+    try:
         a = list(args)
-        a[1] = free_port()
-        try:
-            mp.spawn(worker, args=tuple(a), nprocs=nprocs, join=True)
-            return
-        except Exception as e:  # noqa: BLE001
-            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e).lower():
-                raise
-            last = e
-    raise last
+        a[1] = "file://" + os.path.join(d, "store")
+        mp.spawn(worker, args=tuple(a), nprocs=nprocs, join=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

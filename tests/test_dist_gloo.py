@@ -23,13 +23,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, rdzv, case, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from host_shard import HostShard
     from nmf_amd import dist as nd
     from oracle import nmf_ref as R
@@ -102,13 +101,12 @@ def test_row_range_partitions_any_shape():
 
 
 # ---- AO-ADMM and ANLS over row shards ---------------------------------------
-def _solver_worker(rank, world, port, case, outdir):
+def _solver_worker(rank, world, rdzv, case, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from host_shard import HostShard
     from nmf_amd import dist as nd
     v, w0, h0 = _solver_inputs(case)
@@ -170,12 +168,11 @@ def test_sharded_aoadmm_anls_equal_single_process_oracle(case, tmp_path):
 
 
 # ---- the round-by-round exchange of the W sub-problem, ADMM, and the SPMD entry point -------------------------------
-def _generic_worker(rank, world, port, case, outdir):
+def _generic_worker(rank, world, rdzv, case, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
     os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
     from host_shard import HostShard
     from nmf_amd import dist as nd
@@ -186,7 +183,7 @@ def _generic_worker(rank, world, port, case, outdir):
         res = nd.factorize(v, case["k"], method=case["solver"], backend="gloo", shard_factory=HostShard, **case["kw"])
         w_local = None
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
         r0, r1 = nd.row_range(case["m"], rank, world)
         shard = HostShard(v[r0:r1], case["k"], w0[r0:r1], h0)
         run = {"ao_admm": nd.aoadmm_sharded, "admm": nd.admm_sharded}[case["solver"]]

@@ -24,6 +24,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _join(backend, rdzv, rank, world):
+    """Process group + (shard class, comm factory) for a backend name: "nccl" (RCCL through torch.distributed), "gloo" (two ranks
+    on one GPU, staged through the host), "native" (RCCL behind the C ABI -- nmfx_comm_*; torch.distributed, on gloo, only
+    carries the 128-byte id)."""
+    import torch.distributed as dist
+    from nmf_amd import dist as nd
+    dist.init_process_group("gloo" if backend == "native" else backend, init_method=rdzv, rank=rank, world_size=world)
+    if backend == "native":
+        return nd.NativeShard, (lambda shard: nd.NativeComm.create(shard))
+    return nd.DeviceShard, (lambda shard: nd.TorchComm(stage_through_host=(backend == "gloo")))
+
+
 def _case(k=12):
     from oracle import nmf_ref as R
     m, n = 700, 330
@@ -43,33 +55,43 @@ def _case_wide(k):
 KW = dict(distance_type="eu", min_iter=14, max_iter=14, lambda_w=0.01, lambda_h=0.02)
 
 
-def _worker(rank, world, port, backend, outdir, k=12, wide=False):
+def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    Shard, make_comm = _join(backend, rdzv, rank, world)
     from nmf_amd import dist as nd
+    if rank == 1 and os.environ.get("NMFX_TEST_RANK1_ENV"):          # one rank in another mode (negotiate() must settle it)
+        key, val = os.environ["NMFX_TEST_RANK1_ENV"].split("=")
+        os.environ[key] = val
     m, n, k, v, w0, h0 = (_case_wide if wide else _case)(k)
     r0, r1 = nd.row_range(m, rank, world)
-    shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
-    comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
+    shard = Shard(v[r0:r1], k, w0[r0:r1], h0, 0)
+    comm = make_comm(shard)
+    try:
+        shard.negotiate(comm)
+    except RuntimeError as e:
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), refused=str(e))
+        shard.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     pieces = shard.chunk_ranges(0, nd._exchange_chunks())
     res = nd.mur_sharded(shard, comm, batch=5, **KW)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
-             pieces=len(pieces) if pieces else 1)
+             pieces=len(pieces) if pieces else 1, merged=int(shard.merge_objective()))
     shard.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("k", [12, 40, 100])     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
 def test_sharded_device_path(world, backend, k, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
@@ -88,7 +110,7 @@ def test_sharded_device_path(world, backend, k, tmp_path):
 
 
 @pytest.mark.parametrize("k", [40, 100])
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
 def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, tmp_path, monkeypatch):
     """NMFX_DIST_CHUNKS=2: phase A in two column chunks (nmfx_mur_phase_a_head / _cols), each chunk's range of the exchange
     buffer reduced on its own -- over RCCL asynchronously, behind the product of the next chunk.  Same bars as the
@@ -111,6 +133,31 @@ def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, tmp_path
         np.testing.assert_array_equal(p["h"], h)
 
 
+def test_ranks_agree_on_the_collective_sequence_before_the_first_exchange(tmp_path, monkeypatch):
+    """every rank used to pick its collective sequence from its OWN engine state (merged objective: one all-reduce
+    instead of two; chunk unit) -- a rank that had silently fallen back to the exact-f32 kernels would have sent another
+    sequence than its peers.  negotiate(): a rank that cannot merge makes every rank keep the separate f64 exchange (same iterates
+    as the all-merged run); ranks in different arithmetic modes are refused on every rank, before any exchange."""
+    from oracle import nmf_ref as R
+    d = tmp_path / "merge"
+    d.mkdir()
+    monkeypatch.setenv("NMFX_TEST_RANK1_ENV", "NMFX_DIST_MERGE=0")
+    spawn_ranks(_worker, (2, None, "gloo", str(d), 40), 2)
+    parts = [np.load(d / f"rank{r}.npz") for r in range(2)]
+    assert [int(p["merged"]) for p in parts] == [0, 0]
+    m, n, k, v, w0, h0 = _case(40)
+    ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
+    w = np.concatenate([p["w"] for p in parts])
+    assert np.linalg.norm(w @ parts[0]["h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+    np.testing.assert_array_equal(parts[0]["h"], parts[1]["h"])
+    d = tmp_path / "precision"
+    d.mkdir()
+    monkeypatch.setenv("NMFX_TEST_RANK1_ENV", "NMFX_PRECISION=f32")
+    spawn_ranks(_worker, (2, None, "gloo", str(d), 40), 2)
+    for r in range(2):
+        assert "different arithmetic modes" in str(np.load(d / f"rank{r}.npz")["refused"])
+
+
 def test_sharded_device_path_with_the_separate_objective_exchange(tmp_path, monkeypatch):
     """NMFX_DIST_MERGE=0: the f64 objective partial in its own all-reduce (the only form for the exact-f32 epilogues) instead of
     inside the f32 buffer -- the same iterates bit for bit, the same stop index."""
@@ -129,27 +176,26 @@ def test_sharded_device_path_with_the_separate_objective_exchange(tmp_path, monk
         np.testing.assert_allclose(outs["1"][r]["obj"], outs["0"][r]["obj"], rtol=1e-14)
 
 
-def _graph_worker(rank, world, port, outdir):
+def _graph_worker(rank, world, rdzv, outdir, backend="nccl", k=12):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    Shard, make_comm = _join(backend, rdzv, rank, world)
     from nmf_amd import dist as nd
-    m, n, k, v, w0, h0 = _case()
+    m, n, k, v, w0, h0 = _case(k)
     out = {}
     # a run that the stop rule ends in the middle of a replayed pair, and one that exhausts max_iter
     for name, kw in (("stop", dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-5, tol2=2e-1)),
                      ("full", dict(distance_type="eu", min_iter=99, max_iter=37)),
                      ("kl", dict(distance_type="kl", min_iter=99, max_iter=21, lambda_w=0.01))):
         for graph in (False, True):
-            shard = nd.DeviceShard(v, k, w0, h0, 0)
-            comm = nd.TorchComm()
+            shard = Shard(v, k, w0, h0, 0)
+            comm = make_comm(shard)
             runner_modes = []
             orig = nd.Runner.__call__
 
@@ -165,20 +211,27 @@ def _graph_worker(rank, world, port, outdir):
             out[tag + "_w"], out[tag + "_h"] = res.w, res.h
             out[tag + "_i"], out[tag + "_obj"] = res.i, np.asarray(res.obj_history)
             out[tag + "_mode"] = np.array(runner_modes[-1])
+            out[tag + "_replays"] = shard.eng.comm_graph_replays() if backend == "native" else -1
             shard.close()
     np.savez(os.path.join(outdir, "graph.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_graphed_loop_equals_eager_loop(tmp_path):
+@pytest.mark.parametrize("backend,k", [("nccl", 12), ("native", 12), ("native", 40)])
+def test_graphed_loop_equals_eager_loop(backend, k, tmp_path):
     """hipGraph replays of the sharded iteration (RCCL all-reduce captured inside) give the very
-    same iterates, objective history and stop index as the Python-driven loop."""
+    same iterates, objective history and stop index as the eager loop -- captured by torch around the phase calls ("nccl") or
+    by the library itself inside nmfx_mur_run_sharded ("native": the whole loop is one C call, no torch on the data path)."""
     import torch.multiprocessing as mp
-    spawn_ranks(_graph_worker, (1, None, str(tmp_path)), 1)
+    spawn_ranks(_graph_worker, (1, None, str(tmp_path), backend, k), 1)
     z = np.load(tmp_path / "graph.npz")
     for name in ("stop", "full", "kl"):
-        assert str(z[f"{name}_graph_mode"]) == "hipgraph" and str(z[f"{name}_eager_mode"]) == "eager"
+        if backend == "native":
+            assert str(z[f"{name}_graph_mode"]) == "native-hipgraph" and str(z[f"{name}_eager_mode"]) == "native"
+            assert int(z[f"{name}_graph_replays"]) > 0 and int(z[f"{name}_eager_replays"]) == 0
+        else:
+            assert str(z[f"{name}_graph_mode"]) == "hipgraph" and str(z[f"{name}_eager_mode"]) == "eager"
         assert int(z[f"{name}_graph_i"]) == int(z[f"{name}_eager_i"])
         np.testing.assert_array_equal(z[f"{name}_graph_obj"], z[f"{name}_eager_obj"])
         np.testing.assert_array_equal(z[f"{name}_graph_w"], z[f"{name}_eager_w"])
@@ -219,22 +272,21 @@ def _solver_case(solver):
     return m, n, k, v, w0, h0, kw
 
 
-def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
+def _solver_gpu_worker(rank, world, rdzv, backend, solver, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    Shard, make_comm = _join(backend, rdzv, rank, world)
     from nmf_amd import dist as nd
     m, n, k, v, w0, h0, kw = _solver_case(solver)
     r0, r1 = nd.row_range(m, rank, world)
-    shard = nd.DeviceShard(v[r0:r1], k, w0[r0:r1], h0, 0)
-    comm = nd.TorchComm(stage_through_host=(backend == "gloo"))
+    shard = Shard(v[r0:r1], k, w0[r0:r1], h0, 0)
+    comm = make_comm(shard)
     if solver.startswith("ao_admm"):
         res = nd.aoadmm_sharded(shard, comm, batch=16, fused=(False if solver == "ao_admm_unfused" else None), **kw)
     elif solver.startswith("admm"):
@@ -251,7 +303,7 @@ def _solver_gpu_worker(rank, world, port, backend, solver, outdir):
 
 @pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "admm", "admm_bf16",
                                     "admm_kl", "anls"])
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
     from oracle import nmf_ref as R
@@ -274,12 +326,11 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
 
 
-def _api_worker(rank, world, port, outdir):
+def _api_worker(rank, world, rdzv, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
     os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), "0"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from nmf_amd import dist as nd
@@ -315,21 +366,27 @@ def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
     np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=2e-5)      # (measured: 1.2e-6)
 
 
-def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs():
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two
-    ranks on ONE GPU (gloo staged through the host, shrunken shapes): the strong-scaling leg of config 2 and the config-5
-    leg (each rank draws its own rows of the same matrix on the device) both come back in the one JSON line."""
+@pytest.mark.parametrize("launch", ["torchrun", "self"])
+def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) and as a plain
+    `python bench.py --gpus 2` (no WORLD_SIZE: bench.py starts torch.distributed.run itself, as a child, before anything touches the
+    GPU), rehearsed with two ranks on ONE GPU (gloo staged through the host, shrunken shapes): the strong-scaling leg of config 2
+    and the config-5 leg (each rank draws its own rows of the same matrix on the device) both come back in the one JSON line."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NMFX_BENCH_BACKEND="gloo", NMFX_BENCH_CFG5_SHAPE="2048x1024x128", NMFX_BENCH_SHAPE="1024x512x64",
                NMF_AMD_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for _ in range(4):                                   # (a probed port can be taken by the time the rendezvous binds it: conftest.spawn_ranks)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-               "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic", "--tol-max-iter", "0"]
-        p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NMFX_DIST_INIT_METHOD"):
+        env.pop(key, None)
+    tail = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic",
+            "--tol-max-iter", "0"]
+    for _ in range(1 if launch == "self" else 4):        # (torchrun binds the port probed here a moment later; bench.py's own launch handles that itself)
+        head = [sys.executable] if launch == "self" else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(_free_port())]
+        p = subprocess.run(head + [os.path.join(root, "bench.py")] + tail, env=env, cwd=root, capture_output=True, text=True, timeout=600)
         if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
             break
     assert p.returncode == 0, p.stderr[-3000:]
@@ -338,6 +395,7 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["rows_per_gpu"] == 512
+    assert "strong_scaling_quoted_on" in line
     leg = line["other_configs"][0]
     assert leg.get("config") == "cfg5" and "error" not in leg, leg
     assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 1024 and leg["objective_decreasing"] and leg["iter_per_s"] > 0

@@ -238,3 +238,41 @@ def test_mur_kl_after_another_solver_touched_h_on_the_same_handle():
         wb, hb = b.get_factors()
     np.testing.assert_array_equal(wa, wb)
     np.testing.assert_array_equal(ha, hb)
+
+
+def test_a_second_solver_family_on_the_same_handle_needs_fresh_factors():
+    """every solver family keeps its own device state next to W and H (MUR: W ping-pong, bf16 images, the KL epilogue's
+    leftovers; the ADMM family: duals and auxiliaries; ANLS: warm-start supports).  A different family that continues in the middle
+    of a run -- reusing contiguous iteration indices -- used to read the other's leftovers silently; it is refused now
+    (NMFX_E_STATE) until the factors have been read back and set again, and the KL leftovers are voided by every other entry."""
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.engine import Engine
+    m, n, k = 384, 320, 40
+    v = R.planted_matrix(m, n, k, seed=5, dtype=np.float32)
+    rs = np.random.RandomState(1)
+    w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+    NEVER = 10 ** 9
+    with Engine(m, n, k) as a:
+        a.upload_v(v)
+        a.set_factors(w0, h0)
+        a.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 0, 3)          # KL, iterations 0..2
+        with pytest.raises(NmfxError, match="another solver"):
+            a.anls_run(0.0, 0.0, NEVER, 1e-3, 1e-3, 3, 2)          # ANLS "continuing" at index 3
+        with pytest.raises(NmfxError, match="another solver"):
+            a.aoadmm_run(0, 1, 0.1, 1, 0.1, 5, NEVER, 1e-3, 1e-3, 3, 1)
+        w1, h1 = a.get_factors()
+        a.set_factors(w1, h1)
+        a.anls_run(0.0, 0.0, NEVER, 1e-3, 1e-3, 0, 3)              # ... from fresh factors: fine
+        with pytest.raises(NmfxError, match="another solver"):
+            a.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 3, 2)      # and KL may not pick up behind ANLS at contiguous indices either
+        w2, h2 = a.get_factors()
+        a.set_factors(w2, h2)
+        a.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 0, 3)
+        wa, ha = a.get_factors()
+    with Engine(m, n, k) as b:
+        b.upload_v(v)
+        b.set_factors(w2, h2)
+        b.mur_run(1, 0.01, 0.02, NEVER, 1e-5, 1e-5, 0, 3)
+        wb, hb = b.get_factors()
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(ha, hb)
