@@ -537,10 +537,10 @@ int nmfx_shift_iteration_base(nmfx_handle_t E, int64_t delta) {
 }
 
 // ---- MUR -------------------------------------------------------------------
-static int check_ready(nmfx_engine* E, int64_t first, int64_t count) {
+static int check_ready(nmfx_engine* E, int64_t first, int64_t count, bool mur_entry = true) {
     E->anls_a_ready = false;                           // (another solver's products overwrite A_part)
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
-    { int rc_ = nmfx_enter_family(E, 1); if (rc_) return rc_; }
+    if (mur_entry) { int rc_ = nmfx_enter_family(E, 1); if (rc_) return rc_; }
     if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     return nmfx_ensure_obj_capacity(E, first + count + 2);
@@ -619,7 +619,7 @@ int nmfx_mur_finish_a(nmfx_handle_t E, int distance, int64_t j) {
 
 int nmfx_mur_finish_b(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t j) {
     if (!E) return NMFX_E_ARG;
-    int rc = check_ready(E, j, 1); if (rc) return rc;
+    int rc = check_ready(E, j, 1, false); if (rc) return rc;       // (the closing step of EVERY row-sharded solver, not only MUR's)
     return nmfx_finish_b(E, min_iter, tol1, tol2, j);
 }
 
