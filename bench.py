@@ -135,6 +135,56 @@ def cpu_baseline(v, k, iters):
     return iters / dt, w, h, np.asarray(hist)
 
 
+def converge_on_device(eng, w0, h0, tol, max_iter, min_iter=100):
+    """MUR-eu from (w0, h0) until the reference's stop rule (nmf/utils.py:4-15, tol1 = tol2 = tol, nmf/mur.py:131 `i > min_iter`)
+    fires on the device, or max_iter.  Returns (rule, stop index i, iterations run, seconds, objective slots filled)."""
+    eng.set_factors(w0, h0)
+    eng.synchronize()
+    t1 = time.perf_counter()
+    done_t, rule, stop_i, n_obj_t = 0, 0, -1, 0
+    while done_t < max_iter and not rule:
+        cnt = min(256, max_iter - done_t)
+        eng.mur_run(0, 0.0, 0.0, min_iter, tol, tol, done_t, cnt)
+        done_t += cnt
+        rule, stop_i, n_obj_t = eng.state()
+    return int(rule), int(stop_i), int(done_t), time.perf_counter() - t1, int(n_obj_t)
+
+
+def oracle_stop_check(eng, v, w0, h0, tol, device_rule, device_i, lead=15, span=30, min_iter=100):
+    """The time-to-tol half of the metric, pinned at the full size (part of the cpu_baseline leg: the oracle is the CHECKER here).
+    The device says the reference's stop rule fires at outer iteration `device_i` with rule `device_rule`.  Its run is bit-stable,
+    so running it again for s = device_i - lead iterations gives the iterate (W_s, H_s) it passed through; the float64 oracle
+    (reference evaluation order, nmf/mur.py:119-136) continues from there for `span` iterations with the reference's own
+    convergence_check on ITS float64 objective values.  Both must stop at the same index by the same rule."""
+    from oracle import nmf_ref as R
+    s = max(0, device_i - lead)
+    eng.set_factors(w0, h0)
+    eng.mur_run(0, 0.0, 0.0, min_iter, tol, tol, 0, s)
+    w, h = eng.get_factors()
+    dev_obj = None
+    wh = w @ h
+    hist = [R.objective(v, wh, "eu")]
+    oracle_i, oracle_rule = -1, 0
+    for t in range(span):
+        i = s + t
+        w = R.mur_w_step("eu", v, w, h, wh, 0.0)
+        h = R.mur_h_step("eu", v, w, h, w @ h, 0.0)
+        wh = w @ h
+        hist.append(R.objective(v, wh, "eu"))
+        if i > min_iter:
+            oracle_rule = R.stop_rule(hist[-1], hist[-2], tol, tol)
+            if oracle_rule:
+                oracle_i = i
+                break
+    dec = -np.diff(np.asarray(hist))
+    return {"tol": tol, "device_i": int(device_i), "device_rule": int(device_rule), "oracle_i": int(oracle_i), "oracle_rule": int(oracle_rule),
+            "agree": bool(oracle_i == device_i and oracle_rule == device_rule), "snapshot_iteration": int(s),
+            "oracle_iterations_run": int(len(hist) - 1),
+            "oracle_decrease_last_two": [float(x) for x in dec[-2:]],
+            "note": "f64 oracle continued from the device's iterate `lead` iterations before its stop; convergence_check on the "
+                    "oracle's own objective values (nmf/utils.py:4-15)"}
+
+
 def parity_block(v, w_g, h_g, obj_g, w_r, h_r, obj_r, block=2048):
     """||W_g H_g - W_r H_r||_F / ||V||_F (north_star's bar: < 1e-4) by row blocks + objective histories."""
     num = den = 0.0
@@ -605,21 +655,20 @@ def main():
     if rank == 0 and world == 1 and args.tol_max_iter > 0:
         ttt = []
         for tol in (1e-5, 1e-2):          # the reference's default, and a looser absolute tolerance
-            eng.set_factors(w0, h0)
-            eng.synchronize()
-            t1 = time.perf_counter()
-            done_t, rule = 0, 0
-            while done_t < args.tol_max_iter and not rule:
-                cnt = min(256, args.tol_max_iter - done_t)
-                eng.mur_run(0, 0.0, 0.0, 100, tol, tol, done_t, cnt)
-                done_t += cnt
-                rule, stop_i, n_obj_t = eng.state()
-            secs = time.perf_counter() - t1
+            rule, stop_i, done_t, secs, n_obj_t = converge_on_device(eng, w0, h0, tol, args.tol_max_iter)
             ttt.append({"tol1": tol, "tol2": tol, "min_iter": 100, "max_iter": args.tol_max_iter,
                         "converged": bool(rule), "stop_rule": int(rule),
                         "iterations": int(stop_i + 1) if rule else int(done_t), "seconds": secs,
                         "objective": float(eng.objectives(n_obj_t - 1, 1)[0]),
                         "note": "host checks the device-side stop flag every 256 queued iterations"})
+        # the converged leg against the f64 oracle: same stop index, same rule (needs the host copy of V: done in the cpu_baseline leg)
+        if not args.no_cpu:
+            for leg in ttt:
+                if leg["converged"]:
+                    v_chk = v_local if (r0, r1) == (0, m) else planted_matrix(m, n, k, seed=0, dtype=np.float32)
+                    leg["oracle_stop_check"] = oracle_stop_check(eng, v_chk, w0, h0, leg["tol1"], leg["stop_rule"], leg["iterations"] - 1)
+                    if not os.environ.get("NMFX_BENCH_NOASSERT"):
+                        assert leg["oracle_stop_check"]["agree"], f"time-to-tol: device and oracle stop differently: {leg['oracle_stop_check']}"
 
     # parity at the full size, GPU leg: the same cpu_iters + 1 iterations the cpu_baseline leg runs, from
     # the same start, in the arithmetic that was timed; compared with the oracle's factors further down

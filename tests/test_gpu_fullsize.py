@@ -38,6 +38,26 @@ def test_config2_mur_eu_16384x8192_k64_vs_oracle():
     assert np.all(np.diff(res.obj_history) < 0)
 
 
+def test_config2_time_to_tol_stop_index_equals_the_f64_oracle():
+    """The time-to-tol half of BASELINE.json's metric at the full size: MUR-eu 16384x8192 k = 64 runs until the
+    reference's stop rule fires (nmf/mur.py:127-136 with nmf/utils.py:4-15; tol1 = tol2 = 1e-2: ~4000 iterations, 0.9 s); the f64
+    oracle is continued from the device's own iterate 15 iterations before that stop and must stop at the same outer iteration
+    by the same rule, on its own float64 objective values."""
+    import bench
+    from nmf_amd.engine import Engine
+    m, n, k = 16384, 8192, 64
+    v = R.planted_matrix(m, n, k, seed=0, dtype=np.float32)
+    rs = np.random.RandomState(0)
+    w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+    with Engine(m, n, k) as eng:
+        eng.upload_v(v)
+        rule, stop_i, done, secs, n_obj = bench.converge_on_device(eng, w0, h0, 1e-2, 20000)
+        assert rule == 2 and 1000 < stop_i < 19999, (rule, stop_i)
+        chk = bench.oracle_stop_check(eng, v, w0, h0, 1e-2, rule, stop_i)
+    print(f"\nSTOP CHECK: {chk}")
+    assert chk["agree"], chk
+
+
 def test_config4_mur_kl_32768x16384_k64_vs_oracle():
     """BASELINE config 4: nmf/mur.py:24-27,40-43 + the KL objective nmf/utils.py:21-26, 2 iterations."""
     from nmf_amd.mur import mur
