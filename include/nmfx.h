@@ -188,6 +188,21 @@ int nmfx_set_exchange_rank(nmfx_handle_t h, int rank, int world);
 int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, int64_t n_f32, void* dev_f64, int64_t n_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
 
+/* ---- pair mode: two MUR-Euclidean factorizations of the SAME V in one pass over it ------------------------------
+ * The reference author's parameter grids (nmf/nmf_old.py:52-66, nmf/nmf.py:38-45) call the solver once per (lambda_w, lambda_h,
+ * start); on the GPU two such problems with k <= 64 share the V stream: a handle created with k = 128 holds problem 0 in the
+ * factor columns [0, 64) and problem 1 in [64, 128) -- set with ONE nmfx_set_factors call on the stacked, zero-padded m x 128 /
+ * 128 x n matrices.  The V-sized products are the k = 128 products; objective, Gram matrices, lambda, stop rule and objective
+ * history are per problem (nmf/mur.py:119-136 twice).  A problem whose stop rule fires keeps the iterate the reference returns
+ * while the other one continues; the handle's ordinary stop flag is set when both have stopped.  lambda_w / lambda_h: two values
+ * each.  Split-bf16 path only (NMFX_E_STATE otherwise); single GPU.                                                            */
+int nmfx_mur_pair_run(nmfx_handle_t h, const double* lambda_w, const double* lambda_h, int64_t min_iter, double tol1, double tol2,
+                      int64_t first, int64_t count);
+int nmfx_mur_pair_finish(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t iters_done);
+int nmfx_pair_get_state(nmfx_handle_t h, int p, int* stop_rule, int64_t* stop_i, int64_t* n_obj);
+int nmfx_pair_get_objectives(nmfx_handle_t h, int p, int64_t first, int64_t count, double* out);
+int nmfx_pair_get_factors(nmfx_handle_t h, int p, int k_p, double* w, double* hmat);      /* w: m x k_p, hmat: k_p x n */
+
 /* ---- the exchange step behind the C ABI: RCCL over xGMI, one process per GPU -----------------------------------------------
  * north_star: "shard rows of V and W across the 8 GPUs of one node with an RCCL all-reduce over xGMI of the k x k Gram W^T W and
  * the k x n product W^T V each outer iteration" (nmf/mur.py:45 needs w.T @ x and w.T @ w over ALL rows).  RCCL is bound at run

@@ -70,6 +70,7 @@ __global__ void init_state_kernel(DevState* st) {
     st->nnls_evicted = 0; st->nnls_capped = 0; st->nnls_fallback = 0; st->nnls_noinv = 0;
     for (int i = 0; i < 4; ++i) { st->ao_hint[i >> 1][i & 1] = 0; st->ao_paths[i] = 0; }
     st->ao_continued = 0;
+    for (int p = 0; p < 2; ++p) { st->pflag[p] = 0; st->pstop_i[p] = -1; st->pn_obj[p] = 0; }
 }
 
 __global__ void shift_iteration_base_kernel(DevState* st, long long delta) { st->j_base += delta; }
@@ -176,7 +177,7 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->G_part, std::max<int64_t>(std::max(gs, hs), 4 * std::max<int64_t>(hs, (int64_t)ncu) + 8) * kp * kp));
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));
-    TRY(dev_alloc(E, &E->obj_part, std::max<int64_t>(rb * ws, cb * hs) + 64));
+    TRY(dev_alloc(E, &E->obj_part, 2 * (std::max<int64_t>(rb * ws, cb * hs) + 64)));      // (x 2: pair mode keeps two partials per block)
     TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp + NMFX_XTAIL));
     TRY(dev_alloc(E, &E->xf64, 8 + 4 * NMFX_MAX_FUSED_ROUNDS));
     TRY(dev_alloc(E, &E->state, 1));
@@ -367,6 +368,8 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->bf_ready = false;
     E->kl_h_iter = -2;
     E->family = 0;
+    E->pair = false;
+    E->family_started = false;
     E->himg_both = false;
     E->lazy_objective = false;
     E->anls_a_ready = false;
@@ -540,7 +543,11 @@ int nmfx_shift_iteration_base(nmfx_handle_t E, int64_t delta) {
 static int check_ready(nmfx_engine* E, int64_t first, int64_t count, bool mur_entry = true) {
     E->anls_a_ready = false;                           // (another solver's products overwrite A_part)
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
-    if (mur_entry) { int rc_ = nmfx_enter_family(E, 1); if (rc_) return rc_; }
+    if (mur_entry) {
+        int rc_ = nmfx_enter_family(E, 1); if (rc_) return rc_;
+        if (E->pair) { E->err = "this handle runs two stacked problems (nmfx_mur_pair_run): nmfx_set_factors before a single-problem run"; return NMFX_E_STATE; }
+        E->family_started = true;
+    }
     if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     return nmfx_ensure_obj_capacity(E, first + count + 2);

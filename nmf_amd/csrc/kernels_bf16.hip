@@ -586,7 +586,11 @@ extern "C" int nmfx_debug_stamps(unsigned long long* out) {
 // (double buffered: 64 KiB), V ring 3 deep; stages of (k-step, pair of factor tiles) so that the fragment registers stay
 // at 2 x 16; no cross-group pipeline (its second V register set does not fit next to 64 accumulator and 64 Z registers),
 // no Gram by-product, Euclidean only.
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64>
+// NPROB = 2 (pair mode, KP = 128 with the objective): the factor columns [0, 64) and [64, 128) belong to two independent problems
+// on the same X -- the A-product is the k = 128 product as it stands (A = [X Y_0^T | X Y_1^T]); the residual product is closed
+// after the first four k-steps (objective of problem 0), restarted, and closed again after the last four (problem 1):
+// objpart[p][split][block].
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
     static_assert(KP == 64 || (KP == 128 && !KL && ABL == 0), "KP = 128: Euclidean products only");
+    static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     constexpr int YR = KL ? 3 : 2;                     // Y ring (KL: the second product runs one group behind the first)
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
@@ -693,6 +698,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0, olog = 0.0;                     // (olog: KL, the sum of x log2(q))
+    double osum2 = 0.0;                                // (NPROB = 2: the residual sum of the second problem)
     // Two loop structures.
     //  !WITH_OBJ (H phase and the other objective-free products; bound by the bytes in flight): a V slot is refilled as
     //    soon as every wave holds its tile in registers, VRING groups ahead, at the price of a second barrier per group.
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     // late, right behind the next group's barrier, where it covers the latency of that group's first fragment reads (at
     // the end of its own group it was a serial tail of ~250 cycles -- MFMA result, 16 dependent adds, an f64 add -- with
     // the matrix pipe idle in front of the barrier)
-    auto residual = [&](const VRegs& v) {
+    auto residual = [&](const VRegs& v, double& osum) {
         if (ABL & 4) { osum += (double)(v.d[0] + v.d[5] + v.va[0][0].x + v.va[1][1].y); return; }
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;  // four chains instead of one
 #pragma unroll
@@ -862,11 +868,16 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
                     if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
                     d = MFMA32X(fh[set][ss], zl[s], d);
                 }
+                if (NPROB == 2 && st == NA + ND / 2 - 1) {     // factors 0 .. 63 are done: the first problem's residual, then start over
+                    residual(cur, osum);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                }
             }
             if (PIPE && st == 0) {                     // residual of the previous group, between the MFMAs of stage 0
 #pragma unroll
                 for (int a = 0; a < 4; ++a) pin4(nxt.va[a >> 1][a & 1]);   // (opaque: keeps the arithmetic on this side of the barrier ...
-                residual(nxt);
+                residual(nxt, osum);
                 asm volatile("" : "+v"(osum));         //  ... and of the later stages: hipcc otherwise sinks it to the end of the group)
                 // V(grp + 1) from its LDS slot into the registers the residual has just released (unconditional: behind the last
                 // group this fetches a stale slot that nothing uses; a branch here costs a full LDS drain)
@@ -904,7 +915,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
                 }
             }
         }
-        if (WITH_OBJ && !PIPE) residual(cur);          // (PIPE: one group late, see above)
+        if (WITH_OBJ && !PIPE) residual(cur, NPROB == 2 ? osum2 : osum);          // (PIPE: one group late, see above)
         NMFX_STAMP(ts4);
 #ifdef NMFX_EXP_STAMPS
         acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_early += ts3 - ts2; acc_mfma += ts4 - ts3;
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         }
     }
     if (PIPE && g0 < g1) {                             // the last group's carried stage and residual
-        if ((g1 - g0) & 1) { carried_stage(P.d, false); residual(P); } else { carried_stage(Q.d, false); residual(Q); }
+        if ((g1 - g0) & 1) { carried_stage(P.d, false); residual(P, osum); } else { carried_stage(Q.d, false); residual(Q, osum); }
     }
 #undef NMFX_FENCE
 #ifdef NMFX_EXP_STAMPS
@@ -1163,6 +1174,17 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             double t = 0.0;
             for (int w = 0; w < 8; ++w) t += red[w];
             objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (KL ? 1.0 : 0.5) * t;
+        }
+        if (NPROB == 2) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) osum2 += __shfl_down(osum2, off, 64);
+            if (lane == 0) red[8 + wave] = osum2;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int w = 0; w < 8; ++w) t += red[8 + w];
+                objpart[((int64_t)gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.5 * t;
+            }
         }
     }
 }
@@ -1369,13 +1391,18 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* p) {       // 8 con
                       p[4] | ((unsigned)p[5] << 16), p[6] | ((unsigned)p[7] << 16));
 }
 
-template <int KP>
+// PAIR (KP = 128): two independent problems in the factor halves [0, 64) and [64, 128) -- H H^T is taken block diagonal, lambda is
+// per half (lam, lam1), and a problem whose stop rule has fired keeps the iterate the reference returns: that one lives in the
+// W buffer (stop_i + 1) & 1, so launches that would write THAT buffer (`nxt`) leave the problem's half alone.
+template <int KP, bool PAIR = false>
 __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
     const float* __restrict__ Apart, int wsplit, int64_t mp, const float* __restrict__ Wold,
     const float* __restrict__ HHtpart, int hslabs, float lam, float* __restrict__ Wnew,
     unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
-    unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag)
+    unsigned short* __restrict__ WThi, unsigned short* __restrict__ WTlo, const int* __restrict__ flag,
+    float lam1 = 0.f, const DevState* __restrict__ st = nullptr, int nxt = 0)
 {
+    static_assert(!PAIR || KP == 128, "pair mode stacks two k <= 64 problems into the k = 128 layouts");
     constexpr int RB = 64, LDW = KP + 4, LDH = KP + 16, NT = 512;   // padded LDS rows: conflict-free dword reads
     constexpr int WV = KP / 32;                        // 16-byte pieces of the 64 x KP W tile per thread
     constexpr int HV = KP * KP / 2048;                 // ... of one KP x KP Gram slab per thread
@@ -1393,6 +1420,11 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
     // threads, and everything is requested before the first wait -- the stop flag, the W tile, the A slabs
     // of this thread's outputs four slabs at a time, and the H H^T slabs HCH at a time.
     const int stop = *flag;
+    bool keep[2] = {false, false};                     // (PAIR) halves whose final iterate sits in the buffer this launch writes
+    if (PAIR) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) keep[p] = st->pflag[p] != 0 && (int)((st->pstop_i[p] + 1) & 1) == nxt;
+    }
     const int erow = tid >> 3, ej0 = EP * (tid & 7);
     const int64_t eidx = (r0 + erow) * KP + ej0;
     float4 wt[WV];
@@ -1433,7 +1465,9 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
 #pragma unroll
     for (int u = 0; u < HV; ++u) {
         const int i = tid + NT * u;
-        *reinterpret_cast<float4*>(hs + (i / (KP / 4)) * LDH + 4 * (i % (KP / 4))) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        const bool off = PAIR && ((i / (KP / 4)) < KP / 2) != ((i % (KP / 4)) < KP / 8);      // (off-diagonal block: the other problem's factors)
+        *reinterpret_cast<float4*>(hs + (i / (KP / 4)) * LDH + 4 * (i % (KP / 4))) =
+            off ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
     }
 #pragma unroll
     for (int u = 0; u < WV; ++u) {
@@ -1464,10 +1498,12 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
     {   // epilogue, vectorised along the factor index: thread = (row, EP consecutive j)
         float wn[EP];
         unsigned ph[EP / 2], pl[EP / 2];
+        const float lam_t = (PAIR && ej0 >= KP / 2) ? lam1 : lam;
+        const bool skip = PAIR && keep[ej0 >= KP / 2 ? 1 : 0];
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
             const float w = ws[erow * LDW + ej0 + e];
-            wn[e] = w * a[e] / (dt[erow * LDW + ej0 + e] + lam * w + 1e-9f);
+            wn[e] = w * a[e] / (dt[erow * LDW + ej0 + e] + lam_t * w + 1e-9f);
         }
 #pragma unroll
         for (int e = 0; e < EP / 2; ++e) {
@@ -1475,6 +1511,7 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
             th[(ej0 + 2 * e) * (RB + 2) + erow] = (unsigned short)(ph[e] & 0xffffu); th[(ej0 + 2 * e + 1) * (RB + 2) + erow] = (unsigned short)(ph[e] >> 16);
             tl[(ej0 + 2 * e) * (RB + 2) + erow] = (unsigned short)(pl[e] & 0xffffu); tl[(ej0 + 2 * e + 1) * (RB + 2) + erow] = (unsigned short)(pl[e] >> 16);
         }
+        if (!skip) {
 #pragma unroll
         for (int v4 = 0; v4 < EP / 4; ++v4)
             *reinterpret_cast<float4*>(Wnew + eidx + 4 * v4) = make_float4(wn[4 * v4], wn[4 * v4 + 1], wn[4 * v4 + 2], wn[4 * v4 + 3]);
@@ -1483,9 +1520,11 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
             *reinterpret_cast<uint4*>(Whi + eidx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
             *reinterpret_cast<uint4*>(Wlo + eidx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
         }
+        }
     }
     __syncthreads();
     {   // transposed images: thread (f = tid / 8 (+ 64), eighth = tid % 8) stores 8 rows = 16 bytes per image
+        // (PAIR: a stopped problem's transposed images are no longer read for anything that is kept -- written as they come)
         const int oc = tid & 7;
 #pragma unroll
         for (int f = tid >> 3; f < KP; f += 64) {
@@ -1502,15 +1541,20 @@ __global__ __launch_bounds__(512) void mur_w_update_bf16_kernel(
 // FROM_SLABS: single-GPU runs read the split slabs of the H phase, the Gram slabs and the
 // objective partials directly (no `pack` launch); sharded runs read the all-reduced
 // exchange buffers.
-template <int KP, bool FROM_SLABS>
+// PAIR (KP = 128, not FROM_SLABS): two problems in the factor halves -- W^T W block diagonal, lambda per half (lam, lam1), the two
+// objectives summed here from the product kernel's per-block partials osrc[p][nobj], one stop test and history each
+// (nmfx_record_objective_pair); the rows of a problem that has stopped are left as they are.
+template <int KP, bool FROM_SLABS, bool PAIR = false>
 __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     const float* __restrict__ bsrc, int bsplit, const float* __restrict__ gsrc, int gsplit,
     const double* __restrict__ osrc, int64_t nobj, float* __restrict__ H,
     int64_t np, float lam, long long j, long long min_iter, double tol1, double tol2,
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
-    const float* __restrict__ xtail = nullptr, int xworld = 0)   // NMFX_XTAIL: every rank's objective partial, as 16-bit digits
+    const float* __restrict__ xtail = nullptr, int xworld = 0,   // NMFX_XTAIL: every rank's objective partial, as 16-bit digits
+    float lam1 = 0.f)
 {
+    static_assert(!PAIR || (KP == 128 && !FROM_SLABS), "pair mode: k = 128 layouts, sums from the pack launch");
     constexpr int CB = 64, LDG = KP + 4, LDC = 80, LDD = 68, NT = 512;
     constexpr int TV = KP / 32;                        // 16-byte pieces per thread of the KP x 64 H tile / the 64 x KP B^T tile
     constexpr int GV = KP * KP / 2048;                 // ... of one KP x KP Gram slab
@@ -1522,10 +1566,13 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     float* gs = dyn;                                   // G [j][LDG], later the product tile D [j][LDD]
     float* hs = gs + KP * LDG;                         // H tile [j][LDC]
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
-    __shared__ double shd[8];
+    __shared__ double shd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t c0 = (int64_t)blockIdx.x * CB;
     const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
+    int dead[2] = {0, 0};                              // (PAIR) problems that stopped in an earlier iteration
+    double sacc1 = 0.0;
+    if (PAIR) { dead[0] = st->pflag[0]; dead[1] = st->pflag[1]; for (int64_t i = tid; i < nobj; i += NT) sacc1 += osrc[nobj + i]; }
     // The kernel is a chain of dependent memory round trips, so it is built to have as few as possible:
     // 512 threads, and everything that does not depend on a decision -- the stop flag, the objective
     // partials, the H tile, and the G / B^T slabs of SCH slab indices at a time -- is requested before the
@@ -1533,7 +1580,7 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     // trips: 17.5 us; now 13.)
     const int stop = st->flag;
     double sacc = 0.0;
-    if (FROM_SLABS) { for (int64_t i = tid; i < nobj; i += NT) sacc += osrc[i]; }
+    if (FROM_SLABS || PAIR) { for (int64_t i = tid; i < nobj; i += NT) sacc += osrc[i]; }
     else if (xtail) {                                  // the partials of all ranks, exact, summed in rank order (the same on every rank)
         for (int r = 0; r < xworld; ++r) {
             const float4 dg = *reinterpret_cast<const float4*>(xtail + 4 * r);
@@ -1592,18 +1639,31 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     }
     if (stop) return;
     double obj;
-    if (FROM_SLABS) {                                  // same fixed-order sum in every block
+    if (FROM_SLABS || PAIR) {                          // same fixed-order sum in every block
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
         if (lane == 0) shd[wave] = sacc;
+        if (PAIR) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sacc1 += __shfl_down(sacc1, off, 64);
+            if (lane == 0) shd[8 + wave] = sacc1;
+        }
         __syncthreads();
         obj = ((((((shd[0] + shd[1]) + shd[2]) + shd[3]) + shd[4]) + shd[5]) + shd[6]) + shd[7];
     } else {
         obj = sacc;
     }
+    if (PAIR) {
+        const double obj1 = ((((((shd[8] + shd[9]) + shd[10]) + shd[11]) + shd[12]) + shd[13]) + shd[14]) + shd[15];
+        const bool writer = blockIdx.x == 0 && tid == 0;
+        if (!dead[0]) dead[0] = nmfx_record_objective_pair(st, obj_hist, obj, 0, j, min_iter, tol1, tol2, writer);
+        if (!dead[1]) dead[1] = nmfx_record_objective_pair(st, obj_hist, obj1, 1, j, min_iter, tol1, tol2, writer);
+        if (dead[0] && dead[1]) { if (writer) st->flag = 1; return; }       // both done: every later launch returns at once
+    } else {
     const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2,
                                            blockIdx.x == 0 && tid == 0);
     if (rule) return;
+    }
 #pragma unroll
     for (int u = 0; u < TV; ++u) {
         const int i = tid + NT * u;
@@ -1612,7 +1672,9 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
 #pragma unroll
     for (int u = 0; u < GV; ++u) {
         const int i = tid + NT * u;
-        *reinterpret_cast<float4*>(gs + (i / (KP / 4)) * LDG + 4 * (i % (KP / 4))) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
+        const bool off = PAIR && ((i / (KP / 4)) < KP / 2) != ((i % (KP / 4)) < KP / 8);      // (the other problem's factors)
+        *reinterpret_cast<float4*>(gs + (i / (KP / 4)) * LDG + 4 * (i % (KP / 4))) =
+            off ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
     }
     __syncthreads();
     // D[jrow][c] = sum_l G[jrow][l] H[l][c]; wave = 16 factor rows (tile wave % RTN), CT column tiles
@@ -1637,14 +1699,17 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
         const int jr = tid / TPR, cq = EP * (tid % TPR);
         float hn[EP];
         unsigned ph[EP / 2], pl[EP / 2];
+        const float lam_t = (PAIR && jr >= KP / 2) ? lam1 : lam;
+        const bool skip = PAIR && dead[jr >= KP / 2 ? 1 : 0] != 0;
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
             const float h = hs[jr * LDC + cq + e];
-            hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDD + cq + e] + lam * h + 1e-9f);
+            hn[e] = h * bt[(cq + e) * LDG + jr] / (dt[jr * LDD + cq + e] + lam_t * h + 1e-9f);
         }
 #pragma unroll
         for (int e = 0; e < EP / 2; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
         const int64_t idx = (int64_t)jr * np + c0 + cq;
+        if (!skip) {
 #pragma unroll
         for (int v4 = 0; v4 < EP / 4; ++v4)
             *reinterpret_cast<float4*>(H + idx + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
@@ -1652,6 +1717,7 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
         for (int v8 = 0; v8 < EP / 8; ++v8) {
             *reinterpret_cast<uint4*>(Hhi + idx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
             *reinterpret_cast<uint4*>(Hlo + idx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
+        }
         }
     }
 }
@@ -1690,6 +1756,9 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
     auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP>;
+    if constexpr (OBJ && !KL && KP == 128 && TERMS == 3) {
+        if (E->pair) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 2>;     // two stacked problems: one objective each
+    }
 #ifdef NMFX_EXP_ABLATE
     if constexpr (TERMS == 3 && KL && KP == 64) {
         static const int abl = getenv("NMFX_ABLATE") ? atoi(getenv("NMFX_ABLATE")) : 0;
@@ -2289,6 +2358,166 @@ int nmfx_mur_eu_phase_a_cols_bf16(nmfx_engine* E, int64_t c0, int64_t c1) {
                        E->xf32 + (int64_t)E->kp * E->np, E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->xf64, nb,
                        last ? 1 : 0, &E->state->flag, tail, E->xrank, E->xworld);
     NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// ---- pair mode: two MUR-Euclidean problems in one pass over V (the reference author's parameter grids,
+// nmf/nmf_old.py:52-66 / nmf/nmf.py:38-45, run one factorization per (lambda_w, lambda_h, seed) on the SAME data) ----------------
+// A handle created with k = 128 holds problem 0 in the factor columns [0, 64) and problem 1 in [64, 128) (each with k_p <= 64,
+// zero padded: a zero column of W with a zero row of H is a fixed point of the multiplicative updates).  A = V [H_0; H_1]^T and
+// B = [W_0 W_1]^T V are the k = 128 products as they stand -- V and V^T are streamed ONCE for both problems -- while everything
+// that couples factors is taken per problem: the residual objective (two sums, xyt32_bf16_kernel<..., NPROB = 2>), the Gram
+// matrices (block diagonal), lambda, the stop test and the objective history (slots 2 j + p).  A problem whose stop rule has
+// fired keeps the iterate the reference returns while the other one goes on (see mur_w_update_bf16_kernel).
+static int pair_ready(nmfx_engine* E, int64_t first, int64_t count) {
+    if (!E) return NMFX_E_ARG;
+    E->anls_a_ready = false; E->himg_both = false; E->kl_h_iter = -2;
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    if (first < 0 || count < 0) { E->err = "negative iteration range"; return NMFX_E_ARG; }
+    if (E->kp != 128 || !(E->precision == 1 && nmfx_bf16_supported(E))) {
+        E->err = "pair mode needs a handle created with k = 128 (two problems of k <= 64) on the split-bf16 path"; return NMFX_E_STATE; }
+    if (E->xworld > 0 || E->comm) { E->err = "pair mode is a single-GPU form"; return NMFX_E_STATE; }
+    int rc;
+    if ((rc = nmfx_enter_family(E, 1))) return rc;
+    if (!E->pair && E->family_started) { E->err = "pair mode cannot continue a run that was started as one k = 128 problem (nmfx_set_factors first)"; return NMFX_E_STATE; }
+    E->pair = true; E->family_started = true;
+    NMFX_HIP(hipSetDevice(E->device));
+    return nmfx_ensure_obj_capacity(E, 2 * (first + count) + 8);
+}
+
+__global__ __launch_bounds__(256) void pair_finalize_kernel(const double* __restrict__ osrc, int64_t nobj, long long j, long long min_iter,
+                                                            double tol1, double tol2, DevState* __restrict__ st, double* __restrict__ obj_hist)
+{
+    if (st->flag) return;
+    __shared__ double sh[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = tid; i < nobj; i += 256) { a += osrc[i]; b += osrc[nobj + i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int p = 0; p < 2; ++p)
+            if (!st->pflag[p]) nmfx_record_objective_pair(st, obj_hist, ((sh[p][0] + sh[p][1]) + sh[p][2]) + sh[p][3], p, j, min_iter, tol1, tol2, true);
+        if (st->pflag[0] && st->pflag[1]) st->flag = 1;
+    }
+}
+
+static int pair_iteration(nmfx_engine* E, const double* lw, const double* lh, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    if (!E->bf_ready) E->wsel = (int)(j & 1);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    const int cur = (int)(j & 1), nxt = cur ^ 1;
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const int64_t nobj = (int64_t)(E->mp / 128) * E->bf_wsplit;
+    { ProfScope ps(E, "sum_hht");
+      if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc; }
+    if ((rc = nmfx_bf16_vht(E, true, cur, "wphase", false, 3))) return rc;          // (E->pair: two objective partials per block)
+    { ProfScope ps(E, "w_update");
+      constexpr int KP = 128;
+      constexpr size_t shm = (size_t)(KP * (KP + 16) + 64 * (KP + 4)) * sizeof(float) + (size_t)2 * KP * 66 * sizeof(unsigned short);
+      auto kern = mur_w_update_bf16_kernel<KP, true>;
+      if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / 64)), dim3(512), shm, E->stream, E->A_part, E->bf_wsplit, E->mp,
+                         (const float*)E->W[cur], (const float*)E->HHt, 1, (float)lw[0], E->W[nxt], E->Whi[nxt], E->Wlo[nxt], E->WThi, E->WTlo,
+                         (const int*)&E->state->flag, (float)lw[1], (const DevState*)E->state, nxt);
+      NMFX_HIP(hipGetLastError()); }
+    int gslabs = E->gsplit;
+    if ((rc = nmfx_bf16_gram_tn(E, &gslabs))) return rc;
+    if ((rc = nmfx_bf16_vtw(E, false, "hphase", false, 3))) return rc;
+    if ((rc = nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, gslabs, nobj))) return rc;
+    E->wsel = (int)((j + 1) & 1);
+    E->w_in_place = false;
+    { ProfScope ps(E, "h_update");
+      constexpr int KP = 128;
+      constexpr size_t shm = (size_t)(KP * (KP + 4) + KP * 80 + 64 * (KP + 4)) * sizeof(float);
+      auto kern = mur_h_update_bf16_kernel<KP, false, true>;
+      if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / 64)), dim3(512), shm, E->stream, (const float*)E->xf32, 1,
+                         (const float*)(E->xf32 + (int64_t)E->kp * E->np), 1, (const double*)E->obj_part, nobj, E->H, E->np, (float)lh[0],
+                         (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo,
+                         (const float*)nullptr, 0, (float)lh[1]);
+      NMFX_HIP(hipGetLastError()); }
+    int hslabs = E->gsplit;
+    if ((rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;
+    if (hslabs < E->gsplit)
+        NMFX_HIP(hipMemsetAsync(E->HHt_part + (int64_t)hslabs * kk, 0, (size_t)(E->gsplit - hslabs) * kk * sizeof(float), E->stream));
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_mur_pair_run(nmfx_handle_t E, const double* lambda_w, const double* lambda_h, int64_t min_iter, double tol1,
+                                 double tol2, int64_t first, int64_t count) {
+    if (!E || !lambda_w || !lambda_h) { if (E) E->err = "mur_pair_run: lambda_w[2], lambda_h[2]"; return NMFX_E_ARG; }
+    int rc = pair_ready(E, first, count); if (rc) return rc;
+    for (int64_t j = first; j < first + count; ++j)
+        if ((rc = pair_iteration(E, lambda_w, lambda_h, min_iter, tol1, tol2, j))) return rc;
+    return NMFX_OK;
+}
+
+// objective of the pair(s) the last iteration left, and the last evaluation of the stop rule (nmf/mur.py:127-131 for i = max_iter - 1)
+extern "C" int nmfx_mur_pair_finish(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t iters_done) {
+    int rc = pair_ready(E, iters_done, 1); if (rc) return rc;
+    if (!E->bf_ready) E->wsel = (int)(iters_done & 1);
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_vht(E, true, (int)(iters_done & 1), "wphase", false, 3))) return rc;      // (its A output is scratch here)
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->obj_part,
+                       (int64_t)(E->mp / 128) * E->bf_wsplit, (long long)iters_done, (long long)min_iter, tol1, tol2, E->state, E->obj_hist);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static int pair_state(nmfx_engine* E, DevState* hs) {
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_HIP(hipMemcpyAsync(hs, E->state, sizeof(DevState), hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_pair_get_state(nmfx_handle_t E, int p, int* stop_rule, int64_t* stop_i, int64_t* n_obj) {
+    if (!E || (p != 0 && p != 1)) { if (E) E->err = "pair: problem index 0 or 1"; return NMFX_E_ARG; }
+    DevState hs; int rc;
+    if ((rc = pair_state(E, &hs))) return rc;
+    if (stop_rule) *stop_rule = hs.pflag[p];
+    if (stop_i) *stop_i = hs.pstop_i[p];
+    if (n_obj) *n_obj = hs.pn_obj[p];
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_pair_get_objectives(nmfx_handle_t E, int p, int64_t first, int64_t count, double* out) {
+    if (!E || !out || (p != 0 && p != 1) || first < 0 || count < 0 || 2 * (first + count) > E->obj_cap) {
+        if (E) E->err = "pair_get_objectives: range"; return NMFX_E_ARG; }
+    if (count == 0) return NMFX_OK;
+    NMFX_HIP(hipSetDevice(E->device));
+    std::vector<double> tmp((size_t)(2 * count));
+    NMFX_HIP(hipMemcpyAsync(tmp.data(), E->obj_hist + 2 * first, tmp.size() * 8, hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    for (int64_t i = 0; i < count; ++i) out[i] = tmp[(size_t)(2 * i + p)];
+    return NMFX_OK;
+}
+
+// factors of problem p (k_p <= 64 columns of W / rows of H from offset 64 p): the iterate the reference returns -- W_{stop_i + 1}
+// once the problem's stop rule has fired, else the latest one
+extern "C" int nmfx_pair_get_factors(nmfx_handle_t E, int p, int k_p, double* w, double* hmat) {
+    if (!E || (p != 0 && p != 1) || k_p < 1 || k_p > 64) { if (E) E->err = "pair_get_factors: p in {0, 1}, 1 <= k_p <= 64"; return NMFX_E_ARG; }
+    if (E->kp != 128) { E->err = "pair_get_factors: handle was not created with k = 128"; return NMFX_E_STATE; }
+    DevState hs; int rc;
+    if ((rc = pair_state(E, &hs))) return rc;
+    const int buf = hs.pflag[p] ? (int)((hs.pstop_i[p] + 1) & 1) : E->wsel;
+    if (w) {
+        std::vector<float> tmp((size_t)E->m * k_p);
+        NMFX_HIP(hipMemcpy2DAsync(tmp.data(), (size_t)k_p * 4, E->W[buf] + 64 * p, (size_t)E->kp * 4, (size_t)k_p * 4, (size_t)E->m,
+                                  hipMemcpyDeviceToHost, E->stream));
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+        for (size_t i = 0; i < tmp.size(); ++i) w[i] = (double)tmp[i];
+    }
+    if (hmat) {
+        std::vector<float> tmp((size_t)k_p * E->n);
+        NMFX_HIP(hipMemcpy2DAsync(tmp.data(), (size_t)E->n * 4, E->H + (int64_t)64 * p * E->np, (size_t)E->np * 4, (size_t)E->n * 4, (size_t)k_p,
+                                  hipMemcpyDeviceToHost, E->stream));
+        NMFX_HIP(hipStreamSynchronize(E->stream));
+        for (size_t i = 0; i < tmp.size(); ++i) hmat[i] = (double)tmp[i];
+    }
     return NMFX_OK;
 }
 

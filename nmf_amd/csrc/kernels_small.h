@@ -27,3 +27,21 @@ __device__ __forceinline__ int nmfx_record_objective(DevState* st, double* obj_h
     }
     return rule;
 }
+
+// Pair mode: the same test and bookkeeping for problem p of two (objective slots 2 j + p, state in pflag / pstop_i / pn_obj).
+__device__ __forceinline__ int nmfx_record_objective_pair(DevState* st, double* obj_hist, double obj, int p, long long j,
+                                                          long long min_iter, double tol1, double tol2, bool writer)
+{
+    int rule = 0;
+    if (j >= 1 && (j - 1) > min_iter) {
+        const double prev = obj_hist[2 * (j - 1) + p];
+        if (obj < tol1) rule = 1;
+        else if (obj >= prev - tol2) rule = 2;
+    }
+    if (writer) {
+        obj_hist[2 * j + p] = obj;
+        st->pn_obj[p] = j + 1;
+        if (rule) { st->pflag[p] = rule; st->pstop_i[p] = j - 1; }
+    }
+    return rule;
+}

@@ -50,6 +50,11 @@ struct DevState {          // lives in device memory, written by kernels
     int ao_continued;      // the decide launch of the current sub-problem found no stop among the hinted rounds and went on
     int pad2;
     int ao_paths[4];       // sub-problems whose first leg stood / was cut back / was continued / was continued and cut back
+    // pair mode (two MUR-eu problems stacked into the k = 128 layouts, kernels_bf16.hip): per-problem stop state; the objective
+    // of problem p after iteration j sits at obj_hist[2 j + p]; `flag` is set once BOTH have stopped
+    int pflag[2];
+    long long pstop_i[2];
+    long long pn_obj[2];
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };
@@ -123,6 +128,8 @@ struct nmfx_engine {
     int anls_dist = NMFX_EU;       // objective ANLS reports (anls.py:108,118): the iterates are least-squares either way
     bool anls_a_ready = false;    // ANLS: A_part / H H^T slabs of the CURRENT (W, H) are valid (produced by the fused objective pass)
     int wsel = 0;                  // W buffer holding the current iterate
+    bool family_started = false;   // a MUR run has begun since nmfx_set_factors (pair mode must be chosen at its start)
+    bool pair = false;             // nmfx_mur_pair_*: factor columns [0, 64) and [64, 128) are two independent problems
     int family = 0;                // solver family that has run since nmfx_set_factors (0 none, 1 MUR eu/kl, 2 AO-ADMM, 3 ADMM, 4 ANLS): nmfx_enter_family
     bool w_in_place = false;       // solver updates W[0] in place (all but MUR, which ping-pongs)
     // profiling

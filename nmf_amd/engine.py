@@ -291,6 +291,32 @@ class Engine:
         self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
                                         float(tol2), int(first), int(count)))
 
+    # -- pair mode: two MUR-eu problems stacked into a k = 128 handle (include/nmfx.h) -----------
+    def mur_pair_run(self, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
+        lw = (C.c_double * 2)(float(lambda_w[0]), float(lambda_w[1]))
+        lh = (C.c_double * 2)(float(lambda_h[0]), float(lambda_h[1]))
+        self._ck(self.lib.nmfx_mur_pair_run(self.h, lw, lh, int(min_iter), float(tol1), float(tol2), int(first), int(count)))
+
+    def mur_pair_finish(self, min_iter, tol1, tol2, done):
+        self._ck(self.lib.nmfx_mur_pair_finish(self.h, int(min_iter), float(tol1), float(tol2), int(done)))
+
+    def pair_state(self, p):
+        a, b, c = C.c_int(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_pair_get_state(self.h, int(p), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def pair_objectives(self, p, first, count):
+        out = np.zeros(max(0, int(count)), dtype=np.float64)
+        if count > 0:
+            self._ck(self.lib.nmfx_pair_get_objectives(self.h, int(p), int(first), int(count), _ptr(out)))
+        return out
+
+    def pair_get_factors(self, p, k_p):
+        w = np.empty((self.m, k_p), dtype=np.float64)
+        h = np.empty((k_p, self.n), dtype=np.float64)
+        self._ck(self.lib.nmfx_pair_get_factors(self.h, int(p), int(k_p), _ptr(w), _ptr(h)))
+        return w, h
+
     # -- exchange buffers (row-sharded runs) ---------------------------------
     def set_exchange_rank(self, rank, world):
         """The objective partial travels inside the f32 exchange buffer (one collective per MUR-Euclidean iteration);

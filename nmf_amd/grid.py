@@ -40,6 +40,9 @@ def factorize_grid(data, method='mur', *, features, lambda_w=(0.0,), lambda_h=(0
         if lowest < 0:
             data += abs(lowest)
     out = []
+    pairs = _pairable(method, common) and os.environ.get("NMFX_GRID_PAIR", "1") != "0"
+    if pairs:
+        return _mur_eu_grid_in_pairs(data, solver, features, lambda_w, lambda_h, save_dir, device, common)
     for k in features:
         with Engine(data.shape[0], data.shape[1], k, device=device) as eng:
             eng.upload_v(data)
@@ -63,3 +66,67 @@ def factorize_grid(data, method='mur', *, features, lambda_w=(0.0,), lambda_h=(0
                     holder.results = res
                     holder.save_factorization(save_dir=save_dir)
     return out
+
+
+def _pairable(method, common):
+    return method == 'mur' and common.get('distance_type', 'kl') == 'eu'
+
+
+def _save(data, k, res, save_dir):
+    from .nmf import NMF
+    holder = NMF(data, k)
+    holder.results = res
+    holder.save_factorization(save_dir=save_dir)
+
+
+def _mur_eu_grid_in_pairs(data, solver, features, lambda_w, lambda_h, save_dir, device, common):
+    """MUR with the Euclidean loss: the combinations are taken two at a time, in the legacy driver's order, and each pair is ONE
+    run over V (nmf_amd.mur.mur_pair: two problems of k <= 64 in the halves of a k = 128 engine that stays resident for the whole
+    grid); combinations with k > 64, a combination left over, and engines on the exact-f32 path run as before.  Results, printed
+    lines and RNG consumption are those of the sequential grid."""
+    from .mur import mur_pair
+    combos = [(k, lw, lh) for k in features for lw, lh in product(lambda_w, lambda_h)]
+    out = [None] * len(combos)
+    small = [i for i, c in enumerate(combos) if c[0] <= 64]
+    pair_kw = {key: val for key, val in common.items() if key != 'distance_type'}
+    singles = {}                                               # k -> resident engine for what cannot be paired
+
+    def run_single(i):
+        k, lw, lh = combos[i]
+        if k not in singles:
+            singles[k] = Engine(data.shape[0], data.shape[1], k, device=device)
+            singles[k].upload_v(data)
+        return solver(data, k, device=device, engine=singles[k], lambda_w=lw, lambda_h=lh, **common)
+
+    big = None
+    try:
+        if len(small) >= 2:
+            big = Engine(data.shape[0], data.shape[1], 128, device=device)
+            big.upload_v(data)
+            if big.precision() != 'bf16':
+                big.close()
+                big = None
+        # walk the combinations in order; RNG draws happen in that order too
+        i = 0
+        while i < len(combos):
+            nxt = i + 1
+            if big is not None and combos[i][0] <= 64 and nxt < len(combos) and combos[nxt][0] <= 64:
+                a, b = combos[i], combos[nxt]
+                res = mur_pair(data, a[0], [dict(k=a[0], lambda_w=a[1], lambda_h=a[2]), dict(k=b[0], lambda_w=b[1], lambda_h=b[2])],
+                               engine=big, device=device, **pair_kw)
+                out[i], out[nxt] = res
+                i += 2
+            else:
+                out[i] = run_single(i)
+                i += 1
+    finally:
+        if big is not None:
+            big.close()
+        for eng in singles.values():
+            eng.close()
+    runs = []
+    for (k, lw, lh), res in zip(combos, out):
+        runs.append((dict(features=k, lambda_w=lw, lambda_h=lh), res))
+        if save_dir is not None:
+            _save(data, k, res, save_dir)
+    return runs
