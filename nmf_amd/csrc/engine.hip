@@ -45,7 +45,7 @@ static int preload_once(nmfx_engine* E) {
     std::lock_guard<std::mutex> lock(mu);
     if (done[E->device]) return NMFX_OK;
     if (nmfx_preload_bf16() || nmfx_preload_products() || nmfx_preload_mur() || nmfx_preload_kl() || nmfx_preload_aoadmm() ||
-        nmfx_preload_anls() || nmfx_preload_svd() || nmfx_preload_prox()) {
+        nmfx_preload_anls() || nmfx_preload_svd() || nmfx_preload_prox() || nmfx_preload_generic()) {
         E->err = "loading the kernels onto the device failed"; return NMFX_E_HIP; }
     hipLaunchKernelGGL(nmfx_startup_kernel, dim3(1), dim3(1), 0, 0, (int*)nullptr);
     NMFX_HIP(hipGetLastError());
@@ -134,13 +134,14 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     if (!out) { g_err = "out is NULL"; return NMFX_E_ARG; }
     *out = nullptr;
     if (m <= 0 || n <= 0 || k <= 0) { g_err = "m, n, k must be positive"; return NMFX_E_ARG; }
-    if (k > 128) { g_err = "k > 128 is not supported by this build"; return NMFX_E_ARG; }
+    if (k > 4096) { g_err = "k > 4096 is not supported"; return NMFX_E_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device"; return NMFX_E_HIP; }
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return NMFX_E_ARG; }
     nmfx_engine* E = new nmfx_engine();
     E->device = device; E->m = m; E->n = n; E->k = k;
-    E->kp = k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 128;
+    // (k > 128: a multiple of 128 -- the MUR solvers compose their iteration from the generic product kernel, kernels_generic.hip)
+    E->kp = k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : (int)round_up(k, 128);
     // 128: the split-bf16 kernel works on 128-row blocks of V and of V^T; the f32 kernels need 64
     E->mp = round_up(m, 2 * NMFX_TILE); E->np = round_up(n, 2 * NMFX_TILE);
     auto fail = [&](int rc) { g_err = E->err; nmfx_destroy(E); return rc; };
@@ -221,7 +222,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
-                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk};
+                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -373,7 +374,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->himg_both = false;
     E->lazy_objective = false;
     E->anls_a_ready = false;
-    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if (E->kp <= 128 && (rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;
 }
@@ -561,6 +562,7 @@ int nmfx_mur_phase_a(nmfx_handle_t E, int distance, double lambda_w, int64_t j) 
     if (!E) return NMFX_E_ARG;
     if (distance != NMFX_KL) E->kl_h_iter = -2;
     int rc = check_ready(E, j, 1); if (rc) return rc;
+    if (E->kp > 128 && (distance == NMFX_EU || distance == NMFX_KL)) return nmfx_generic_mur_phase_a(E, distance, lambda_w, j);
     if (distance == NMFX_EU)
         return (E->precision == 1 && nmfx_bf16_supported(E)) ? nmfx_mur_eu_phase_a_bf16(E, lambda_w, j)
                                                              : nmfx_mur_eu_phase_a(E, lambda_w, j);
@@ -605,6 +607,7 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
     int rc = check_ready(E, j, 1); if (rc) return rc;
     E->wsel = (int)((j + 1) & 1);
     E->w_in_place = false;
+    if (E->kp > 128 && (distance == NMFX_EU || distance == NMFX_KL)) return nmfx_generic_mur_phase_b(E, distance, lambda_h, min_iter, tol1, tol2, j);
     if (distance == NMFX_EU)
         return (E->precision == 1 && nmfx_bf16_supported(E))
                    ? nmfx_mur_eu_phase_b_bf16(E, lambda_h, min_iter, tol1, tol2, j)
@@ -619,6 +622,7 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
 int nmfx_mur_finish_a(nmfx_handle_t E, int distance, int64_t j) {
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;
+    if (E->kp > 128 && (distance == NMFX_EU || distance == NMFX_KL)) return nmfx_generic_mur_finish_a(E, distance, j);
     if (distance == NMFX_EU) return nmfx_mur_eu_finish_a(E, j);
     if (distance == NMFX_KL) return nmfx_mur_kl_finish_a(E, j);
     E->err = "Unknown distance type."; return NMFX_E_ARG;

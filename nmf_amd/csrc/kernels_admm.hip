@@ -189,6 +189,7 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
     if (!(rho != 0.0)) { E->err = "prox_apply: rho must not be zero"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_small_k_only(E, "prox_apply"))) return rc;
     if ((rc = admm_alloc(E))) return rc;
     E->wsel = 0; E->w_in_place = true;
     return nmfx_launch_prox_l1inf(E, side == 1, prox == NMFX_PROX_L1INF_T, rho, lambda, 1.0, update_dual != 0);
@@ -209,6 +210,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
     if (first < 0 || count < 0 || !(rho >= 0.0)) { E->err = "negative iteration range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_small_k_only(E, "ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 3))) return rc;
     if ((rc = admm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;

@@ -866,7 +866,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0 || lam < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
-    { int rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
+    { int rc_ = nmfx_small_k_only(E, "ANLS"); if (rc_) return rc_; rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
     NMFX_HIP(hipSetDevice(E->device));
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
@@ -914,6 +914,7 @@ extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, 
     if (first < 0 || count < 0 || lambda_w < 0 || lambda_h < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_small_k_only(E, "ANLS"))) return rc;
     if ((rc = nmfx_enter_family(E, 4))) return rc;
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));

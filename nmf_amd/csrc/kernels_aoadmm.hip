@@ -1614,6 +1614,7 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
+    if ((rc = nmfx_small_k_only(E, "AO-ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -1642,6 +1643,7 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
+    if ((rc = nmfx_small_k_only(E, "AO-ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;

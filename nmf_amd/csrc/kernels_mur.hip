@@ -264,10 +264,10 @@ int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const 
     return NMFX_OK;
 }
 
-int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj) {
+int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj, const double* src) {
     ProfScope ps(E, "small");
     if (nobj <= 0) nobj = E->obj_count > 0 ? E->obj_count : (int64_t)(E->mp / 64) * E->wsplit;
-    hipLaunchKernelGGL(obj_reduce_kernel, dim3(1), dim3(256), 0, E->stream, E->obj_part, nobj, E->xf64,
+    hipLaunchKernelGGL(obj_reduce_kernel, dim3(1), dim3(256), 0, E->stream, src ? src : (const double*)E->obj_part, nobj, E->xf64,
                        &E->state->flag);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

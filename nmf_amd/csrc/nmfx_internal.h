@@ -84,6 +84,10 @@ struct nmfx_engine {
     float* xf32 = nullptr;         // exchange: [kp*np | kp*kp | kp]
     double* xf64 = nullptr;        // exchange: [8] = objective partial, 4 inner-loop norm sums, 3 spare
     bool own_x = true;
+    // k > 128 (kernels_generic.hip): objective partials per 128 x 128 tile, an m x kp / kp x n scratch, split-product slabs
+    double* gx_part = nullptr;
+    float* gx_d = nullptr;
+    float* gx_s = nullptr;
     struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
@@ -172,7 +176,7 @@ int nmfx_launch_h_update(nmfx_engine* E, float lam, int64_t j, int64_t min_iter,
 int nmfx_launch_pack(nmfx_engine* E, const int* flag2 = nullptr);   // xf32 = [sum B_part | sum G_part], xf64[0] = sum obj_part
 int nmfx_launch_pack_from(nmfx_engine* E, const float* Bpart, int bsplit, const float* Gpart, int gsplit,
                           int64_t nobj);
-int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj = 0);    // xf64[0] = sum obj_part (nobj 0: the f32 W phase's count)
+int nmfx_launch_obj_reduce(nmfx_engine* E, int64_t nobj = 0, const double* src = nullptr);    // xf64[0] = sum obj_part (nobj 0: the f32 W phase's count)
 bool nmfx_bf16_supported(const nmfx_engine* E);
 inline int nmfx_bf16_hht_slabs(const nmfx_engine* E) { return E->gram_ng_w * E->bf_wsplit; }   // H H^T by-product slabs
 inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt_split; }      // W^T W by-product slabs
@@ -206,6 +210,17 @@ inline int nmfx_enter_family(nmfx_engine* E, int fam) {
 }
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
 void nmfx_comm_free(nmfx_engine* E);      // comm.hip
+// kernels_generic.hip: MUR for k > 128 (kp a multiple of 128), same phase protocol
+int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j);
+int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j);
+int nmfx_preload_generic();
+// the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
+inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {
+    if (E->kp <= 128) return NMFX_OK;
+    E->err = std::string(what) + ": more than 128 components are supported by the MUR solvers only in this build";
+    return NMFX_E_ARG;
+}
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);
 
 // AO-ADMM / ADMM building blocks (kernels_aoadmm.hip)

@@ -33,8 +33,9 @@ def test_error_codes_without_device():
     import ctypes as C
     h = C.c_void_p()
     assert lib.nmfx_create(C.byref(h), 0, 8, 8, 2) == _lib.NMFX_E_HIP
-    assert lib.nmfx_create(C.byref(h), 0, 8, 8, 500) == _lib.NMFX_E_ARG
-    assert b"k > 128" in lib.nmfx_last_error(None)
+    assert lib.nmfx_create(C.byref(h), 0, 8, 8, 5000) == _lib.NMFX_E_ARG
+    assert b"k > 4096" in lib.nmfx_last_error(None)
+    assert lib.nmfx_create(C.byref(h), 0, 8, 8, 500) == _lib.NMFX_E_HIP          # (k > 128 is a valid request: MUR runs it)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -1,0 +1,74 @@
+"""More than 128 components (missing 1): the reference takes any `factors` (nmf/nmf.py:32-35, nmf/mur.py:52).
+MUR (both divergences) composes its iteration from the generic exact-f32 product kernel (kernels_generic.hip) beyond k = 128."""
+import numpy as np
+import pytest
+
+from gpu_common import WH_TOL, direct_objective, wh_error, wh_error_blocked
+from oracle import nmf_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,k", [((520, 700), 160), ((640, 520), 256), ((400, 900), 300)])
+@pytest.mark.parametrize("distance", ["eu", "kl"])
+def test_mur_beyond_128_components_vs_oracle(shape, k, distance):
+    from nmf_amd.mur import mur
+    m, n = shape
+    v = R.planted_matrix(m, n, 24, seed=m + k, dtype=np.float32)
+    kw = dict(distance_type=distance, min_iter=20, max_iter=20, lambda_w=0.02, lambda_h=0.01)
+    np.random.seed(5)
+    res = mur(v.copy(), k, **kw)
+    np.random.seed(5)
+    ref = R.mur(v.astype(np.float64), k, **kw)
+    assert res.w.shape == (m, k) and res.h.shape == (k, n)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)
+
+
+def test_mur_eu_k160_stop_rule_and_negative_data():
+    """k = 160 with the stop rule firing (same index and rule as the oracle) on data with negative entries (lifted in place,
+    nmf/mur.py:99-101)."""
+    from nmf_amd.mur import mur
+    v = R.planted_matrix(300, 260, 36, seed=77, dtype=np.float32) - 0.05
+    kw = dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-9, tol2=2e-2)
+    a, b = v.copy(), v.astype(np.float64)
+    np.random.seed(3)
+    res = mur(a, 160, **kw)
+    np.random.seed(3)
+    ref = R.mur(b, 160, **kw)
+    assert a.min() >= 0 and ref.trace["stop_rule"] == 2 and ref.i < 399
+    assert abs(res.i - ref.i) <= 1 and len(res.obj_history) == res.i + 2
+    if res.i == ref.i:
+        assert wh_error(res.w, res.h, ref.w, ref.h, b) < WH_TOL
+
+
+def test_other_solvers_say_so_beyond_128_components():
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.anls import anls
+    from nmf_amd.ao_admm import ao_admm
+    v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
+    for call in (lambda: ao_admm(v.copy(), 160, reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
+                 lambda: anls(v.copy(), 160, max_iter=2, nndsvd_init=(False, "zero"))):
+        with pytest.raises(NmfxError, match="more than 128 components"):
+            call()
+
+
+def test_mur_eu_16384x8192_k256_vs_oracle():
+    """The config-2 matrix with k = 256: 3 outer iterations against the f64 oracle (~ 1 s of host GEMMs per iteration at this k)."""
+    from nmf_amd.mur import mur
+    m, n, k, iters = 16384, 8192, 256, 3
+    v = R.planted_matrix(m, n, 64, seed=0, dtype=np.float32)
+    kw = dict(distance_type="eu", min_iter=iters, max_iter=iters)
+    np.random.seed(0)
+    res = mur(v, k, **kw)
+    np.random.seed(0)
+    ref = R.mur(v, k, **kw)
+    assert res.i == ref.i == iters - 1
+    err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
+    assert err < WH_TOL, err
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-5)
+    direct = direct_objective(v, res.w, res.h, "eu")
+    assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
