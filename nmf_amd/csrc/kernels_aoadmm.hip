@@ -1614,7 +1614,7 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
-    if ((rc = nmfx_small_k_only(E, "AO-ADMM"))) return rc;
+    if (distance != NMFX_EU && (rc = nmfx_small_k_only(E, "AO-ADMM with the KL loss"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -1622,6 +1622,8 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
     E->wsel = 0;
     E->w_in_place = true;
+    if (E->kp > 128)           // composed from the generic product kernel (kernels_generic.hip)
+        return nmfx_generic_aoadmm_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count);
     if (distance != NMFX_EU) { E->lazy_objective = false; E->himg_both = false; }
     if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
         if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
@@ -1813,7 +1815,7 @@ extern "C" int nmfx_aoadmm_finish(nmfx_handle_t E, int64_t min_iter, double tol1
     if (!E) return NMFX_E_ARG;
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
-    if ((rc = ao_final_objective(E))) return rc;
+    if (E->kp <= 128 && (rc = ao_final_objective(E))) return rc;      // (k > 128: the run left the objective partial in place)
     return nmfx_finish_b(E, min_iter, tol1, tol2, done);
 }
 

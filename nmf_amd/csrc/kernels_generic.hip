@@ -65,9 +65,10 @@ __device__ __forceinline__ void gx_store(float* __restrict__ plane, int tid, con
 template <bool AK, bool BK, int MODE>
 __global__ __launch_bounds__(256) void gx_gemm_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    int64_t cstride, int64_t K, const float* __restrict__ X, int64_t ldx, double* __restrict__ part, const int* __restrict__ flag)
+    int64_t cstride, int64_t K, const float* __restrict__ X, int64_t ldx, double* __restrict__ part, const int* __restrict__ flag,
+    const int* __restrict__ flag2)
 {
-    if (*flag) return;
+    if (*flag || (flag2 && *flag2)) return;
     __shared__ __attribute__((aligned(16))) float lds[2][2][GX_KC * GX_LD];        // [buffer][A / B][k][row]
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
@@ -244,12 +245,12 @@ int gx_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
 
 template <bool AK, bool BK>
 int gx_launch(nmfx_engine* E, int mode, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t cstride,
-              int64_t M, int64_t N, int64_t K, int S, const float* X, int64_t ldx, double* part) {
+              int64_t M, int64_t N, int64_t K, int S, const float* X, int64_t ldx, double* part, const int* flag2 = nullptr) {
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
-    if (mode == GX_STORE) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_STORE>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag);
-    else if (mode == GX_RESID) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_RESID>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag);
-    else hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_KLQ>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag);
+    if (mode == GX_STORE) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_STORE>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    else if (mode == GX_RESID) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_RESID>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    else hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_KLQ>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -369,6 +370,209 @@ int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j) {
       else rc = gx_launch<true, false>(E, GX_KLQ, E->W[j & 1], kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       if (rc) return rc; }
     return nmfx_launch_obj_reduce(E, nblk, E->gx_part);
+}
+
+// ---- AO-ADMM, least-squares loss, prox nn / l1n (nmf/ao_admm.py:46-68, 113-124, 33-43, 259-292) for k > 128 -------------------------
+namespace {
+
+// rho = trace(G) / k, M^-1 = (G + rho I)^-1 (ao_admm.py:53-55, 59: cholesky + cho_solve) by an in-place Gauss-Jordan inversion in
+// f64 without pivoting (the matrix is positive definite: a pivot <= 0 is the reference's LinAlgError -> st->notpd), one workgroup,
+// the matrix in a global f64 work area (L2-resident), pivot row and column through LDS, two barriers per pivot.  fixed_rho >= 0
+// replaces trace / k.  Also opens the sub-problem: inner_stop = inner_count = 0.
+__global__ __launch_bounds__(1024) void gx_prepare_kernel(const float* __restrict__ G, int kp, int k, double* __restrict__ work,
+                                                          float* __restrict__ Minv, DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    extern __shared__ double gsh[];                    // row [kp] | col [kp] | 16 partials
+    double* prow = gsh;
+    double* pcol = gsh + kp;
+    double* part = pcol + kp;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double tr = 0.0;
+    for (int i = tid; i < k; i += nt) tr += (double)G[(int64_t)i * kp + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = tr;
+    __syncthreads();
+    double rho = 0.0;
+    for (int w = 0; w < nt / 64; ++w) rho += part[w];
+    rho /= (double)k;
+    const int64_t kk = (int64_t)kp * kp;
+    for (int64_t e = tid; e < kk; e += nt) work[e] = (double)G[e] + ((e / kp) == (e % kp) ? rho : 0.0);
+    __syncthreads();
+    int bad = 0;
+    for (int p = 0; p < kp; ++p) {
+        for (int i = tid; i < kp; i += nt) { prow[i] = work[(int64_t)p * kp + i]; pcol[i] = work[(int64_t)i * kp + p]; }
+        __syncthreads();
+        const double d = prow[p];
+        if (!(d > 0.0)) bad = 1;
+        const double inv = 1.0 / d;
+        for (int64_t e = tid; e < kk; e += nt) {
+            const int i = (int)(e / kp), j = (int)(e % kp);
+            double v;
+            if (i == p) v = (j == p) ? inv : prow[j] * inv;
+            else v = (j == p) ? -pcol[i] * inv : work[e] - pcol[i] * (prow[j] * inv);
+            work[e] = v;
+        }
+        __syncthreads();
+    }
+    for (int64_t e = tid; e < kk; e += nt) Minv[e] = (float)work[e];
+    if (tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; if (bad) st->notpd = 1; }
+}
+
+// rhs = B + rho (X + U)   (ao_admm.py:59, the argument of cho_solve)
+__global__ __launch_bounds__(256) void gx_rhs_kernel(const float* __restrict__ B, const float* __restrict__ X, const float* __restrict__ U,
+                                                     float* __restrict__ rhs, int64_t count4, const DevState* __restrict__ st)
+{
+    if (st->flag || st->inner_stop) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count4) return;
+    const float rho = (float)st->rho;
+    const float4 b = reinterpret_cast<const float4*>(B)[i], x = reinterpret_cast<const float4*>(X)[i], u = reinterpret_cast<const float4*>(U)[i];
+    reinterpret_cast<float4*>(rhs)[i] = make_float4(b.x + rho * (x.x + u.x), b.y + rho * (x.y + u.y), b.z + rho * (x.z + u.z), b.w + rho * (x.w + u.w));
+}
+
+// X = prox(aux, U); U += X - aux; the four sums of squares `terminate` needs (ao_admm.py:60-62, 33-43): part[block][4]
+__global__ __launch_bounds__(256) void gx_prox_kernel(const float* __restrict__ aux, float* __restrict__ X, float* __restrict__ U, int prox, float lam,
+                                                      int64_t count4, double* __restrict__ part, const DevState* __restrict__ st)
+{
+    if (st->flag || st->inner_stop) return;
+    __shared__ double sh[4][4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+    if (i < count4) {
+        const float4 a4 = reinterpret_cast<const float4*>(aux)[i], x4 = reinterpret_cast<const float4*>(X)[i], u4 = reinterpret_cast<const float4*>(U)[i];
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w};
+        float xn[4], un[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = (av[e] - uv[e]) - shift;
+            xn[e] = (d < 0.f) ? 0.f : d;
+            un[e] = uv[e] + xn[e] - av[e];
+            const float d0 = xn[e] - av[e], d2 = xn[e] - xv[e];
+            n0 += d0 * d0; n1 += xn[e] * xn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
+        }
+        reinterpret_cast<float4*>(X)[i] = make_float4(xn[0], xn[1], xn[2], xn[3]);
+        reinterpret_cast<float4*>(U)[i] = make_float4(un[0], un[1], un[2], un[3]);
+    }
+    double v[4] = {(double)n0, (double)n1, (double)n2, (double)n3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[(int64_t)blockIdx.x * 4 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// terminate (ao_admm.py:33-43) on the sums of this round: ||X - aux|| / ||X|| < 1e-2 and ||X - X_prev|| / ||U|| < 1e-2, as
+// a < 1e-4 b on the sums of squares (a zero denominator gives inf / nan in the reference: both compare False, as here)
+__global__ __launch_bounds__(256) void gx_decide_kernel(const double* __restrict__ part, int nblk, DevState* __restrict__ st)
+{
+    if (st->flag || st->inner_stop) return;
+    __shared__ double sh[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = tid; b < nblk; b += 256)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += part[(int64_t)b * 4 + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if (lane == 0) sh[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double n[4];
+        for (int c = 0; c < 4; ++c) n[c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+        st->inner_count += 1;
+        if (n[0] < 1e-4 * n[1] && n[2] < 1e-4 * n[3]) st->inner_stop = 1;
+    }
+}
+
+// end of a sub-problem: rounds run | fired << 16 (the slot nmfx_get_inner_counts reads)
+__global__ void gx_close_kernel(DevState* __restrict__ st, int32_t* __restrict__ slot)
+{
+    if (st->flag) return;
+    *slot = st->inner_count | (st->inner_stop << 16);
+    st->inner_stop = 0;
+}
+
+// one sub-problem (ao_admm.py:46-68) on the factor X ([rows][cols] with the factor index along `cols` for W: rows = m,
+// cols = kp -- or along `rows` for H: rows = kp, cols = n), its dual U, the Gram matrix G and the cross product B
+int gx_ao_subproblem(nmfx_engine* E, bool hside, const float* G, const float* B, float* X, float* U, int prox, float lam, int admm_iter,
+                     int32_t* slot) {
+    int rc;
+    const int64_t kp = E->kp, rows = hside ? kp : E->mp, cols = hside ? E->np : kp, cnt4 = rows * cols / 4;
+    const size_t shm = (size_t)(2 * kp + 16) * sizeof(double);
+    { ProfScope ps(E, "prepare");
+      if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gx_prepare_kernel), (int)shm))) return rc;
+      hipLaunchKernelGGL(gx_prepare_kernel, dim3(1), dim3(1024), shm, E->stream, G, (int)kp, E->k, E->gx_w64, E->Minv, E->state);
+      NMFX_HIP(hipGetLastError()); }
+    ProfScope ps(E, hside ? "inner_h" : "inner_w");
+    const int nblk = (int)((cnt4 + 255) / 256);
+    const int* stop = &E->state->inner_stop;
+    for (int r = 0; r < admm_iter; ++r) {
+        hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, B, (const float*)X, (const float*)U, E->gx_r, cnt4,
+                           (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        if (hside) rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, cols, E->gx_d, cols, 0, kp, cols, kp, 1, nullptr, 0, nullptr, stop);
+        else rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->gx_d, kp, 0, rows, kp, kp, 1, nullptr, 0, nullptr, stop);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, X, U, prox, lam, cnt4, E->gx_nrm,
+                           (const DevState*)E->state);
+        hipLaunchKernelGGL(gx_decide_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->state);
+        NMFX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gx_close_kernel, dim3(1), dim3(1), 0, E->stream, E->state, slot);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int gx_objective_partial(nmfx_engine* E) {            // 1/2 ||V - W H||^2 of the current pair -> xf64[0]
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    { ProfScope ps(E, "objective");
+      if ((rc = gx_launch<true, false>(E, GX_RESID, E->W[0], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
+    return nmfx_launch_obj_reduce(E, (mp / GX_T) * (np / GX_T), E->gx_part);
+}
+
+}  // namespace
+
+int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
+                            double tol1, double tol2, int64_t first, int64_t count) {
+    int rc;
+    if ((rc = gx_buffers(E, false))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if ((rc = gx_alloc(E, &E->gx_r, std::max(mp, np) * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_w64, kp * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_nrm, std::max(mp, np) * kp / 1024 * 4 + 64))) return rc;
+    float* W = E->W[0];
+    float* xB = E->xf32;
+    float* xG = E->xf32 + kp * np;
+    if (first == 0 && count > 0 && (rc = gx_objective_partial(E))) return rc;      // obj[0] (ao_admm.py:256)
+    for (int64_t j = first; j < first + count; ++j) {
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        // H sub-problem: G = W^T W, B = W^T V
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");
+          if ((rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
+        if ((rc = gx_ao_subproblem(E, true, xG, xB, E->H, E->dualH, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2))) return rc;
+        // W sub-problem on the transposed data: G = H H^T, B^T = V H^T
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");
+          if ((rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1))) return rc; }
+        if ((rc = gx_ao_subproblem(E, false, E->HHt, E->A_part, W, E->dualW, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+        if ((rc = gx_objective_partial(E))) return rc;
+    }
+    return NMFX_OK;
 }
 
 int nmfx_preload_generic() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gx_record_kernel)) == hipSuccess ? 0 : -1; }

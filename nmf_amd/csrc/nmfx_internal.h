@@ -88,6 +88,9 @@ struct nmfx_engine {
     double* gx_part = nullptr;
     float* gx_d = nullptr;
     float* gx_s = nullptr;
+    float* gx_r = nullptr;         // AO-ADMM for k > 128: right-hand side of a round
+    double* gx_w64 = nullptr;      // ... the f64 work matrix of the Gauss-Jordan inversion
+    double* gx_nrm = nullptr;      // ... norm partials of a round
     struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
@@ -214,6 +217,8 @@ void nmfx_comm_free(nmfx_engine* E);      // comm.hip
 int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j);
 int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j);
+int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
+                            double tol1, double tol2, int64_t first, int64_t count);
 int nmfx_preload_generic();
 // the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
 inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {

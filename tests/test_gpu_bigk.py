@@ -43,12 +43,30 @@ def test_mur_eu_k160_stop_rule_and_negative_data():
         assert wh_error(res.w, res.h, ref.w, ref.h, b) < WH_TOL
 
 
+@pytest.mark.parametrize("shape,k,regs", [((520, 700), 160, ((0.1, "l1n"), (0.05, "l1n"))), ((640, 520), 256, ((0.02, "l1n"), (0, "nn")))])
+def test_aoadmm_beyond_128_components_vs_oracle(shape, k, regs):
+    """AO-ADMM (least-squares loss, nn / l1n) for k > 128: Gram systems by an f64 Gauss-Jordan inversion, the rounds of
+    nmf/ao_admm.py:59-64 one by one with the stop test on the device; inner round counts equal to the oracle's."""
+    from nmf_amd.ao_admm import ao_admm
+    m, n = shape
+    v = R.planted_matrix(m, n, 24, seed=m + k, dtype=np.float32)
+    kw = dict(distance_type="eu", reg_w=regs[0], reg_h=regs[1], min_iter=6, max_iter=6, admm_iter=8, nndsvd_init=(True, "zero"))
+    res = ao_admm(v.copy(), k, **kw)
+    ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2
+    assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)
+
+
 def test_other_solvers_say_so_beyond_128_components():
     from nmf_amd._lib import NmfxError
+    from nmf_amd.admm import admm
     from nmf_amd.anls import anls
     from nmf_amd.ao_admm import ao_admm
     v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
-    for call in (lambda: ao_admm(v.copy(), 160, reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
+    for call in (lambda: admm(v.copy(), 160, reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
+                 lambda: ao_admm(v.copy(), 160, distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
                  lambda: anls(v.copy(), 160, max_iter=2, nndsvd_init=(False, "zero"))):
         with pytest.raises(NmfxError, match="more than 128 components"):
             call()
