@@ -333,7 +333,8 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
         torch.cuda.empty_cache()
 
 
-def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None):
+def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None,
+                 precision=None, bound="hbm"):
     """One of BASELINE.json's non-headline single-GPU configs: iterations/s over `steps` steps after `warmup`,
     per-kernel device times (HIP events on the engine's stream, separate pass), the algorithmic work per
     iteration and the dominant kernel against the HBM roofline."""
@@ -342,7 +343,9 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
     t_all = time.perf_counter()
     eng = Engine(m, n, k, device=dev.index or 0)
     try:
-        device_planted(eng, torch, m, n, k, 0, dev)
+        if precision:
+            eng.set_precision(precision)
+        device_planted(eng, torch, m, n, min(k, 128), 0, dev)
         rs = np.random.RandomState(0)
         if init == "randn":                      # nmf/mur.py:108-109
             w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
@@ -396,9 +399,14 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                 "warmup": warmup, "precision": eng.precision(), "host_ms_to_queue_all_steps": t_queued * 1e3,
                 "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
-                "dominant_kernel": {"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
-                                    "algorithmic_bytes_per_launch": m * n * 4.0, "bound": "hbm",
-                                    "achieved_gbs": m * n * 4.0 / dsec / 1e9, "frac": m * n * 4.0 / dsec / 1e9 / PEAK_HBM_GBS},
+                "dominant_kernel": ({"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
+                                     "algorithmic_bytes_per_launch": m * n * 4.0, "bound": "hbm",
+                                     "achieved_gbs": m * n * 4.0 / dsec / 1e9, "frac": m * n * 4.0 / dsec / 1e9 / PEAK_HBM_GBS}
+                                    if bound == "hbm" else
+                                    {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (f32 inputs)",
+                                     "tflops": 2.0 * m * n * (-(-k // 128) * 128 if k > 128 else k) / dsec / 1e12,
+                                     "peak_tflops": PEAK_F32_MFMA_TFLOPS,
+                                     "frac": 2.0 * m * n * (-(-k // 128) * 128 if k > 128 else k) / dsec / 1e12 / PEAK_F32_MFMA_TFLOPS}),
                 "mean_inner_rounds_h_w": inner, "inner_first_leg_stood_cut_continued_both": paths, "objective_first_last": [float(obj[0]), float(obj[-1])],
                 "kernels": prof, "data": "synthetic, drawn on the device (torch generator, seed 0)",
                 "wall_s_incl_setup": round(time.perf_counter() - t_all, 1)}
@@ -437,6 +445,17 @@ def other_configs(torch, dev, only=None):
              m=16384, n=8192, k=64, steps=10, warmup=4, init="rand",
              queue=lambda e, f, c: e.anls_run(0.0, 0.0, NEVER, 1e-3, 1e-3, f, c),
              flops=6.0 * 16384 * 8192 * 64, nbytes=3.0 * 16384 * 8192 * 4),
+        # the headline config in the exact-f32 arithmetic (NMFX_PRECISION=f32: f32-input MFMA, bit-exact FMA chains): MFMA-bound
+        dict(name="cfg2_exact_f32", workload="MUR Euclidean, V=16384x8192 f32, k=64 with the exact-f32 products (NMFX_PRECISION=f32)",
+             m=16384, n=8192, k=64, steps=20, warmup=3, init="randn", precision="f32", bound="mfma",
+             queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
+             flops=4.0 * 16384 * 8192 * 64 + 4.0 * 64 * 64 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 64 * 4),
+        # beyond 128 components (nmf/nmf.py:32-35 takes any `factors`): the iteration composed from the generic exact-f32 product
+        # kernel (kernels_generic.hip)
+        dict(name="mur_k256_on_cfg2_shape", workload="MUR Euclidean, V=16384x8192 f32, k=256 (generic exact-f32 path for k > 128)",
+             m=16384, n=8192, k=256, steps=10, warmup=2, init="randn", bound="mfma",
+             queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
+             flops=4.0 * 16384 * 8192 * 256 + 4.0 * 256 * 256 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 256 * 4),
     ]
     for sp in specs:
         if only and sp["name"] not in only:
@@ -446,7 +465,71 @@ def other_configs(torch, dev, only=None):
         except Exception as e:  # noqa: BLE001
             out.append({"config": sp["name"], "error": f"{type(e).__name__}: {e}"})
         torch.cuda.empty_cache()
+    if not only or "pair_on_cfg2_shape" in only:
+        try:
+            out.append(pair_config(torch, dev))
+        except Exception as e:  # noqa: BLE001
+            out.append({"config": "pair_on_cfg2_shape", "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
     return out
+
+
+def pair_config(torch, dev, steps=40, warmup=5):
+    """SURVEY 8 f4, the parameter grid of the reference's author (nmf/nmf_old.py:52-66): two MUR-Euclidean problems (k = 64 each,
+    different lambda and start) on the config-2 matrix, as ONE pass over V per half-iteration (nmfx_mur_pair_run) against the same
+    two problems one after the other on a k = 64 engine."""
+    from nmf_amd.engine import Engine
+    m, n, k = M, N, K
+    NEVER = 10 ** 12
+    rs = np.random.RandomState(0)
+    starts = [(np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))) for _ in range(2)]
+    lws, lhs = [0.0, 0.1], [0.0, 0.05]
+    single = []
+    with Engine(m, n, k, device=dev.index or 0) as e:
+        device_planted(e, torch, m, n, k, 0, dev)
+        for (w0, h0), lw, lh in zip(starts, lws, lhs):
+            e.set_factors(w0, h0)
+            e.mur_run(0, lw, lh, NEVER, 1e-5, 1e-5, 0, 200)          # clocks + pools
+            e.synchronize()
+            e.set_factors(w0, h0)
+            e.mur_run(0, lw, lh, NEVER, 1e-5, 1e-5, 0, warmup)
+            e.synchronize()
+            t0 = time.perf_counter()
+            e.mur_run(0, lw, lh, NEVER, 1e-5, 1e-5, warmup, steps)
+            e.synchronize()
+            single.append((time.perf_counter() - t0) / steps)
+    with Engine(m, n, 128, device=dev.index or 0) as e:
+        device_planted(e, torch, m, n, k, 0, dev)
+        w0 = np.concatenate([starts[0][0], starts[1][0]], axis=1)
+        h0 = np.concatenate([starts[0][1], starts[1][1]], axis=0)
+        e.set_factors(w0, h0)
+        e.mur_pair_run(lws, lhs, NEVER, 1e-5, 1e-5, 0, 200)
+        e.synchronize()
+        e.set_factors(w0, h0)
+        e.mur_pair_run(lws, lhs, NEVER, 1e-5, 1e-5, 0, warmup)
+        e.synchronize()
+        t0 = time.perf_counter()
+        e.mur_pair_run(lws, lhs, NEVER, 1e-5, 1e-5, warmup, steps)
+        e.synchronize()
+        pair = (time.perf_counter() - t0) / steps
+        objs = [e.pair_objectives(p, 0, warmup + steps) for p in (0, 1)]
+        assert all(np.all(np.isfinite(o)) and o[-1] < o[0] for o in objs), "pair: bad objective history"
+        e.profile_enable(True)
+        e.profile_reset()
+        e.mur_pair_run(lws, lhs, NEVER, 1e-5, 1e-5, warmup + steps, 4)
+        e.synchronize()
+        prof = {}
+        for kn in ALL_KERNELS:
+            ms, cnt = e.profile_get(kn)
+            if cnt:
+                prof[kn] = {"us_per_launch": round(ms / cnt * 1e3, 2), "launches_per_iter": cnt / 4}
+    return {"config": "pair_on_cfg2_shape",
+            "workload": f"two MUR-Euclidean problems (k = {k} each, lambda_w = {lws}, lambda_h = {lhs}, separate |randn| starts) on V={m}x{n}: "
+                        "one pass over V per half-iteration for both (k = 128 layouts) vs one after the other",
+            "ms_per_iteration_of_the_pair": pair * 1e3, "ms_per_iteration_single": [s_ * 1e3 for s_ in single],
+            "problem_iterations_per_s_paired": 2.0 / pair, "problem_iterations_per_s_sequential": 2.0 / sum(single),
+            "speedup_per_problem": sum(single) / pair, "kernels": prof,
+            "data": "synthetic, drawn on the device (torch generator, seed 0)"}
 
 
 def self_launch(args):
