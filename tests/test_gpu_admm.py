@@ -47,6 +47,11 @@ def test_admm_eu_k64_k128_both_precisions_vs_oracle(precision, shape, reg_h, mon
     res = admm(v.copy(), k, **kw)
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
     assert res.i == ref.i and len(res.obj_history) == len(ref.obj_history)
+    # The objective of a small residual is far more sensitive than WH: d(obj) / obj <= 2 ||dWH|| / ||V - WH||, and ||V - WH|| is
+    # 3.3 % of ||V|| here, so the measured 2.4e-4 (split bf16) / 1.1e-4 (exact f32) IS a WH error of 7e-6 .. 1e-5 (asserted
+    # above at north_star's 1e-4).  tools/lab/admm_f32_state.py: with rho fixed at 1 the systems are as ill-conditioned as the
+    # Gram matrix, and ALL-f32 arithmetic in numpy (f64 everywhere else) already moves the objective by 2.3e-4 -- the f32
+    # accumulation of the V-sized products (1.8e-4 alone) and of M^-1 rhs (9e-5), not a defect of a kernel.
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
 
 

@@ -56,7 +56,7 @@ def test_anls_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
     err = np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
     assert err < 1e-4, err
     assert res.i == ref.i
-    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)      # (measured: 7.6e-5 split bf16, 5.0e-5 exact f32)
 
 
 @pytest.mark.parametrize("k", [6, 40, 100])

@@ -320,7 +320,7 @@ def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
         assert any(t[1] < 10 for t in ref.trace["inner"]), "case must exercise the repair launch of the W sub-problem"
     for p in parts:
         assert int(p["i"]) == ref.i
-        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-5 if solver in ("admm_kl", "ao_admm_kl") else 3e-4)      # (measured: 3.5e-6 / 6.1e-5, the ANLS cases)
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=5e-5 if solver in ("admm_kl", "ao_admm_kl") else 3e-4 if solver.startswith("admm") else 1e-4)      # (measured: 4e-6 KL; 6.1e-5 ADMM, see test_gpu_admm.py; 2e-5 the others)
         np.testing.assert_array_equal(p["h"], h)
         if solver.startswith("ao_admm"):
             assert [tuple(r) for r in p["inner"]] == [tuple(t) for t in ref.trace["inner"]]
