@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo"); os.environ["NMF_AMD_QUIET"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np
 from nmf_amd.synth import planted_matrix
 from nmf_amd.engine import Engine
