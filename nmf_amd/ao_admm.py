@@ -7,14 +7,16 @@ system and up to `admm_iter` inner rounds (ao_admm.py:46-68) -- runs on the
 device through libnmfx (nmfx_aoadmm_run); the inner stop test (ao_admm.py:33-43)
 is evaluated on the device too.
 
-Regularisers: 'nn' and 'l1n' are built.  'l2n' raises ValueError exactly like
-the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it
-is also the reference's DEFAULT reg_h, so callers must pass reg_h explicitly);
-'l1inf' / 'l1inf_transpose' raise numpy.linalg.LinAlgError like the reference:
-its ao_admm copy of the operator (nmf/ao_admm.py:143-195) divides by a zero
-count in the first sub-problem and the Cholesky factorisation of the next one
-fails ("leading minor not positive definite"; probed for all four placements).
-The working copy of the operator is ADMM's (nmf_amd.admm)."""
+Regularisers: 'nn' and 'l1n' are built (any number of components; beyond 128 with the least-squares loss only).  'l2n' raises
+ValueError exactly like the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it is also the reference's
+DEFAULT reg_h, so callers must pass reg_h explicitly).  'l1inf' / 'l1inf_transpose' raise numpy.linalg.LinAlgError up front:
+the reference's ao_admm copy of the operator (nmf/ao_admm.py:143-195) makes the iteration blow up until a Cholesky
+factorisation fails ("leading minor not positive definite").  DEVIATION: as `reg_h` that happens in the first outer
+iteration of the reference too; as `reg_w` (with a well-behaved `reg_h`) the reference first completes some outer iterations --
+printing their `[i]: objective` lines, and with a small `max_iter` even returning a Results -- before the same exception at an
+iteration between 3 and 60 that depends on rounding.  This port does not reproduce those diverging iterates (their values are
+an amplification of rounding differences, DESIGN.md 4c'); it raises the reference's exception type before the first one.  The
+working copy of the operator is ADMM's (nmf_amd.admm)."""
 from collections import namedtuple
 
 import numpy as np

@@ -15,13 +15,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // and the factor rank is padded to KP in {16, 32, 64, 128}.  Zero padding is a
 // fixed point of every update rule implemented here ("padding").
 #define NMFX_TILE 64
-#define NMFX_MAX_FUSED_ROUNDS 64
+#define NMFX_MAX_FUSED_ROUNDS 64     // rows of the norm table in the f64 exchange buffer (sharded fused W sub-problem)
 // Tail of the f32 exchange buffer, behind [k n | k k | k]: per rank (up to 64) the four 16-bit digits of its f64 objective
 // partial as exact small floats.  A rank writes its own slot and zeros in the others, so the SUM all-reduce of the buffer
 // hands every rank every rank's partial bit for bit (x + 0 = x); the consumer adds them in rank order in f64.  One
 // collective per outer iteration instead of two (MUR, Euclidean loss, split-bf16 epilogues).
 #define NMFX_XTAIL_RANKS 64
-#define NMFX_XTAIL (NMFX_XTAIL_RANKS * 4)     // rows of the norm table in the f64 exchange buffer (sharded fused W sub-problem)
+#define NMFX_XTAIL (NMFX_XTAIL_RANKS * 4)     // floats of that tail
 
 struct DevState {          // lives in device memory, written by kernels
     int flag;              // 0 running, 1/2 = convergence_check branch (utils.py:8-11)
