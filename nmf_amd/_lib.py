@@ -131,8 +131,11 @@ def load():
             and os.environ.get("NMF_AMD_NO_TORCH") != "1":
         import torch  # noqa: F401  (ordering only)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lax = os.environ.get("NMFX_LIB_LAX") == "1"      # (A/B runs against an OLDER build through NMFX_LIB: entry points it lacks are skipped)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)      # AttributeError = header/library mismatch
+        fn = getattr(lib, name, None) if lax else getattr(lib, name)      # AttributeError = header/library mismatch
+        if fn is None:
+            continue
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
