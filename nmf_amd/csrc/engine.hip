@@ -246,7 +246,7 @@ int nmfx_reset_stream(nmfx_handle_t E) {
 }
 
 int nmfx_set_precision(nmfx_handle_t E, int mode) {
-    if (E) E->himg_both = false;
+    if (E) { E->himg_both = false; E->wimg_ok = false; }
     if (!E || (mode != 0 && mode != 1)) { if (E) E->err = "precision must be 0 (f32) or 1 (split bf16)"; return NMFX_E_ARG; }
     E->precision = mode;
     return NMFX_OK;
@@ -368,6 +368,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->have_f = true;
     E->bf_ready = false;
     E->kl_h_iter = -2;
+    E->wimg_ok = false;
     E->family = 0;
     E->pair = false;
     E->family_started = false;

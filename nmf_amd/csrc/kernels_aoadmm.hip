@@ -830,7 +830,9 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, float* __restrict__ Xb,
     float* __restrict__ Ub, const float* __restrict__ Minv, int64_t np, int prox, float lam, int admm_iter,
     DevState* __restrict__ st, double* __restrict__ nrm_rounds, int phase, int32_t* __restrict__ slot,
-    const int* __restrict__ hint_rd, int* __restrict__ hint_wr)
+    const int* __restrict__ hint_rd, int* __restrict__ hint_wr,
+    unsigned short* __restrict__ ihi = nullptr, unsigned short* __restrict__ ilo = nullptr,       // r3: the bf16 images of the new H
+    unsigned short* __restrict__ ithi = nullptr, unsigned short* __restrict__ itlo = nullptr)     // ([KP][np]) and of H^T ([np][KP])
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -1024,6 +1026,39 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
             }
         }
     }
+    // r3: every launch that leaves an X behind also leaves its bf16 hi / lo images in both layouts -- the values, the split and
+    // hence the bits of split_images_kernel, without its launch (config 3: 2 x 11 us per outer iteration)
+    if (ihi) {
+#pragma unroll
+        for (int r = 0; r < ITW; ++r) {
+            const int it = wave + 4 * r;
+            if (it < JT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {          // [factor][column]: NE consecutive columns per lane
+                    const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + NE * x;
+                    unsigned h[NE / 2], l[NE / 2];
+#pragma unroll
+                    for (int e = 0; e < NE / 2; ++e) ao_split2(hx[r][g][2 * e], hx[r][g][2 * e + 1], h[e], l[e]);
+                    if (NE == 2) {
+                        *reinterpret_cast<unsigned*>(ihi + idx) = h[0];
+                        *reinterpret_cast<unsigned*>(ilo + idx) = l[0];
+                    } else {
+                        *reinterpret_cast<uint2*>(ihi + idx) = make_uint2(h[0], h[NE / 2 - 1]);
+                        *reinterpret_cast<uint2*>(ilo + idx) = make_uint2(l[0], l[NE / 2 - 1]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {         // [column][factor]: the lane's four consecutive factors of one column
+                    const int64_t idx = (c0 + NE * x + e) * KP + 16 * it + 4 * q;
+                    unsigned h0, l0, h1, l1;
+                    ao_split2(hx[r][0][e], hx[r][1][e], h0, l0);
+                    ao_split2(hx[r][2][e], hx[r][3][e], h1, l1);
+                    *reinterpret_cast<uint2*>(ithi + idx) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(itlo + idx) = make_uint2(l0, l1);
+                }
+            }
+        }
+    }
 }
 
 // W side: block = 64 rows (4 waves x 16), M^-1 in LDS; the right-hand side of a wave's 16 rows is
@@ -1037,7 +1072,9 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
     float* __restrict__ Ub, const float* __restrict__ Minv, int prox, float lam, int admm_iter,
     DevState* __restrict__ st, double* __restrict__ nrm_rounds, int phase, int32_t* __restrict__ slot,
     const double* __restrict__ decide_tab,             // row-sharded runs: the ALL-REDUCED norm sums [admm_iter][4]
-    const int* __restrict__ hint_rd, int* __restrict__ hint_wr)
+    const int* __restrict__ hint_rd, int* __restrict__ hint_wr,
+    unsigned short* __restrict__ ihi = nullptr, unsigned short* __restrict__ ilo = nullptr,       // r3: the bf16 images of the new W
+    unsigned short* __restrict__ ithi = nullptr, unsigned short* __restrict__ itlo = nullptr, int64_t mp = 0)   // ([mp][KP]), W^T ([KP][mp])
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -1178,6 +1215,35 @@ __global__ __launch_bounds__(RB * 4) void ao_fused_rows_kernel(
             const int64_t idx = (r0 + 4 * q + g) * KP + 16 * it + x;
             X[idx] = wx[it][g]; U[idx] = dx[it][g];
         }
+    // r3: the bf16 hi / lo images of the new W in both layouts (see ao_fused_cols_kernel).  [factor][row]: the lane's four
+    // consecutive rows of one factor; [row][factor]: the tile is turned through the wave's LDS tile once more, so that a lane
+    // stores eight consecutive factors (16 bytes per image).
+    if (SPLIT && ihi) {
+#pragma unroll
+        for (int it = 0; it < JT; ++it) {
+            unsigned h0, l0, h1, l1;
+            ao_split2(wx[it][0], wx[it][1], h0, l0);
+            ao_split2(wx[it][2], wx[it][3], h1, l1);
+            const int64_t idx = (int64_t)(16 * it + x) * mp + r0 + 4 * q;
+            *reinterpret_cast<uint2*>(ithi + idx) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(itlo + idx) = make_uint2(l0, l1);
+        }
+#pragma unroll
+        for (int it = 0; it < JT; ++it)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const int row = 4 * q + g, col = 16 * it + x; myrs[row * KP + 4 * ((col >> 2) ^ row) + (col & 3)] = wx[it][g]; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const float4 p0 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q) ^ x));
+            const float4 p1 = *reinterpret_cast<const float4*>(myrs + x * KP + 4 * ((8 * u + 2 * q + 1) ^ x));
+            AoFrag8 h, l;
+            ao_split8(p0, p1, h, l);
+            const int64_t idx = (r0 + x) * KP + 32 * u + 8 * q;
+            *reinterpret_cast<uint4*>(ihi + idx) = h.u;
+            *reinterpret_cast<uint4*>(ilo + idx) = l.u;
+        }
+    }
 }
 
 // Row-sharded runs: this rank's four norm sums of round `round` -> out[0..3] (fixed order), to be
@@ -1344,7 +1410,8 @@ static bool ao_bf16(const nmfx_engine* E) { return E->precision == 1 && nmfx_bf1
 static int ao_bf16_objective_product(nmfx_engine* E) {   // Bt_part, obj_part (and G_part for kp = 64) of the current pair
     int rc;
     if ((rc = nmfx_bf16_prepare(E))) return rc;
-    if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
+    if (!E->wimg_ok && (rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;       // (r3: the fused W-side launches leave them)
+    E->wimg_ok = true;
     if (!E->himg_both && (rc = nmfx_bf16_images_h(E, true))) return rc;   // (the W side of the previous iteration built both)
     return nmfx_bf16_vtw(E, true, "hphase", false, 3);
 }
@@ -1418,8 +1485,10 @@ static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_it
                        64 * sizeof(double);
     auto kern = ao_fused_cols_kernel<KP, CB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
+    const bool img = E->ao_images;                     // (ao_fused_subproblem: split-bf16 run, images allocated)
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
-                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, hint_rd, hint_wr);
+                       E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, hint_rd, hint_wr,
+                       img ? E->Hhi : nullptr, img ? E->Hlo : nullptr, img ? E->HThi : nullptr, img ? E->HTlo : nullptr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -1449,7 +1518,9 @@ static int launch_fused_rows_rb(nmfx_engine* E, float* W, int prox, float lam, i
     const bool slabs = E->ao_a_slabs > 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->mp / RB)), dim3(RB * 4), shm, E->stream, slabs ? E->A_part : E->auxW,
                        slabs ? E->ao_a_slabs : 1, (int64_t)E->mp * E->kp, W, E->dualW, E->bkX, E->bkU,
-                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, decide_tab, hint_rd, hint_wr);
+                       E->Minv, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, decide_tab, hint_rd, hint_wr,
+                       E->ao_images ? E->Whi[0] : nullptr, E->ao_images ? E->Wlo[0] : nullptr, E->ao_images ? E->WThi : nullptr,
+                       E->ao_images ? E->WTlo : nullptr, E->mp);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -1493,6 +1564,14 @@ static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, fl
     static const bool hinted = !(getenv("NMFX_AO_HINT") && atoi(getenv("NMFX_AO_HINT")) == 0);
     int rc;
     if ((rc = ao_fused_alloc(E, admm_iter))) return rc;
+    // r3: in a split-bf16 run the launches below leave the bf16 images of the factor they update (NMFX_AO_IMG=0: the separate
+    // `images` launches of round 2; a sub-problem of zero rounds has no launch that writes anything)
+    static const bool img_on = !(getenv("NMFX_AO_IMG") && atoi(getenv("NMFX_AO_IMG")) == 0);
+    E->ao_images = img_on && ao_bf16(E) && admm_iter > 0 && W == (cols ? nullptr : E->W[0]) && E->Whi[0] && E->Hhi;
+    if (E->ao_images && cols) {
+        if ((rc = lazy_alloc(E, &E->HThi, (int64_t)E->kp * E->np))) return rc;
+        if ((rc = lazy_alloc(E, &E->HTlo, (int64_t)E->kp * E->np))) return rc;
+    }
     const int* hint_rd = hinted ? &E->state->ao_hint[cols ? 0 : 1][parity & 1] : nullptr;
     int* hint_wr = hinted ? &E->state->ao_hint[cols ? 0 : 1][(parity & 1) ^ 1] : nullptr;
     for (int phase = 0; phase < (hinted ? 3 : 2); ++phase) {
@@ -1506,8 +1585,10 @@ static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, fl
         } else {
             rc = fused_rows_any(E, W, prox, lam, admm_iter, phase, slot, nullptr, hint_rd, hint_wr);
         }
-        if (rc) return rc;
+        if (rc) { E->ao_images = false; return rc; }
     }
+    if (E->ao_images) { if (cols) E->himg_both = true; else E->wimg_ok = true; }
+    E->ao_images = false;                              // (the row-sharded entry points launch the same kernels without images)
     return NMFX_OK;
 }
 
@@ -1528,7 +1609,8 @@ static int ao_w_products(nmfx_engine* E, int64_t j, int64_t min_iter, double tol
     const int64_t kk = (int64_t)E->kp * E->kp;
     E->ao_a_slabs = 0;
     if (ao_bf16(E)) {
-        if ((rc = nmfx_bf16_images_h(E, true))) return rc;   // the H the sub-problem above produced; H^T images for the next H-side product
+        // the images of the H the sub-problem above produced (and of H^T, for the next H-side product): left by its fused launches, or built here
+        if (!E->himg_both && (rc = nmfx_bf16_images_h(E, true))) return rc;
         if ((rc = nmfx_bf16_vht(E, false, 0, "wphase_noobj", false, 3))) return rc;      // kp = 64: H H^T slabs as a by-product
         const bool byprod = E->kp == 64;
         int hslabs = E->gsplit;                        // k = 128: H H^T from the images just built (four-term split products, like W^T W)
@@ -1556,6 +1638,7 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     if ((rc = ao_h_solve(E, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j))) return rc;
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
     if ((rc = ao_w_products(E, j, min_iter, tol1, tol2, !ao_fused_enabled(E, admm_iter)))) return rc;
+    E->wimg_ok = false;                                // W changes below
     { ProfScope ps(E, "inner_w");
       if (ao_fused_enabled(E, admm_iter)) {
           if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1, (int)(j & 1)))) return rc;
@@ -1644,6 +1727,7 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
     if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
+    E->wimg_ok = false; E->ao_images = false;          // (the phase entry points rebuild the W images themselves)
     int rc;
     if ((rc = nmfx_small_k_only(E, "AO-ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;

@@ -111,6 +111,8 @@ struct nmfx_engine {
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
+    bool wimg_ok = false;          // Whi/Wlo[0] and WThi/WTlo are the images of the current W[0] (AO-ADMM: left by the fused W-side launches)
+    bool ao_images = false;        // the fused round kernels being launched write the images of the factor they update
     bool himg_both = false;        // Hhi/Hlo AND HThi/HTlo are the images of the current H (AO-ADMM skips a rebuild)
     bool lazy_objective = false;   // AO-ADMM split-bf16: the objective of the current pair rides on the next H-side product
     bool drop_v = false;           // split-bf16 mode: free the row-major V once Vtile / Vt exist (rebuilt on demand, nmfx_need_v)

@@ -151,3 +151,20 @@ def test_hinted_inner_rounds_are_the_unhinted_ones(shape, admm_iter, iters, expe
     # modelled on the CPU by tools/lab/ao_f32_state.py) it is 5e-6 in every product mode.)
     err = float(np.linalg.norm(got["1"]["w"] @ got["1"]["h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)))
     assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("shape,admm_iter,iters", [((320, 448, 100), 10, 8), ((384, 256, 40), 6, 10)])
+def test_images_left_by_the_fused_rounds_are_those_of_the_images_launch(shape, admm_iter, iters, tmp_path):
+    """r3: in a split-bf16 AO-ADMM run the fused round kernels leave the bf16 hi / lo images of the factor they update (both
+    layouts) instead of a separate `images` launch per sub-problem (NMFX_AO_IMG=0 keeps the launches): same values, same split,
+    hence factors, objectives and inner counts bit for bit -- also when a first leg is cut back or continued (the hint paths)."""
+    m, n, k = shape
+    got = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"img{mode}.npz")
+        run = subprocess.run([sys.executable, "-c", HINT_CHILD % {"root": ROOT}, str(m), str(n), str(k), str(admm_iter), str(iters), out],
+                             env=dict(os.environ, NMFX_AO_IMG=mode), capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        got[mode] = np.load(out)
+    for key in ("w", "h", "obj", "inner"):
+        np.testing.assert_array_equal(got["1"][key], got["0"][key], err_msg=key)
