@@ -44,12 +44,17 @@ __device__ __forceinline__ void gx_load(const float* __restrict__ base, int64_t 
         r1 = *reinterpret_cast<const float4*>(p + 8 * ld);
     }
 }
+// An operand that is contiguous along the contraction keeps that layout in LDS: [row][GX_LDK] with a row stride of 20 floats -- the
+// two float4 go in as they are, and the MFMA fragment read of lane (x, q) -- element (row x, k = 4 u + q) -- hits bank
+// (20 x + 4 u + q) mod 64: sixteen distinct multiples of four plus q, conflict free.  (A first form transposed such operands into
+// the [k][row] plane with eight scalar stores per thread and chunk: V H^T ran at 82 TFLOP/s against 109 for the W H product.)
+constexpr int GX_LDK = 20;
 template <bool KCONTIG>
 __device__ __forceinline__ void gx_store(float* __restrict__ plane, int tid, const float4& r0, const float4& r1) {
     if constexpr (KCONTIG) {
-        float* q = plane + (8 * (tid & 1)) * GX_LD + (tid >> 1);
-        q[0] = r0.x; q[GX_LD] = r0.y; q[2 * GX_LD] = r0.z; q[3 * GX_LD] = r0.w;
-        q[4 * GX_LD] = r1.x; q[5 * GX_LD] = r1.y; q[6 * GX_LD] = r1.z; q[7 * GX_LD] = r1.w;
+        float* q = plane + (tid >> 1) * GX_LDK + 8 * (tid & 1);
+        *reinterpret_cast<float4*>(q) = r0;
+        *reinterpret_cast<float4*>(q + 4) = r1;
     } else {
         float* q = plane + (tid >> 5) * GX_LD + 4 * (tid & 31);
         *reinterpret_cast<float4*>(q) = r0;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void gx_gemm_kernel(
     const int* __restrict__ flag2)
 {
     if (*flag || (flag2 && *flag2)) return;
-    __shared__ __attribute__((aligned(16))) float lds[2][2][GX_KC * GX_LD];        // [buffer][A / B][k][row]
+    __shared__ __attribute__((aligned(16))) float lds[2][2][128 * GX_LDK];         // [buffer][A / B]: [k][GX_LD] or [row][GX_LDK] (>= 16 x 144 floats)
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
     const int64_t i0 = (int64_t)blockIdx.y * GX_T, j0 = (int64_t)blockIdx.x * GX_T;
@@ -82,33 +87,46 @@ __global__ __launch_bounds__(256) void gx_gemm_kernel(
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 a0, a1, b0, b1;
+    // Two chunks in flight: a chunk is requested two iterations (~4000 cycles of MFMA work) before it is stored to LDS -- with one
+    // (~2000 cycles) the loads of a loaded HBM system had not landed when the store needed them.  Branch-free prefetch (behind the
+    // last chunk it fetches that chunk again): a conditionally assigned prefetch register is what hipcc parks in scratch.
+    const int nch = (int)(kper / GX_KC);
+    float4 a0, a1, b0, b1, a2, a3, b2, b3;
     gx_load<AK>(Ab, lda, kbeg, tid, a0, a1);
     gx_load<BK>(Bb, ldb, kbeg, tid, b0, b1);
-    const int nch = (int)(kper / GX_KC);
-    for (int ch = 0; ch < nch; ++ch) {
-        float* pa = lds[ch & 1][0];
-        float* pb = lds[ch & 1][1];
-        gx_store<AK>(pa, tid, a0, a1);
-        gx_store<BK>(pb, tid, b0, b1);
-        __syncthreads();                               // (two buffers: the chunk multiplied below is not the one written next time)
-        {   // branch-free prefetch (behind the last chunk it fetches that chunk again): a conditionally assigned prefetch array
-            // is what hipcc parks in scratch
-            const int64_t kn = kbeg + (int64_t)(ch + 1 < nch ? ch + 1 : ch) * GX_KC;
-            gx_load<AK>(Ab, lda, kn, tid, a0, a1);
-            gx_load<BK>(Bb, ldb, kn, tid, b0, b1);
-        }
+    { const int64_t k1 = kbeg + (int64_t)(nch > 1 ? 1 : 0) * GX_KC;
+      gx_load<AK>(Ab, lda, k1, tid, a2, a3);
+      gx_load<BK>(Bb, ldb, k1, tid, b2, b3); }
+    auto multiply = [&](const float* pa, const float* pb) {
 #pragma unroll
         for (int u = 0; u < GX_KC / 4; ++u) {
             float av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = pa[(4 * u + q) * GX_LD + wr + 16 * a + x];
+            for (int a = 0; a < 4; ++a) av[a] = AK ? pa[(wr + 16 * a + x) * GX_LDK + 4 * u + q] : pa[(4 * u + q) * GX_LD + wr + 16 * a + x];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = pb[(4 * u + q) * GX_LD + wc + 16 * b + x];
+            for (int b = 0; b < 4; ++b) bv[b] = BK ? pb[(wc + 16 * b + x) * GX_LDK + 4 * u + q] : pb[(4 * u + q) * GX_LD + wc + 16 * b + x];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = GX_MFMA(av[a], bv[b], acc[a][b]);
+        }
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        gx_store<AK>(lds[0][0], tid, a0, a1);
+        gx_store<BK>(lds[0][1], tid, b0, b1);
+        __syncthreads();                               // (two buffers: the chunk multiplied below is not the one written next)
+        { const int64_t kn = kbeg + (int64_t)(ch + 2 < nch ? ch + 2 : nch - 1) * GX_KC;
+          gx_load<AK>(Ab, lda, kn, tid, a0, a1);
+          gx_load<BK>(Bb, ldb, kn, tid, b0, b1); }
+        multiply(lds[0][0], lds[0][1]);
+        if (ch + 1 < nch) {                            // (block-uniform)
+            gx_store<AK>(lds[1][0], tid, a2, a3);
+            gx_store<BK>(lds[1][1], tid, b2, b3);
+            __syncthreads();
+            { const int64_t kn = kbeg + (int64_t)(ch + 3 < nch ? ch + 3 : nch - 1) * GX_KC;
+              gx_load<AK>(Ab, lda, kn, tid, a2, a3);
+              gx_load<BK>(Bb, ldb, kn, tid, b2, b3); }
+            multiply(lds[1][0], lds[1][1]);
         }
     }
     // acc[a][b][r] = C(i0 + wr + 16 a + 4 q + r, j0 + wc + 16 b + x)
