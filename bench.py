@@ -571,6 +571,7 @@ def self_launch(args):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before anything initialises HIP: the host driver only supports dmabuf IPC)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     # the contract is ONE JSON line on stdout: RCCL prints a version banner to stdout when the
