@@ -137,17 +137,19 @@ def cpu_baseline(v, k, iters):
 
 def converge_on_device(eng, w0, h0, tol, max_iter, min_iter=100):
     """MUR-eu from (w0, h0) until the reference's stop rule (nmf/utils.py:4-15, tol1 = tol2 = tol, nmf/mur.py:131 `i > min_iter`)
-    fires on the device, or max_iter.  Returns (rule, stop index i, iterations run, seconds, objective slots filled)."""
+    fires, or max_iter: the product's own loop (nmf_amd._driver.drive, 64 queued iterations per host round trip) with its float64
+    referee of the stop rule (nmf_amd._driver.Referee).  Returns (rule, stop index i, iterations run, seconds, referee)."""
+    from nmf_amd._driver import Referee, drive
+    NEVER = 10 ** 15
     eng.set_factors(w0, h0)
     eng.synchronize()
+    referee = Referee(eng, lambda i: eng.mur_run(0, 0.0, 0.0, NEVER, tol, tol, i, 1), min_iter, tol, tol)
     t1 = time.perf_counter()
-    done_t, rule, stop_i, n_obj_t = 0, 0, -1, 0
-    while done_t < max_iter and not rule:
-        cnt = min(256, max_iter - done_t)
-        eng.mur_run(0, 0.0, 0.0, min_iter, tol, tol, done_t, cnt)
-        done_t += cnt
-        rule, stop_i, n_obj_t = eng.state()
-    return int(rule), int(stop_i), int(done_t), time.perf_counter() - t1, int(n_obj_t)
+    i, history = drive(eng, lambda first, count: eng.mur_run(0, 0.0, 0.0, min_iter, tol, tol, first, count),
+                       lambda done: eng.mur_finish(0, NEVER if referee.walked else min_iter, tol, tol, done), max_iter, tol, tol, referee=referee)
+    secs = time.perf_counter() - t1
+    referee.history = history
+    return int(referee.final_rule), int(i if referee.final_rule else -1), int(i + 1 if referee.final_rule else max_iter), secs, referee
 
 
 def oracle_stop_check(eng, v, w0, h0, tol, device_rule, device_i, lead=15, span=30, min_iter=100):
@@ -738,17 +740,21 @@ def main():
     ttt = None
     if rank == 0 and world == 1 and args.tol_max_iter > 0:
         ttt = []
-        for tol in (1e-5, 1e-2):          # the reference's default, and a looser absolute tolerance
-            rule, stop_i, done_t, secs, n_obj_t = converge_on_device(eng, w0, h0, tol, args.tol_max_iter)
+        for tol in (1e-5, 1e-2, 1e-3):    # the reference's default (capped), and two looser absolute tolerances
+            rule, stop_i, done_t, secs, ref = converge_on_device(eng, w0, h0, tol, args.tol_max_iter)
             ttt.append({"tol1": tol, "tol2": tol, "min_iter": 100, "max_iter": args.tol_max_iter,
                         "converged": bool(rule), "stop_rule": int(rule),
                         "iterations": int(stop_i + 1) if rule else int(done_t), "seconds": secs,
-                        "objective": float(eng.objectives(n_obj_t - 1, 1)[0]),
-                        "note": "host checks the device-side stop flag every 256 queued iterations"})
+                        "objective": float(ref.history[-1]),
+                        "stop_guard": ref.guard, "iterations_refereed_in_f64": ref.walked,
+                        "note": "the product's loop: 64 queued iterations per host round trip; near the stop the rule is refereed "
+                                "with the float64 objective of the device's iterate (nmfx_objective_f64), one iteration at a time"})
         # the converged leg against the f64 oracle: same stop index, same rule (needs the host copy of V: done in the cpu_baseline leg)
         if not args.no_cpu:
             for leg in ttt:
-                if leg["converged"]:
+                # (only where the decrease still changes fast against the transient an oracle restarted from an f32 iterate goes
+                # through -- tol >= 1e-2 here; the 1e-3 leg is pinned in DESIGN.md 2 with a 100-iteration lead, 80 s of host time)
+                if leg["converged"] and leg["tol2"] >= 1e-2:
                     v_chk = v_local if (r0, r1) == (0, m) else planted_matrix(m, n, k, seed=0, dtype=np.float32)
                     leg["oracle_stop_check"] = oracle_stop_check(eng, v_chk, w0, h0, leg["tol1"], leg["stop_rule"], leg["iterations"] - 1)
                     if not os.environ.get("NMFX_BENCH_NOASSERT"):

@@ -190,6 +190,18 @@ int nmfx_set_exchange_rank(nmfx_handle_t h, int rank, int world);
 int nmfx_set_exchange_buffers(nmfx_handle_t h, void* dev_f32, int64_t n_f32, void* dev_f64, int64_t n_f64);
 int nmfx_get_exchange_buffers(nmfx_handle_t h, void** dev_f32, void** dev_f64);
 
+/* ---- the stop rule's referee (r3) ---------------------------------------------------------------------------------------------
+ * The objective every iteration records is evaluated in float32 products with float64 sums; near the stop of a long run its
+ * iteration-to-iteration jitter (~3e-9 of the objective at 16384 x 8192) is what `new >= old - tol2` (nmf/utils.py:10) sees once
+ * tol2 is below ~1e-6 of the objective.  nmfx_objective_f64 evaluates 1/2 ||V - W H||^2 of the CURRENT pair with the product and
+ * the sum in float64 (f64 MFMA; ~0.4 ms at 16384 x 8192, k = 64), as the reference's arithmetic would for this iterate.
+ * nmfx_set_stop_guard(h, g): the device's rule 2 becomes `new >= old - tol2 - g` -- with g a few times the jitter it fires EARLY, as
+ * a candidate; nmfx_resume(h) clears the stop flag so that the caller can walk on one iteration at a time with the f64 objective
+ * deciding (nmf_amd._driver.drive, `verify_stop`).  g = 0 (the default) is the plain rule.                                        */
+int nmfx_objective_f64(nmfx_handle_t h, double* out);
+int nmfx_set_stop_guard(nmfx_handle_t h, double guard);
+int nmfx_resume(nmfx_handle_t h);
+
 /* ---- pair mode: two MUR-Euclidean factorizations of the SAME V in one pass over it ------------------------------
  * The reference author's parameter grids (nmf/nmf_old.py:52-66, nmf/nmf.py:38-45) call the solver once per (lambda_w, lambda_h,
  * start); on the GPU two such problems with k <= 64 share the V stream: a handle created with k = 128 holds problem 0 in the

@@ -13,7 +13,66 @@ Results = namedtuple('Results', 'w h i obj_history experiment')
 BATCH = 64     # outer iterations queued between two host syncs
 
 
-def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None):
+class Referee:
+    """The stop rule refereed in float64 (MUR, Euclidean loss, one GPU).
+
+    The objective the device records every iteration is evaluated with float32 products: fine as a value (1e-6 relative), but its
+    iteration-to-iteration jitter (~3e-9 of the objective at 16384 x 8192) is what `new >= old - tol2` (nmf/utils.py:10) sees once
+    tol2 is below ~1e-6 of the objective -- the stop came 0.4 % early at tol2 = 1e-3 on the config-2 matrix.  The iterates
+    themselves are fine: evaluated in float64 (nmfx_objective_f64) their objective decreases smoothly (jitter 100 x smaller) and
+    the reference's rule fires on it at exactly the iteration at which the float64 oracle, continued from the device's iterate,
+    stops.  So: the jitter sigma of the recorded decreases is estimated from the history after every batch; when 6 sigma is no
+    longer negligible against tol2 the device's rule gets that much head start (nmfx_set_stop_guard: it fires EARLY, as a
+    candidate), and from the candidate on the loop walks one iteration at a time with the float64 objective deciding.
+    NMFX_VERIFY_STOP=0 turns it off, =1 forces the guard to at least 10 % of tol2."""
+
+    def __init__(self, engine, run_one, min_iter, tol1, tol2):
+        import os
+        self.eng, self.run_one, self.min_iter, self.tol1, self.tol2 = engine, run_one, min_iter, tol1, tol2
+        self.mode = os.environ.get("NMFX_VERIFY_STOP", "auto")
+        self.guard = 0.0
+        self.walked = 0
+        self.final_rule = 0
+
+    def update_guard(self, history):
+        if self.mode == "0" or len(history) < 24:
+            return
+        dd = np.diff(np.asarray(history[-66:], dtype=np.float64), n=2)          # second differences: sqrt(6) x the noise of one value
+        sigma_d = 1.4826 * np.median(np.abs(dd - np.median(dd))) / np.sqrt(3.0)    # ... -> the jitter of a decrease
+        g = 6.0 * sigma_d
+        if self.mode == "1":
+            g = max(g, 0.1 * self.tol2)
+        # (How far the jitter moves the stop depends on how fast the decrease itself changes, not on its size against tol2 -- at
+        # tol2 = 1e-3 on the config-2 matrix a jitter of 0.1 % of tol2 was worth 64 iterations -- and the head start costs about
+        # guard / |change of the decrease per iteration| refereed iterations: one or two where the decrease still moves fast.)
+        if g < 1e-6 * self.tol2:                     # nothing the rule could see: plain rule, no referee
+            g = 0.0
+        if g != self.guard:
+            self.guard = g
+            self.eng.set_stop_guard(g)
+
+    def walk(self, candidate_i, max_iter, pull):
+        """From the candidate stop (device rule 2 with the guard at loop index `candidate_i`) on: the current pair is the one that
+        entered iteration j = candidate_i + 1.  Returns (rule, stop_i, iterations done)."""
+        eng = self.eng
+        i = candidate_i + 1
+        eng.resume()
+        old = eng.objective_f64()
+        while i < max_iter:
+            self.run_one(i)                          # iteration i in full (stop rule off): the pair i + 1
+            pull()                                   # the device's recorded obj[i] -> history, printed like any other line
+            new = eng.objective_f64()
+            self.walked += 1
+            if i > self.min_iter:                    # nmf/mur.py:131 with nmf/utils.py:4-15 on the float64 values
+                rule = 1 if new < self.tol1 else 2 if new >= old - self.tol2 else 0
+                if rule:
+                    return rule, i, i + 1
+            old = new
+            i += 1
+        return 0, -1, max_iter
+
+
+def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None, referee=None):
     """run_batch(first, count) queues iterations; finish(done) completes the
     bookkeeping of the last one; before_line(i) may print what the reference
     prints inside iteration i before its objective line.  Returns (i, obj_history) like the reference
@@ -25,6 +84,15 @@ def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None):
     history = []
     done = 0
     rule, stop_i = 0, -1
+    def pull():
+        _, _, n_obj = engine.state()
+        for val in engine.objectives(len(history), n_obj - len(history)):
+            history.append(np.float64(val))
+            if len(history) >= 2:
+                if before_line is not None:
+                    before_line(len(history) - 2)
+                utils.say('[{}]: {:.{}f}'.format(len(history) - 2, val, digits))
+
     while done < max_iter and not rule:
         count = min(BATCH, max_iter - done)
         run_batch(done, count)
@@ -32,13 +100,18 @@ def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None):
         if done == max_iter:
             finish(done)
         rule, stop_i, n_obj = engine.state()
-        fresh = engine.objectives(len(history), n_obj - len(history))
-        for val in fresh:
-            history.append(np.float64(val))
-            if len(history) >= 2:
-                if before_line is not None:
-                    before_line(len(history) - 2)
-                utils.say('[{}]: {:.{}f}'.format(len(history) - 2, val, digits))
+        pull()
+        if referee is not None:
+            if rule == 2 and referee.guard > 0:      # a candidate: the float64 objective decides from here on
+                rule, stop_i, done = referee.walk(stop_i, max_iter, pull)
+                finish(done)                         # the objective of the last pair, evaluated as every other history entry
+                pull()
+                if not rule:
+                    break
+            elif not rule:
+                referee.update_guard(history)
+    if referee is not None:
+        referee.final_rule = rule                    # (callers that need it: the device's flag was cleared by a walk)
     if rule:
         utils.convergence_message(rule)
         logging.warning('Converged.')

@@ -79,6 +79,9 @@ SIGNATURES = {
     "nmfx_comm_graph_replays": (_i32, [_vp, C.POINTER(_i64)]),
     "nmfx_mur_run_sharded": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_mur_finish_sharded": (_i32, [_vp, _i32, _i64, _dbl, _dbl, _i64]),
+    "nmfx_objective_f64": (_i32, [_vp, _pd]),
+    "nmfx_set_stop_guard": (_i32, [_vp, _dbl]),
+    "nmfx_resume": (_i32, [_vp]),
     "nmfx_mur_pair_run": (_i32, [_vp, _pd, _pd, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_mur_pair_finish": (_i32, [_vp, _i64, _dbl, _dbl, _i64]),
     "nmfx_pair_get_state": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),

@@ -71,7 +71,11 @@ __global__ void init_state_kernel(DevState* st) {
     for (int i = 0; i < 4; ++i) { st->ao_hint[i >> 1][i & 1] = 0; st->ao_paths[i] = 0; }
     st->ao_continued = 0;
     for (int p = 0; p < 2; ++p) { st->pflag[p] = 0; st->pstop_i[p] = -1; st->pn_obj[p] = 0; }
+    st->stop_guard = 0.0;
 }
+
+__global__ void set_guard_kernel(DevState* st, double g) { st->stop_guard = g; }
+__global__ void resume_kernel(DevState* st) { st->flag = 0; st->stop_i = -1; }
 
 __global__ void shift_iteration_base_kernel(DevState* st, long long delta) { st->j_base += delta; }
 
@@ -523,6 +527,23 @@ int nmfx_get_exchange_buffers(nmfx_handle_t E, void** f32, void** f64) {
     if (!E) return NMFX_E_ARG;
     if (f32) *f32 = E->xf32;
     if (f64) *f64 = E->xf64;
+    return NMFX_OK;
+}
+
+// ---- the f64 referee of the stop rule (kernels_generic.hip: nmfx_objective_f64) ---------------
+int nmfx_set_stop_guard(nmfx_handle_t E, double guard) {
+    if (!E || !(guard >= 0.0)) { if (E) E->err = "set_stop_guard: guard >= 0"; return NMFX_E_ARG; }
+    NMFX_HIP(hipSetDevice(E->device));
+    hipLaunchKernelGGL(set_guard_kernel, dim3(1), dim3(1), 0, E->stream, E->state, guard);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_resume(nmfx_handle_t E) {
+    if (!E) return NMFX_E_ARG;
+    NMFX_HIP(hipSetDevice(E->device));
+    hipLaunchKernelGGL(resume_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
+    NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 

@@ -173,6 +173,85 @@ __global__ __launch_bounds__(256) void gx_gemm_kernel(
     if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (MODE == GX_RESID ? 0.5 : 1.0) * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
+// 1/2 sum (X - W H)^2 with the product AND the sum in float64 (v_mfma_f64_16x16x4_f64; W, H, X are float32 values, exact in
+// f64): the objective of the device's iterate as the reference's float64 arithmetic would evaluate it.  The f32-evaluated
+// objective of every iteration jitters by ~3e-9 relative (each element of W H carries its own f32 rounding, and they change with
+// the iterate), which decides the stop rule once tol2 is below ~1e-6 of the objective; this kernel is the referee near the stop
+// (nmfx_objective_f64).  Same tiling as gx_gemm_kernel<true, false, .>; C/D layout of the f64 MFMA: column = lane & 15,
+// row = (lane >> 4) + 4 reg.
+typedef double gx_f64x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gx_resid64_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K, const float* __restrict__ X, int64_t ldx,
+    double* __restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2][2][128 * GX_LDK];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * GX_T, j0 = (int64_t)blockIdx.x * GX_T;
+    const float* Ab = A + i0 * lda;
+    const float* Bb = B + j0;
+    const int wr = 64 * (wave >> 1), wc = 64 * (wave & 1);
+    gx_f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (gx_f64x4){0.0, 0.0, 0.0, 0.0};
+    const int nch = (int)(K / GX_KC);
+    float4 a0, a1, b0, b1;
+    gx_load<true>(Ab, lda, 0, tid, a0, a1);
+    gx_load<false>(Bb, ldb, 0, tid, b0, b1);
+    for (int ch = 0; ch < nch; ++ch) {
+        float* pa = lds[ch & 1][0];
+        float* pb = lds[ch & 1][1];
+        gx_store<true>(pa, tid, a0, a1);
+        gx_store<false>(pb, tid, b0, b1);
+        __syncthreads();
+        { const int64_t kn = (int64_t)(ch + 1 < nch ? ch + 1 : ch) * GX_KC;
+          gx_load<true>(Ab, lda, kn, tid, a0, a1);
+          gx_load<false>(Bb, ldb, kn, tid, b0, b1); }
+#pragma unroll
+        for (int u = 0; u < GX_KC / 4; ++u) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = (double)pa[(wr + 16 * a + x) * GX_LDK + 4 * u + q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = (double)pb[(4 * u + q) * GX_LD + wc + 16 * b + x];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double d = (double)X[(i0 + wr + 16 * a + q + 4 * r) * ldx + j0 + wc + 16 * b + x] - acc[a][b][r];
+                tot += d * d;
+            }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+// sum of `n` doubles in a fixed order -> out[0]
+__global__ __launch_bounds__(256) void gx_sum64_kernel(const double* __restrict__ part, int64_t n, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += part[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
 // X_new = X * Num / (Den + lam X + 1e-9)   (nmf/mur.py:29 / :45), 4 elements per thread
 __global__ __launch_bounds__(256) void gx_eu_update_kernel(const float* __restrict__ Xold, const float* __restrict__ Num,
                                                            const float* __restrict__ Den, float lam, float* __restrict__ Xnew,
@@ -590,6 +669,26 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
         if ((rc = gx_ao_subproblem(E, false, E->HHt, E->A_part, W, E->dualW, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
         if ((rc = gx_objective_partial(E))) return rc;
     }
+    return NMFX_OK;
+}
+
+// The Euclidean objective of the CURRENT pair (W as nmfx_get_factors would return it, H) evaluated entirely in float64 on the
+// device: the referee of the stop rule near the stop (see gx_resid64_kernel).  Synchronises.  Any k.
+extern "C" int nmfx_objective_f64(nmfx_handle_t E, double* out) {
+    if (!E || !out) { if (E) E->err = "objective_f64: out is NULL"; return NMFX_E_ARG; }
+    if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+    NMFX_HIP(hipSetDevice(E->device));
+    int rc;
+    if ((rc = nmfx_need_v(E))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp, nblk = (mp / GX_T) * (np / GX_T);
+    if ((rc = gx_alloc(E, &E->gx_part, nblk + 64))) return rc;
+    const float* W = E->W[E->wsel];
+    hipLaunchKernelGGL(gx_resid64_kernel, dim3((unsigned)(np / GX_T), (unsigned)(mp / GX_T)), dim3(256), 0, E->stream, W, kp, (const float*)E->H, np, kp,
+                       (const float*)E->V, np, E->gx_part);
+    hipLaunchKernelGGL(gx_sum64_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_part, nblk, E->gx_part + nblk);
+    NMFX_HIP(hipGetLastError());
+    NMFX_HIP(hipMemcpyAsync(out, E->gx_part + nblk, sizeof(double), hipMemcpyDeviceToHost, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
     return NMFX_OK;
 }
 

@@ -18,7 +18,7 @@ __device__ __forceinline__ int nmfx_record_objective(DevState* st, double* obj_h
     if (j >= 1 && (j - 1) > min_iter) {
         const double prev = obj_hist[j - 1];
         if (obj < tol1) rule = 1;
-        else if (obj >= prev - tol2) rule = 2;
+        else if (obj >= prev - tol2 - st->stop_guard) rule = 2;      // (stop_guard = 0 unless nmfx_set_stop_guard)
     }
     if (writer) {
         obj_hist[j] = obj;

@@ -55,6 +55,8 @@ struct DevState {          // lives in device memory, written by kernels
     int pflag[2];
     long long pstop_i[2];
     long long pn_obj[2];
+    // nmfx_set_stop_guard: rule 2 fires at `new >= old - tol2 - stop_guard` (a CANDIDATE stop that the f64 objective referees)
+    double stop_guard;
 };
 
 struct ProfSlot { double ms = 0; int64_t n = 0; };

@@ -291,6 +291,19 @@ class Engine:
         self._ck(self.lib.nmfx_anls_run(self.h, float(lam_w), float(lam_h), int(min_iter), float(tol1),
                                         float(tol2), int(first), int(count)))
 
+    # -- the f64 referee of the stop rule (include/nmfx.h) --------------------------------------
+    def objective_f64(self):
+        """1/2 ||V - W H||^2 of the current pair with product and sum in float64 on the device."""
+        out = C.c_double()
+        self._ck(self.lib.nmfx_objective_f64(self.h, C.byref(out)))
+        return out.value
+
+    def set_stop_guard(self, guard):
+        self._ck(self.lib.nmfx_set_stop_guard(self.h, float(guard)))
+
+    def resume(self):
+        self._ck(self.lib.nmfx_resume(self.h))
+
     # -- pair mode: two MUR-eu problems stacked into a k = 128 handle (include/nmfx.h) -----------
     def mur_pair_run(self, lambda_w, lambda_h, min_iter, tol1, tol2, first, count):
         lw = (C.c_double * 2)(float(lambda_w[0]), float(lambda_w[1]))

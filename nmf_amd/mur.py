@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 from . import utils
-from ._driver import Results, drive
+from ._driver import Referee, Results, drive
 from .engine import Engine
 
 Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_init max_iter tol1 tol2 lambda_w lambda_h')
@@ -44,11 +44,16 @@ def mur(x, k, *, distance_type='kl', min_iter=100, max_iter=100000, tol1=1e-5, t
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         logging.info('Entering Main Loop.')
+        NEVER = 10 ** 15
+        referee = None
+        if distance_type == 'eu':                   # (the float64 objective kernel is the Euclidean one)
+            referee = Referee(eng, lambda i: eng.mur_run(dist, lambda_w, lambda_h, NEVER, tol1, tol2, i, 1), min_iter, tol1, tol2)
         i, history = drive(
             eng,
             lambda first, count: eng.mur_run(dist, lambda_w, lambda_h, min_iter, tol1, tol2, first, count),
-            lambda done: eng.mur_finish(dist, min_iter, tol1, tol2, done),
-            max_iter, tol1, tol2)
+            lambda done: eng.mur_finish(dist, NEVER if referee is not None and referee.walked else min_iter, tol1, tol2, done),
+            max_iter, tol1, tol2, referee=referee)
+        mur.last_referee = referee                  # diagnostic: guard in force, iterations walked with the float64 objective
         w, h = eng.get_factors()
     return Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)
 
