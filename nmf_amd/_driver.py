@@ -40,6 +40,8 @@ class Referee:
         dd = np.diff(np.asarray(history[-66:], dtype=np.float64), n=2)          # second differences: sqrt(6) x the noise of one value
         sigma_d = 1.4826 * np.median(np.abs(dd - np.median(dd))) / np.sqrt(3.0)    # ... -> the jitter of a decrease
         g = 6.0 * sigma_d
+        if not np.isfinite(g):                       # (a history with inf / nan in it: nothing to estimate from)
+            return
         if self.mode == "1":
             g = max(g, 0.1 * self.tol2)
         # (How far the jitter moves the stop depends on how fast the decrease itself changes, not on its size against tol2 -- at
