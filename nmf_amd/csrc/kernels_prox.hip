@@ -38,13 +38,18 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red /* [16] *
     return t;
 }
 
-// vector `blockIdx.x`: element e at base + e * es (aux, X and U share the layout)
+// vector `blockIdx.x`: element e at base + e * es (aux, X and U share the layout).
+// GLOBALK (r3, vectors beyond 32768 entries -- W-side vectors of a tall matrix): the keys of vector b are sorted in the global
+// work area gkeys[b][Lpad] instead of LDS; the workgroup barrier between the passes orders its own global accesses (one CU, one
+// vector cache), the data stays in L2.  Same passes, same result, about a millisecond per vector of 131072 entries.
+template <bool GLOBALK>
 __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
     const float* __restrict__ AUX, float* __restrict__ X, float* __restrict__ U, int64_t vec_stride, int64_t es,
-    int L, int Lpad, double rho, double lam, double ub, int update_dual, const int* __restrict__ flag)
+    int L, int Lpad, double rho, double lam, double ub, int update_dual, const int* __restrict__ flag, float* __restrict__ gkeys)
 {
     if (*flag) return;
-    extern __shared__ __attribute__((aligned(16))) float keys[];       // [Lpad]
+    extern __shared__ __attribute__((aligned(16))) float lkeys[];      // [Lpad] (LDS form)
+    float* keys = GLOBALK ? gkeys + (int64_t)blockIdx.x * Lpad : lkeys;
     __shared__ double red[ROWS_NT / 64];
     __shared__ double scan[ROWS_NT / 64];
     __shared__ int first_bad;
@@ -218,13 +223,24 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
     // storage: H-like [kp][np] (factor t, column c at t * np + c), W-like [mp][kp] (row r, factor t at r * kp + t)
     const int64_t cols = h_side ? E->n : E->m;
     if (!transpose) {       // a vector = all entries of one factor: k vectors of `cols` entries
-        int Lpad = 2; while (Lpad < cols) Lpad <<= 1;
-        if (Lpad > 32768) { E->err = "prox 'l1inf': vectors longer than 32768 entries are not supported"; return NMFX_E_ARG; }
-        const size_t shm = (size_t)Lpad * sizeof(float);
-        int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(prox_l1inf_rows_kernel), (int)shm + 1024); if (rc) return rc;
-        hipLaunchKernelGGL(prox_l1inf_rows_kernel, dim3((unsigned)E->k), dim3(ROWS_NT), shm, E->stream, aux, x, u,
-                           h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, Lpad, rho, lam, ub,
-                           update_dual ? 1 : 0, &E->state->flag);
+        int64_t Lpad = 2; while (Lpad < cols) Lpad <<= 1;
+        if (Lpad > (int64_t)1 << 30) { E->err = "prox 'l1inf': vector too long"; return NMFX_E_ARG; }
+        if (Lpad <= 32768) {
+            const size_t shm = (size_t)Lpad * sizeof(float);
+            int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(prox_l1inf_rows_kernel<false>), (int)shm + 1024); if (rc) return rc;
+            hipLaunchKernelGGL(prox_l1inf_rows_kernel<false>, dim3((unsigned)E->k), dim3(ROWS_NT), shm, E->stream, aux, x, u,
+                               h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
+                               update_dual ? 1 : 0, &E->state->flag, (float*)nullptr);
+        } else {            // longer vectors: the same kernel with its keys in a global work area
+            if (E->prox_keys_cap < (int64_t)E->k * Lpad) {
+                if (E->prox_keys) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->prox_keys); E->prox_keys = nullptr; }
+                NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->prox_keys), (size_t)E->k * Lpad * sizeof(float)));
+                E->prox_keys_cap = (int64_t)E->k * Lpad;
+            }
+            hipLaunchKernelGGL(prox_l1inf_rows_kernel<true>, dim3((unsigned)E->k), dim3(ROWS_NT), 16, E->stream, aux, x, u,
+                               h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
+                               update_dual ? 1 : 0, &E->state->flag, E->prox_keys);
+        }
     } else {                // a vector = the k factors of one column of mat_aux
         if (cols < 2) { E->err = "prox 'l1inf_transpose' reads column 1 of the dual: needs at least 2 columns"; return NMFX_E_ARG; }
         // (every vector reads the dual of vector 1: the dual update is a launch of its own behind this one)

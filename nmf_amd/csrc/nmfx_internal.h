@@ -87,6 +87,8 @@ struct nmfx_engine {
     double* xf64 = nullptr;        // exchange: [8] = objective partial, 4 inner-loop norm sums, 3 spare
     bool own_x = true;
     // k > 128 (kernels_generic.hip): objective partials per 128 x 128 tile, an m x kp / kp x n scratch, split-product slabs
+    float* prox_keys = nullptr;    // l1inf prox on vectors beyond 32768 entries: the sort's global work area [k][Lpad]
+    int64_t prox_keys_cap = 0;
     double* gx_part = nullptr;
     float* gx_d = nullptr;
     float* gx_s = nullptr;

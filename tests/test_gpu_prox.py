@@ -62,6 +62,22 @@ def test_prox_l1inf_long_vectors_vs_oracle(kind, shape, side):
     np.testing.assert_allclose(new_dual, dual + want - aux, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
 
 
+@pytest.mark.parametrize("side,shape", [("h", (6, 40000)), ("w", (9, 70001))])
+def test_prox_l1inf_vectors_beyond_32768_entries(side, shape):
+    """r3 (missing 6): 'l1inf' vectors longer than the 32768 entries an LDS sort holds -- the W-side vectors of a tall
+    matrix have m entries -- take the same kernel with its sort keys in a global work area."""
+    k, cols = shape
+    rs = np.random.RandomState(k + cols)
+    scale = np.where(np.arange(k) % 3 == 0, 1e-5, 1.0)[:, None]
+    aux = (rs.randn(k, cols) * scale).astype(np.float32).astype(np.float64)
+    dual = (0.3 * rs.randn(k, cols) * scale).astype(np.float32).astype(np.float64)
+    want = R.prox("l1inf", aux, dual, rho=1.7, lam=0.3)
+    got, new_dual = device_prox("l1inf", aux, dual, 1.7, 0.3, side, update_dual=True)
+    assert (want == 0).any() and (want > 0).any()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(want).max()))
+    np.testing.assert_allclose(new_dual, dual + want - aux, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
+
+
 @pytest.mark.parametrize("name", ["admm_eu_l1inf", "admm_eu_l1inf_t"])
 def test_admm_with_l1inf_follows_the_reference_over_the_first_iterations(name, capsys):
     """As written the operator makes the ADMM iteration expansive, so parity is asserted where f32 against
