@@ -37,9 +37,12 @@ class Referee:
     def update_guard(self, history):
         if self.mode == "0" or len(history) < 24:
             return
-        dd = np.diff(np.asarray(history[-66:], dtype=np.float64), n=2)          # second differences: sqrt(6) x the noise of one value
-        sigma_d = 1.4826 * np.median(np.abs(dd - np.median(dd))) / np.sqrt(3.0)    # ... -> the jitter of a decrease
-        g = 6.0 * sigma_d
+        # FOURTH differences of the recorded objectives: what a smooth history leaves of itself there is far below its curvature
+        # (second differences mistook the curvature of a young run for jitter and started the walk hundreds of iterations early),
+        # while independent noise of spread s per value arrives with spread sqrt(70) s; the jitter of a decrease is sqrt(2) s
+        d4 = np.diff(np.asarray(history[-68:], dtype=np.float64), n=4)
+        sigma_d = 1.4826 * np.median(np.abs(d4 - np.median(d4))) * np.sqrt(2.0 / 70.0)
+        g = min(6.0 * sigma_d, self.tol2)            # (a jitter beyond tol2 itself: the walk starts at twice tol2, not earlier)
         if not np.isfinite(g):                       # (a history with inf / nan in it: nothing to estimate from)
             return
         if self.mode == "1":
