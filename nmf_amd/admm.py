@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib as L
 from . import utils
-from ._driver import Results, drive
+from ._driver import Referee, Results, drive
 from .engine import Engine
 
 Experiment = namedtuple('Experiment', 'method components rho distance_type nndsvd_init min_iter max_iter tol1 tol2 lambda_w prox_w lambda_h prox_h')
@@ -63,11 +63,17 @@ def admm(v, k, *, rho=1, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), 
             if reg_w[1] == 'l1inf_transpose':
                 utils.say('will go {}'.format(v.shape[0]))
 
+        NEVER = 10 ** 15
+        referee = None
+        if distance_type == 'eu':                   # the stop rule refereed in float64 near the stop (nmf_amd._driver.Referee)
+            referee = Referee(eng, lambda i: eng.admm_run(dist, rho, prox_w, reg_w[0], prox_h, reg_h[0], NEVER, tol1, tol2, i, 1),
+                              min_iter, tol1, tol2)
+        admm.last_referee = referee
         i, history = drive(
             eng,
             lambda first, count: eng.admm_run(dist, rho, prox_w, reg_w[0], prox_h, reg_h[0], min_iter,
                                               tol1, tol2, first, count),
-            lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
-            max_iter, tol1, tol2, before_line=will_go)
+            lambda done: eng.aoadmm_finish(NEVER if referee is not None and referee.walked else min_iter, tol1, tol2, done),
+            max_iter, tol1, tol2, before_line=will_go, referee=referee)
         w, h = eng.get_factors()
     return Results(w=w, h=h, i=i, obj_history=history, experiment=experiment)

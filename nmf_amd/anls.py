@@ -14,7 +14,7 @@ from collections import namedtuple
 
 from . import _lib as L
 from . import utils
-from ._driver import Results, drive
+from ._driver import Referee, Results, drive
 from .engine import Engine
 
 Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_init max_iter tol1 tol2 lambda_w lambda_h fcnnls')
@@ -33,11 +33,16 @@ def anls(x, k, *, distance_type='eu', use_fcnnls=False, lambda_w=0, lambda_h=0, 
         w0, h0 = utils.device_initial_factors(eng, x, k, nndsvd_init, init)
         eng.set_factors(w0, h0)
         eng.anls_set_distance(dist)
+        NEVER = 10 ** 15
+        referee = None
+        if distance_type == 'eu':                   # the stop rule refereed in float64 near the stop (nmf_amd._driver.Referee)
+            referee = Referee(eng, lambda i: eng.anls_run(lambda_w, lambda_h, NEVER, tol1, tol2, i, 1), min_iter, tol1, tol2)
+        anls.last_referee = referee
         i, history = drive(
             eng,
             lambda first, count: eng.anls_run(lambda_w, lambda_h, min_iter, tol1, tol2, first, count),
-            lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
-            max_iter, tol1, tol2)
+            lambda done: eng.aoadmm_finish(NEVER if referee is not None and referee.walked else min_iter, tol1, tol2, done),
+            max_iter, tol1, tol2, referee=referee)
         w, h = eng.get_factors()
         evicted, capped = eng.diagnostics()
     if capped:                    # (the reference's FCNNLS prints 'Not converged.' there, nmf/fcnnls.py:118)

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib as L
 from . import utils
-from ._driver import Results, drive
+from ._driver import Referee, Results, drive
 from .engine import Engine
 
 Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_init min_iter max_iter admm_iter tol1 tol2 lambda_w prox_w lambda_h prox_h')
@@ -70,13 +70,19 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
                 if fired:
                     utils.say('ADMM break after {} iterations.'.format(rounds - 1))
 
+        NEVER = 10 ** 15
+        referee = None
+        if distance_type == 'eu':                   # the stop rule refereed in float64 near the stop (nmf_amd._driver.Referee)
+            referee = Referee(eng, lambda i: eng.aoadmm_run(dist, prox_w, reg_w[0], prox_h, reg_h[0], admm_iter, NEVER, tol1, tol2, i, 1),
+                              min_iter, tol1, tol2)
+        ao_admm.last_referee = referee
         try:
             i, history = drive(
                 eng,
                 lambda first, count: eng.aoadmm_run(dist, prox_w, reg_w[0], prox_h, reg_h[0], admm_iter,
                                                     min_iter, tol1, tol2, first, count),
-                lambda done: eng.aoadmm_finish(min_iter, tol1, tol2, done),
-                max_iter, tol1, tol2, before_line=breaks)
+                lambda done: eng.aoadmm_finish(NEVER if referee is not None and referee.walked else min_iter, tol1, tol2, done),
+                max_iter, tol1, tol2, before_line=breaks, referee=referee)
         except L.NmfxError as e:
             if e.code == L.NMFX_E_NOTPD:                        # scipy cholesky, ao_admm.py:55
                 raise np.linalg.LinAlgError('matrix is not positive definite (Gram + rho I)') from e

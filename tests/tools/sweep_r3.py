@@ -58,4 +58,18 @@ for (m, n, k, tol2) in [(300, 260, 36, 5e-3), (512, 384, 40, 1e-3), (640, 1000, 
     ok = abs(res.i - ref.i) <= 1 and len(res.obj_history) == res.i + 2
     bad += not ok
     print(f"{m}x{n} k={k} tol2={tol2}: stop {res.i} (oracle {ref.i}), guard {rf.guard:.1e}, {rf.walked} iterations refereed {'ok' if ok else 'FAIL'}", flush=True)
+from nmf_amd.admm import admm
+from nmf_amd.anls import anls
+for name, solver, oracle, kw in [
+        ("ao_admm", ao_admm, R.ao_admm, dict(reg_w=(0.05, "l1n"), reg_h=(0.02, "l1n"), min_iter=2, max_iter=400, tol1=1e-9, tol2=2e-3, admm_iter=6)),
+        ("admm", admm, R.admm, dict(rho=1.0, reg_w=(0.02, "l1n"), reg_h=(0.02, "l1n"), min_iter=2, max_iter=800, tol1=1e-9, tol2=2e-3)),
+        ("anls", anls, R.anls, dict(lambda_w=0.05, lambda_h=0.02, min_iter=2, max_iter=300, tol1=1e-9, tol2=1e-4))]:
+    for (m, n, k) in [(300, 260, 12), (384, 520, 40)]:
+        v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
+        res = solver(v.copy(), k, nndsvd_init=(True, "zero"), **kw)
+        ref = oracle(v.astype(np.float64), k, nndsvd_init=(True, "zero"), **kw)
+        rf = solver.last_referee
+        ok = abs(res.i - ref.i) <= 1 and len(res.obj_history) == res.i + 2 and err(res, ref, v) < 1e-4
+        bad += not ok
+        print(f"{name} {m}x{n} k={k}: stop {res.i} (oracle {ref.i}), WH {err(res, ref, v):.1e}, guard {rf.guard:.1e}, {rf.walked} refereed {'ok' if ok else 'FAIL'}", flush=True)
 sys.exit(1 if bad else 0)
