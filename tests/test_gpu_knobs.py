@@ -168,3 +168,33 @@ def test_images_left_by_the_fused_rounds_are_those_of_the_images_launch(shape, a
         got[mode] = np.load(out)
     for key in ("w", "h", "obj", "inner"):
         np.testing.assert_array_equal(got["1"][key], got["0"][key], err_msg=key)
+
+
+@pytest.mark.parametrize("solver", ["mur", "ao_admm", "anls"])
+def test_refereed_stop_equals_the_oracles_stop_index(solver, monkeypatch):
+    """NMFX_VERIFY_STOP=1 forces the float64 referee of the stop rule (nmf_amd._driver.Referee) on small problems, where the plain
+    rule is right anyway: the guarded candidate + one-iteration-at-a-time walk with nmfx_objective_f64 must stop where the oracle
+    stops (nmf/utils.py:4-15 through nmf/mur.py:131 / ao_admm.py:298 / anls.py:121), with the history and factors of that iterate."""
+    from oracle import nmf_ref as R
+    monkeypatch.setenv("NMFX_VERIFY_STOP", "1")
+    m, n = 300, 260
+    if solver == "mur":
+        from nmf_amd.mur import mur as fn
+        k, kw, ref_fn = 36, dict(distance_type="eu", min_iter=5, max_iter=3000, tol1=1e-9, tol2=5e-3), R.mur
+    elif solver == "ao_admm":
+        from nmf_amd.ao_admm import ao_admm as fn
+        k, kw, ref_fn = 12, dict(reg_w=(0.05, "l1n"), reg_h=(0.02, "l1n"), min_iter=2, max_iter=400, tol1=1e-9, tol2=2e-3, admm_iter=6,
+                                 nndsvd_init=(True, "zero")), R.ao_admm
+    else:
+        from nmf_amd.anls import anls as fn
+        k, kw, ref_fn = 6, dict(lambda_w=0.05, lambda_h=0.02, min_iter=2, max_iter=300, tol1=1e-9, tol2=1e-4, nndsvd_init=(True, "zero")), R.anls
+    v = R.planted_matrix(m, n, k, seed=312 if solver == "ao_admm" else 77, dtype=np.float32)      # (runs longer than the first batch of 64)
+    np.random.seed(3)
+    res = fn(v.copy(), k, **kw)
+    np.random.seed(3)
+    ref = ref_fn(v.astype(np.float64), k, **kw)
+    rf = fn.last_referee
+    assert rf.guard > 0 and rf.walked > 0, (rf.guard, rf.walked)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2, (res.i, ref.i)
+    assert np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)
