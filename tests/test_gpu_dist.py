@@ -90,7 +90,7 @@ def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [12, 40, 100])     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128
+@pytest.mark.parametrize("k", [12, 40, 100, 160])     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128; generic path (k > 128)
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
 def test_sharded_device_path(world, backend, k, tmp_path):
     import torch.multiprocessing as mp
