@@ -399,3 +399,18 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
     leg = line["other_configs"][0]
     assert leg.get("config") == "cfg5" and "error" not in leg, leg
     assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 1024 and leg["objective_decreasing"] and leg["iter_per_s"] > 0
+
+
+def test_sharded_entry_points_need_a_communicator():
+    """nmfx_mur_run_sharded / nmfx_comm_all_reduce without nmfx_comm_init_rank: NMFX_E_STATE, not a crash."""
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.engine import Engine
+    m, n, k, v, w0, h0 = _case()
+    with Engine(m, n, k) as e:
+        e.upload_v(v)
+        e.set_factors(w0, h0)
+        with pytest.raises(NmfxError, match="communicator"):
+            e.mur_run_sharded(0, 0.0, 0.0, 10 ** 9, 1e-5, 1e-5, 0, 1)
+        with pytest.raises(NmfxError, match="communicator"):
+            e.comm_all_reduce(0, 0, 8)
+        assert e.comm_info()[:3] == (0, 1, False)

@@ -89,3 +89,36 @@ def test_grid_runs_mur_eu_in_pairs_and_equals_the_oracle(capsys, monkeypatch):
         assert _rel(ra.w @ ra.h, rb.w @ rb.h) < 1e-6
     strip = lambda text: [ln.split(":")[0] for ln in text.splitlines() if ln.startswith("[")]      # noqa: E731
     assert strip(paired_out) == strip(seq_out) and len(strip(seq_out)) == 6 * 12
+
+
+def test_pair_mode_says_so_where_it_does_not_apply(monkeypatch):
+    """The pair entry points need a k = 128 handle on the split-bf16 path and fresh factors; the grid then runs one by one."""
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.engine import Engine
+    from nmf_amd.grid import factorize_grid
+    v = R.planted_matrix(260, 180, 6, seed=4, dtype=np.float32)
+    rs = np.random.RandomState(0)
+    with Engine(260, 180, 64) as e:                      # not a k = 128 handle
+        e.upload_v(v)
+        e.set_factors(np.abs(rs.randn(260, 64)), np.abs(rs.randn(64, 180)))
+        with pytest.raises(NmfxError, match="k = 128"):
+            e.mur_pair_run([0, 0], [0, 0], 10 ** 9, 1e-5, 1e-5, 0, 1)
+    with Engine(260, 180, 128) as e:
+        e.upload_v(v)
+        e.set_factors(np.abs(rs.randn(260, 128)), np.abs(rs.randn(128, 180)))
+        e.mur_run(0, 0.0, 0.0, 10 ** 9, 1e-5, 1e-5, 0, 2)       # started as ONE k = 128 problem ...
+        with pytest.raises(NmfxError, match="set_factors"):
+            e.mur_pair_run([0, 0], [0, 0], 10 ** 9, 1e-5, 1e-5, 2, 1)      # ... cannot continue as a pair
+        w, h = e.get_factors()
+        e.set_factors(w, h)
+        e.mur_pair_run([0, 0.1], [0, 0.1], 10 ** 9, 1e-5, 1e-5, 0, 2)
+        with pytest.raises(NmfxError, match="two stacked problems"):
+            e.mur_run(0, 0.0, 0.0, 10 ** 9, 1e-5, 1e-5, 2, 1)
+    monkeypatch.setenv("NMFX_PRECISION", "f32")               # exact-f32 engines: no pair mode, the grid runs singly and still equals the oracle
+    common = dict(distance_type="eu", min_iter=6, max_iter=6, nndsvd_init=(False, "zero"))
+    np.random.seed(5)
+    runs = factorize_grid(v.copy(), "mur", features=(6,), lambda_w=(0.0, 0.1), lambda_h=(0.05,), **common)
+    np.random.seed(5)
+    for params, res in runs:
+        ref = R.mur(v.astype(np.float64), params["features"], lambda_w=params["lambda_w"], lambda_h=params["lambda_h"], **common)
+        assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
