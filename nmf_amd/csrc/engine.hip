@@ -728,8 +728,15 @@ int nmfx_profile_repeat(nmfx_handle_t E, const char* which, int distance, int re
     E->prof = false;
     hipEvent_t a, b;
     NMFX_HIP(hipEventCreate(&a)); NMFX_HIP(hipEventCreate(&b));
+#ifdef NMFX_EXP_REVERSE
+    extern int nmfx_debug_set_reverse(void* stream, int v);
+    static const int altrev = getenv("NMFX_EXP_ALTREV") ? atoi(getenv("NMFX_EXP_ALTREV")) : 0;
+#endif
     for (int i = -2; i < reps && !rc; ++i) {                               // two untimed launches first
         if (i == 0) NMFX_HIP(hipEventRecord(a, E->stream));
+#ifdef NMFX_EXP_REVERSE
+        nmfx_debug_set_reverse(E->stream, altrev ? (i & 1) : 0);          // (the setter launch is there in both variants)
+#endif
         if (bf) rc = wph ? nmfx_bf16_vht(E, true, E->wsel, "wphase", kl, 3) : nmfx_bf16_vtw(E, false, "hphase", kl, 3);
         else if (kl) { E->err = "profile_repeat: KL only in the split-bf16 mode"; rc = NMFX_E_ARG; }
         else rc = wph ? nmfx_launch_wphase(E, E->W[E->wsel], true, true) : nmfx_launch_hphase(E, E->W[E->wsel], nmfx_hphase_can_fuse_gram(E));

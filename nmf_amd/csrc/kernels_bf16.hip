@@ -590,6 +590,17 @@ extern "C" int nmfx_debug_stamps(unsigned long long* out) {
 // on the same X -- the A-product is the k = 128 product as it stands (A = [X Y_0^T | X Y_1^T]); the residual product is closed
 // after the first four k-steps (objective of problem 0), restarted, and closed again after the last four (problem 1):
 // objpart[p][split][block].
+#ifdef NMFX_EXP_REVERSE
+// Experiment (tools/lab/rev_probe.py): every other launch walks its groups backwards, so that what the previous launch streamed
+// LAST is read FIRST -- how much of a V-sized stream does the 256 MiB Infinity Cache serve on the turn-around?
+__device__ int nmfx_rev_flag = 0;
+__global__ void nmfx_set_rev_kernel(int v) { nmfx_rev_flag = v; }
+extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
+    hipLaunchKernelGGL(nmfx_set_rev_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), v);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
@@ -627,7 +638,14 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const int lw = wave & 3;
     const int ytile = (lw * YPW) / (KP / 8), p0 = (lw * YPW) % (KP / 8);
     const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
-    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)g0 * 128ull;
+#ifdef NMFX_EXP_REVERSE
+    const bool rev = __builtin_amdgcn_readfirstlane(nmfx_rev_flag) != 0;
+#else
+    constexpr bool rev = false;
+#endif
+    const int gfirst = rev ? g1 - 1 : g0;
+    const long long ystep = rev ? -128ll : 128ll, vstep = rev ? -32768ll : 32768ll;
+    unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)gfirst * 128ull;
     unsigned yoffs[YPW];
 #pragma unroll
     for (int i = 0; i < YPW; ++i) {
@@ -636,7 +654,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     }
     const unsigned ydst = (unsigned)(ytile * YT + p0 * 1024);
     // X is tile-major: [R/128][ldx/64] tiles of [128 rows][64 cols], 32 KiB contiguous each
-    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)blockIdx.x * (ldx / 64) + g0) * 32768ull;
+    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)blockIdx.x * (ldx / 64) + gfirst) * 32768ull;
     unsigned long long vbaseA = tile0 + (unsigned long long)lw * 32 * 256, vbaseB = vbaseA + 16 * 256;
     unsigned voffs[4];
 #pragma unroll
@@ -648,21 +666,21 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int i = 0; i < YPW; i += 4)
             dma_run4(ybase, smem0 + yq * YBUF + ydst + i * 1024, yoffs[i], yoffs[i + 1], yoffs[i + 2], yoffs[i + 3]);
-        ybase += 128ull; yq = (yq == YR - 1) ? 0 : yq + 1;
+        ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1;
     };
     auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
         if (yrole) {
             if (st < 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * st], yoffs[2 * st + 1]);
-            if (st == 1) { ybase += 128ull; yq = (yq == YR - 1) ? 0 : yq + 1; }
+            if (st == 1) { ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1; }
         } else {
             dma_run2_nt(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
-            if (st == 3) { vbaseA += 32768ull; vbaseB += 32768ull; vq = (vq == VRING - 1) ? 0 : vq + 1; }
+            if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1; }
         }
     };
     auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
         dma_run4_nt(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         dma_run4_nt(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
-        vbaseA += 32768ull; vbaseB += 32768ull; vq = (vq == VRING - 1) ? 0 : vq + 1;
+        vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1;
     };
 
     // ---- loop-invariant LDS read offsets ----
