@@ -70,6 +70,9 @@ __device__ __forceinline__ void dma_run4(unsigned long long base, unsigned dst, 
 }
 __device__ __forceinline__ void dma_run4_nt(unsigned long long base, unsigned dst, unsigned o0, unsigned o1,
                                             unsigned o2, unsigned o3) {       // streaming (non-temporal) policy
+#ifdef NMFX_EXP_TEMPORAL      // experiment: the tile stream with the default cache policy (does a small V stay in the Infinity Cache?)
+    dma_run4(base, dst, o0, o1, o2, o3); return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
                  "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
@@ -86,6 +89,9 @@ __device__ __forceinline__ void dma_run2(unsigned long long base, unsigned dst, 
                  : "=&s"(keep) : "s"(base), "s"(dst), "v"(o0), "v"(o1) : "memory", "scc");
 }
 __device__ __forceinline__ void dma_run2_nt(unsigned long long base, unsigned dst, unsigned o0, unsigned o1) {
+#ifdef NMFX_EXP_TEMPORAL
+    dma_run2(base, dst, o0, o1); return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
                  "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
@@ -601,7 +607,12 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 }
 #endif
 
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1>
+// TEMPORAL (r3): the V tiles with the default cache policy instead of non-temporal.  A V-sized stream goes 6 % faster
+// non-temporal (config 2: 212.8 vs 225.9 us per iteration) and leaves nothing in the 256 MiB Infinity Cache; but when V and V^T
+// TOGETHER fit there -- a rank's shard of a strongly scaled problem: 2 x 64 MiB at config 2 over 8 GPUs -- the default policy keeps
+// both resident from one iteration to the next: 62.7 -> 60.4 us per iteration at 2048 rows (tools/lab/ab_iter.py shard8), 81.0 -> 79.9
+// at 4096 rows, 122 -> 134 (worse) at 8192.  Chosen per launch from the size of the two copies (nmfx_bf16_temporal).
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -673,13 +684,13 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             if (st < 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * st], yoffs[2 * st + 1]);
             if (st == 1) { ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1; }
         } else {
-            dma_run2_nt(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
+            (TEMPORAL ? dma_run2 : dma_run2_nt)(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
             if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1; }
         }
     };
     auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
-        dma_run4_nt(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
-        dma_run4_nt(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+        (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+        (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1;
     };
 
@@ -1774,6 +1785,12 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
     auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP>;
+    if constexpr (!KL && KP == 64 && TERMS == 3) {
+        // V and V^T together small enough to live in the Infinity Cache (see the kernel's TEMPORAL note; NMFX_TEMPORAL=0/1 overrides)
+        static const int forced = getenv("NMFX_TEMPORAL") ? atoi(getenv("NMFX_TEMPORAL")) : -1;
+        const bool small = 2.0 * (double)E->mp * (double)E->np * 4.0 <= 192.0 * 1024 * 1024;
+        if (forced == 1 || (forced < 0 && small)) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, true>;
+    }
     if constexpr (OBJ && !KL && KP == 128 && TERMS == 3) {
         if (E->pair) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 2>;     // two stacked problems: one objective each
     }

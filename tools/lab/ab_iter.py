@@ -6,7 +6,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-CFG = {"cfg2": (16384, 8192, 64, 0), "cfg4": (32768, 16384, 64, 1), "cfg3shape": (16384, 8192, 128, 0)}
+CFG = {"cfg2": (16384, 8192, 64, 0), "cfg4": (32768, 16384, 64, 1), "cfg3shape": (16384, 8192, 128, 0),
+       "shard8": (2048, 8192, 64, 0), "shard4": (4096, 8192, 64, 0), "shard2": (8192, 8192, 64, 0), "c5shard8": (16384, 16384, 128, 0)}
 CHILD = r'''
 import os, sys, json, time
 sys.path.insert(0, %(root)r)
