@@ -40,9 +40,15 @@ class Referee:
         # FOURTH differences of the recorded objectives: what a smooth history leaves of itself there is far below its curvature
         # (second differences mistook the curvature of a young run for jitter and started the walk hundreds of iterations early),
         # while independent noise of spread s per value arrives with spread sqrt(70) s; the jitter of a decrease is sqrt(2) s
-        d4 = np.diff(np.asarray(history[-68:], dtype=np.float64), n=4)
+        tail = np.asarray(history[-68:], dtype=np.float64)
+        d4 = np.diff(tail, n=4)
         sigma_d = 1.4826 * np.median(np.abs(d4 - np.median(d4))) * np.sqrt(2.0 / 70.0)
-        g = min(6.0 * sigma_d, self.tol2)            # (a jitter beyond tol2 itself: the walk starts at twice tol2, not earlier)
+        g = 6.0 * sigma_d
+        if g >= 1e-6 * self.tol2:
+            # The walk can only test loop indices BEHIND the candidate (the pair in front of it is gone), so the candidate has to
+            # come at least one iteration early even without any jitter: twice the change of the decrease per iteration on top.
+            g += 2.0 * abs(np.median(np.diff(tail, n=2)))
+        g = min(g, self.tol2)                        # (a jitter beyond tol2 itself: the walk starts at twice tol2, not earlier)
         if not np.isfinite(g):                       # (a history with inf / nan in it: nothing to estimate from)
             return
         if self.mode == "1":
