@@ -7,7 +7,7 @@ system and up to `admm_iter` inner rounds (ao_admm.py:46-68) -- runs on the
 device through libnmfx (nmfx_aoadmm_run); the inner stop test (ao_admm.py:33-43)
 is evaluated on the device too.
 
-Regularisers: 'nn' and 'l1n' are built (any number of components; beyond 128 with the least-squares loss only).  'l2n' raises
+Regularisers: 'nn' and 'l1n' are built (any number of components, both losses).  'l2n' raises
 ValueError exactly like the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it is also the reference's
 DEFAULT reg_h, so callers must pass reg_h explicitly).  'l1inf' / 'l1inf_transpose' raise numpy.linalg.LinAlgError up front:
 the reference's ao_admm copy of the operator (nmf/ao_admm.py:143-195) makes the iteration blow up until a Cholesky

@@ -197,7 +197,7 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
 
 // argument checks, allocations and (for the first iteration) the start state w_aux = w, h_aux = h (admm.py:27-28)
 // with the objective partials of the initial pair (admm.py:289)
-static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count) {
+static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count, bool any_k = false) {
     if (E) E->anls_a_ready = false; E->kl_h_iter = -2;
     if (!E) return NMFX_E_ARG;
     E->himg_both = false;
@@ -210,7 +210,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
     if (first < 0 || count < 0 || !(rho >= 0.0)) { E->err = "negative iteration range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
-    if ((rc = nmfx_small_k_only(E, "ADMM"))) return rc;
+    if (!any_k && (rc = nmfx_small_k_only(E, "row-sharded ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 3))) return rc;
     if ((rc = admm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -222,6 +222,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
     if (first == 0 && count > 0) {
         NMFX_HIP(hipMemcpyAsync(E->auxW, E->W[0], (size_t)E->mp * E->kp * 4, hipMemcpyDeviceToDevice, E->stream));
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
+        if (E->kp > 128) return NMFX_OK;               // (nmfx_generic_admm_run evaluates the initial objective itself)
         if (distance == NMFX_EU) rc = admm_objective(E);
         else rc = nmfx_launch_wphase(E, E->W[0], false, true, true);
         if (rc) return rc;
@@ -250,7 +251,9 @@ extern "C" int nmfx_admm_phase_update(nmfx_handle_t E, int distance, double rho,
 extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox_w, double lambda_w, int prox_h,
                              double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
                              int64_t count) {
-    int rc = admm_begin(E, distance, rho, prox_w, prox_h, first, count); if (rc) return rc;
+    int rc = admm_begin(E, distance, rho, prox_w, prox_h, first, count, true); if (rc) return rc;
+    if (E->kp > 128)           // composed from the generic product kernel (kernels_generic.hip)
+        return nmfx_generic_admm_run(E, distance, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, first, count);
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)

@@ -1697,7 +1697,6 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
     int rc;
-    if (distance != NMFX_EU && (rc = nmfx_small_k_only(E, "AO-ADMM with the KL loss"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -1706,7 +1705,9 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     E->wsel = 0;
     E->w_in_place = true;
     if (E->kp > 128)           // composed from the generic product kernel (kernels_generic.hip)
-        return nmfx_generic_aoadmm_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count);
+        return distance == NMFX_EU
+            ? nmfx_generic_aoadmm_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count)
+            : nmfx_generic_aoadmm_kl_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count);
     if (distance != NMFX_EU) { E->lazy_objective = false; E->himg_both = false; }
     if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
         if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int GX_T = 128, GX_KC = 16, GX_LD = 144;
 
-enum { GX_STORE = 0, GX_RESID = 1, GX_KLQ = 2 };
+enum { GX_STORE = 0, GX_RESID = 1, GX_KLQ = 2, GX_VAUX = 3 };
 
 // one operand's chunk [GX_KC][128]: global -> registers (two float4 per thread), registers -> LDS plane [k][GX_LD].
 // KCONTIG: element (row, t) at base[row * ld + t]; else element (t, col) at base[t * ld + col].
@@ -65,13 +65,15 @@ __device__ __forceinline__ void gx_store(float* __restrict__ plane, int tid, con
 // C[z][i][j] = sum_{t in split z} A(i, t) B(t, j)     (i < 128 gridDim.y, j < 128 gridDim.x)
 //   AK: A(i, t) = A[i * lda + t], else A[t * lda + i];   BK: B(t, j) = B[j * ldb + t], else B[t * ldb + j]
 //   MODE GX_STORE: C stored.  GX_RESID: nothing stored, part[block] = 1/2 sum (X - C)^2 (utils.py:29).
-//   GX_KLQ: Q = X / (C + 1e-9) stored (mur.py:25,41) and, with part != nullptr, part[block] = the KL objective of the tile
+//   GX_KLQ: Q = X / (C + 1e-9) stored (mur.py:25,41; not with C == nullptr) and, with part != nullptr, part[block] = the KL objective of the tile
 //   (utils.py:23-26: x log(x / c) with inf / nan -> 0, - x + c).
+//   GX_VAUX (KL-loss ADMM, ao_admm.py:90-95 / admm.py:312-315): with P = the product, X = V, C = dual_v, C2 = S:
+//   v_aux = ((P - dual_v - 1) + sqrt((P - dual_v - 1)^2 + 4 V)) / 2;  dual_v += v_aux - P;  S = v_aux + dual_v  (P is not stored).
 template <bool AK, bool BK, int MODE>
 __global__ __launch_bounds__(256) void gx_gemm_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     int64_t cstride, int64_t K, const float* __restrict__ X, int64_t ldx, double* __restrict__ part, const int* __restrict__ flag,
-    const int* __restrict__ flag2)
+    const int* __restrict__ flag2, float* __restrict__ C2 = nullptr)
 {
     if (*flag || (flag2 && *flag2)) return;
     __shared__ __attribute__((aligned(16))) float lds[2][2][128 * GX_LDK];         // [buffer][A / B]: [k][GX_LD] or [row][GX_LDK] (>= 16 x 144 floats)
@@ -141,6 +143,22 @@ __global__ __launch_bounds__(256) void gx_gemm_kernel(
                     Cz[(i0 + wr + 16 * a + 4 * q + r) * ldc + j0 + wc + 16 * b + x] = acc[a][b][r];
         return;
     }
+    if (MODE == GX_VAUX) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t row = i0 + wr + 16 * a + 4 * q + r, col = j0 + wc + 16 * b + x;
+                    const float pv = acc[a][b][r], dv = C[row * ldc + col], t = (pv - dv) - 1.f;
+                    const float va = 0.5f * (t + sqrtf(t * t + 4.f * X[row * ldx + col]));
+                    const float dn = dv + va - pv;
+                    C[row * ldc + col] = dn;
+                    C2[row * ldc + col] = va + dn;
+                }
+        return;
+    }
     double tot = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void gx_gemm_kernel(
                     const float d = xv - cv;
                     if (b & 1) s1 += d * d; else s0 += d * d;
                 } else {
-                    C[(i0 + wr + 16 * a + 4 * q + r) * ldc + j0 + wc + 16 * b + x] = xv / (cv + 1e-9f);
+                    if (C) C[(i0 + wr + 16 * a + 4 * q + r) * ldc + j0 + wc + 16 * b + x] = xv / (cv + 1e-9f);
                     if (part) {
                         float t = xv * logf(xv / cv);
                         t = (t != t || t == __builtin_inff() || t == -__builtin_inff()) ? 0.f : t;
@@ -342,11 +360,12 @@ int gx_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
 
 template <bool AK, bool BK>
 int gx_launch(nmfx_engine* E, int mode, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t cstride,
-              int64_t M, int64_t N, int64_t K, int S, const float* X, int64_t ldx, double* part, const int* flag2 = nullptr) {
+              int64_t M, int64_t N, int64_t K, int S, const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, float* C2 = nullptr) {
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
     if (mode == GX_STORE) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_STORE>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
     else if (mode == GX_RESID) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_RESID>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    else if (mode == GX_VAUX) hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_VAUX>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2, C2);
     else hipLaunchKernelGGL((gx_gemm_kernel<AK, BK, GX_KLQ>), grid, block, 0, E->stream, A, lda, B, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -364,13 +383,14 @@ int gx_buffers(nmfx_engine* E, bool kl) {
 }
 
 // split-K product into the slab buffer gx_s, summed into `out`
+// (flag2: a second skip flag for the product launches; the slab sum behind them is idempotent and runs regardless)
 template <bool AK, bool BK>
 int gx_split_product(nmfx_engine* E, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K,
-                     int cap) {
+                     int cap, const int* flag2 = nullptr) {
     int rc;
     const int S = gx_split(E, (M / GX_T) * (N / GX_T), K, cap);
-    if (S == 1) return gx_launch<AK, BK>(E, GX_STORE, A, lda, B, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr);
-    if ((rc = gx_launch<AK, BK>(E, GX_STORE, A, lda, B, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr))) return rc;
+    if (S == 1) return gx_launch<AK, BK>(E, GX_STORE, A, lda, B, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr, flag2);
+    if ((rc = gx_launch<AK, BK>(E, GX_STORE, A, lda, B, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr, flag2))) return rc;
     return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
 }
 
@@ -477,7 +497,7 @@ namespace {
 // the matrix in a global f64 work area (L2-resident), pivot row and column through LDS, two barriers per pivot.  fixed_rho >= 0
 // replaces trace / k.  Also opens the sub-problem: inner_stop = inner_count = 0.
 __global__ __launch_bounds__(1024) void gx_prepare_kernel(const float* __restrict__ G, int kp, int k, double* __restrict__ work,
-                                                          float* __restrict__ Minv, DevState* __restrict__ st)
+                                                          float* __restrict__ Minv, DevState* __restrict__ st, double fixed_rho)
 {
     if (st->flag) return;
     extern __shared__ double gsh[];                    // row [kp] | col [kp] | 16 partials
@@ -494,6 +514,7 @@ __global__ __launch_bounds__(1024) void gx_prepare_kernel(const float* __restric
     double rho = 0.0;
     for (int w = 0; w < nt / 64; ++w) rho += part[w];
     rho /= (double)k;
+    if (fixed_rho >= 0.0) rho = fixed_rho;
     const int64_t kk = (int64_t)kp * kp;
     for (int64_t e = tid; e < kk; e += nt) work[e] = (double)G[e] + ((e / kp) == (e % kp) ? rho : 0.0);
     __syncthreads();
@@ -598,17 +619,23 @@ __global__ void gx_close_kernel(DevState* __restrict__ st, int32_t* __restrict__
     st->inner_stop = 0;
 }
 
+// M^-1 = (G + rho I)^-1 -> E->Minv, st->rho (fixed_rho < 0: trace(G) / k), the inner-round state reset
+int gx_prepare(nmfx_engine* E, const float* G, double fixed_rho) {
+    ProfScope ps(E, "prepare");
+    const size_t shm = (size_t)(2 * E->kp + 16) * sizeof(double);
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gx_prepare_kernel), (int)shm); if (rc) return rc;
+    hipLaunchKernelGGL(gx_prepare_kernel, dim3(1), dim3(1024), shm, E->stream, G, (int)E->kp, E->k, E->gx_w64, E->Minv, E->state, fixed_rho);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // one sub-problem (ao_admm.py:46-68) on the factor X ([rows][cols] with the factor index along `cols` for W: rows = m,
 // cols = kp -- or along `rows` for H: rows = kp, cols = n), its dual U, the Gram matrix G and the cross product B
 int gx_ao_subproblem(nmfx_engine* E, bool hside, const float* G, const float* B, float* X, float* U, int prox, float lam, int admm_iter,
                      int32_t* slot) {
     int rc;
     const int64_t kp = E->kp, rows = hside ? kp : E->mp, cols = hside ? E->np : kp, cnt4 = rows * cols / 4;
-    const size_t shm = (size_t)(2 * kp + 16) * sizeof(double);
-    { ProfScope ps(E, "prepare");
-      if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gx_prepare_kernel), (int)shm))) return rc;
-      hipLaunchKernelGGL(gx_prepare_kernel, dim3(1), dim3(1024), shm, E->stream, G, (int)kp, E->k, E->gx_w64, E->Minv, E->state);
-      NMFX_HIP(hipGetLastError()); }
+    if ((rc = gx_prepare(E, G, -1.0))) return rc;
     ProfScope ps(E, hside ? "inner_h" : "inner_w");
     const int nblk = (int)((cnt4 + 255) / 256);
     const int* stop = &E->state->inner_stop;
@@ -669,6 +696,202 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
         if ((rc = gx_ao_subproblem(E, false, E->HHt, E->A_part, W, E->dualW, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
         if ((rc = gx_objective_partial(E))) return rc;
     }
+    return NMFX_OK;
+}
+
+// ---- AO-ADMM with the KL loss (nmf/ao_admm.py:71-101, 274-289) and ADMM (nmf/admm.py:216-230, 292-334) for k > 128 --------------------
+namespace {
+
+// out = a - b
+__global__ __launch_bounds__(256) void gx_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t count4,
+                                                      const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count4) return;
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+}
+
+// prox 'l2n' behind its operator product (admm.py:141-156): X = max(P (aux - U), 0) = max(d, 0);  U += X - aux (admm.py:321-322)
+__global__ __launch_bounds__(256) void gx_l2n_finish_kernel(const float* __restrict__ d, const float* __restrict__ aux, float* __restrict__ X,
+                                                            float* __restrict__ U, int64_t count4, const int* __restrict__ flag)
+{
+    if (*flag) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count4) return;
+    const float4 d4 = reinterpret_cast<const float4*>(d)[i], a4 = reinterpret_cast<const float4*>(aux)[i];
+    float4 u4 = reinterpret_cast<float4*>(U)[i];
+    const float4 x4 = make_float4(d4.x < 0.f ? 0.f : d4.x, d4.y < 0.f ? 0.f : d4.y, d4.z < 0.f ? 0.f : d4.z, d4.w < 0.f ? 0.f : d4.w);
+    u4.x += x4.x - a4.x; u4.y += x4.y - a4.y; u4.z += x4.z - a4.z; u4.w += x4.w - a4.w;
+    reinterpret_cast<float4*>(X)[i] = x4;
+    reinterpret_cast<float4*>(U)[i] = u4;
+}
+
+int gx_kl_objective_partial(nmfx_engine* E) {        // KL(V, W H) (utils.py:21-26) of the current pair -> xf64[0]; the quotient is not stored
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    { ProfScope ps(E, "objective");
+      if ((rc = gx_launch<true, false>(E, GX_KLQ, E->W[0], kp, E->H, np, nullptr, np, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
+    return nmfx_launch_obj_reduce(E, (mp / GX_T) * (np / GX_T), E->gx_part);
+}
+
+int gx_admm_buffers(nmfx_engine* E) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if ((rc = gx_buffers(E, false))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_r, std::max(mp, np) * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_w64, kp * kp))) return rc;
+    return gx_alloc(E, &E->gx_nrm, std::max(mp, np) * kp / 1024 * 4 + 64);
+}
+
+// one KL sub-problem (ao_admm.py:71-101): hside: X = H ([kp][np]), other factor W, data S = v_aux + dual_v; else X = W on the
+// transposed data.  G = the other factor's Gram matrix.
+int gx_ao_kl_subproblem(nmfx_engine* E, bool hside, const float* G, int prox, float lam, int admm_iter, int32_t* slot) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp, rows = hside ? kp : mp, cols = hside ? np : kp, cnt4 = rows * cols / 4;
+    float* W = E->W[0];
+    float* X = hside ? E->H : W;
+    float* U = hside ? E->dualH : E->dualW;
+    if ((rc = gx_prepare(E, G, -1.0))) return rc;
+    ProfScope ps(E, hside ? "inner_h" : "inner_w");
+    const int nblk = (int)((cnt4 + 255) / 256);
+    const int* stop = &E->state->inner_stop;
+    for (int r = 0; r < admm_iter; ++r) {
+        // right-hand side product with the CURRENT S (ao_admm.py:85)
+        if (hside) rc = gx_split_product<false, false>(E, W, kp, E->S, np, E->xf32, kp, np, mp, 8, stop);
+        else rc = gx_split_product<true, true>(E, E->S, np, E->H, np, E->A_part, mp, kp, np, 1, stop);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, hside ? (const float*)E->xf32 : (const float*)E->A_part,
+                           (const float*)X, (const float*)U, E->gx_r, cnt4, (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        if (hside) rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr, stop);
+        else rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr, stop);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, X, U, prox, lam, cnt4, E->gx_nrm,
+                           (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        // v_aux, dual_v from P = (other factor) x (this round's aux) (ao_admm.py:90-95): the aux matrix is gx_d
+        if (hside) rc = gx_launch<true, false>(E, GX_VAUX, W, kp, E->gx_d, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, stop, E->S);
+        else rc = gx_launch<true, false>(E, GX_VAUX, E->gx_d, kp, E->H, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, stop, E->S);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_decide_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->state);
+        NMFX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gx_close_kernel, dim3(1), dim3(1), 0, E->stream, E->state, slot);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// X = prox(aux, U), U += X - aux for one side of the ADMM state (admm.py:117-156, 321-322)
+int gx_admm_prox(nmfx_engine* E, bool hside, int prox, double rho, double lam) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp, cnt4 = (hside ? kp * np : mp * kp) / 4;
+    const int nblk = (int)((cnt4 + 255) / 256);
+    const float* aux = hside ? E->auxH : E->auxW;
+    float* X = hside ? E->H : E->W[0];
+    float* U = hside ? E->dualH : E->dualW;
+    const int* flag = &E->state->flag;
+    ProfScope ps(E, hside ? "inner_h" : "inner_w");
+    if (prox == NMFX_PROX_NN || prox == NMFX_PROX_L1N) {
+        hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, aux, X, U, prox, (float)lam, cnt4, E->gx_nrm, (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
+    if (prox == NMFX_PROX_L2N) {                       // P is symmetric ((lambda T^T T + rho I) / rho)^-1: W-like operands take it from the right
+        hipLaunchKernelGGL(gx_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, aux, (const float*)U, E->gx_r, cnt4, flag);
+        NMFX_HIP(hipGetLastError());
+        if (hside) rc = gx_launch<true, false>(E, GX_STORE, E->Ph, kp, E->gx_r, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr);
+        else rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Pw, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_l2n_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, aux, X, U, cnt4, flag);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
+    if (prox == NMFX_PROX_L1INF) return nmfx_launch_prox_l1inf(E, hside, false, rho, lam, 1.0, true);
+    E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components";
+    return NMFX_E_ARG;
+}
+
+}  // namespace
+
+int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
+                               double tol1, double tol2, int64_t first, int64_t count) {
+    int rc;
+    if ((rc = gx_admm_buffers(E))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    float* W = E->W[0];
+    float* xG = E->xf32 + kp * np;
+    if (first == 0 && count > 0 && (rc = gx_kl_objective_partial(E))) return rc;   // obj[0] (ao_admm.py:256)
+    for (int64_t j = first; j < first + count; ++j) {
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
+        if ((rc = gx_ao_kl_subproblem(E, true, xG, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2))) return rc;
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        if ((rc = gx_ao_kl_subproblem(E, false, E->HHt, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+        if ((rc = gx_kl_objective_partial(E))) return rc;
+    }
+    return NMFX_OK;
+}
+
+// ADMM (one level, fixed rho): aux_update twice, prox twice, dual updates, KL: v_aux / dual_v from w_aux h_aux (admm.py:292-324).
+// The caller (nmfx_admm_run) has allocated the ADMM state and, for the first iteration, set w_aux = w, h_aux = h.
+int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
+                          double tol1, double tol2, int64_t first, int64_t count) {
+    int rc;
+    if (prox_w == NMFX_PROX_L1INF_T || prox_h == NMFX_PROX_L1INF_T) {
+        E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components"; return NMFX_E_ARG; }
+    if ((rc = gx_admm_buffers(E))) return rc;
+    const bool kl = distance == NMFX_KL;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    float* W = E->W[0];
+    float* xB = E->xf32;
+    float* xG = E->xf32 + kp * np;
+    const float* data = kl ? E->S : E->V;              // (KL: v_aux + dual_v, admm.py:224)
+    const int* flag = &E->state->flag;
+    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;     // (admm.py:289)
+    for (int64_t j = first; j < first + count; ++j) {
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        // h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T data + rho (h + dual_h))
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, E->auxW, kp, E->auxW, kp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");
+          if ((rc = gx_split_product<false, false>(E, E->auxW, kp, data, np, xB, kp, np, mp, 8))) return rc; }
+        if ((rc = gx_prepare(E, xG, rho))) return rc;
+        { ProfScope ps(E, "inner_h");
+          const int64_t c4 = kp * np / 4;
+          hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)xB, (const float*)E->H,
+                             (const float*)E->dualH, E->gx_r, c4, (const DevState*)E->state);
+          NMFX_HIP(hipGetLastError());
+          if ((rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, np, E->auxH, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc; }
+        // w_aux^T = (h_aux h_aux^T + rho I)^-1 (h_aux data^T + rho (w^T + dual_w^T)), from the NEW h_aux
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->auxH, np, E->auxH, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");
+          if ((rc = gx_split_product<true, true>(E, data, np, E->auxH, np, E->A_part, mp, kp, np, 1))) return rc; }
+        if ((rc = gx_prepare(E, E->HHt, rho))) return rc;
+        { ProfScope ps(E, "inner_w");
+          const int64_t c4 = mp * kp / 4;
+          hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->A_part, (const float*)W,
+                             (const float*)E->dualW, E->gx_r, c4, (const DevState*)E->state);
+          NMFX_HIP(hipGetLastError());
+          if ((rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->auxW, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc; }
+        // h = prox(h_aux, dual_h), w = prox(w_aux, dual_w), duals += x - x_aux
+        if ((rc = gx_admm_prox(E, true, prox_h, rho, lam_h))) return rc;
+        if ((rc = gx_admm_prox(E, false, prox_w, rho, lam_w))) return rc;
+        if (kl) {                                      // v_aux, dual_v from w_aux h_aux (admm.py:312-315)
+            ProfScope ps(E, "kl_vaux");
+            if ((rc = gx_launch<true, false>(E, GX_VAUX, E->auxW, kp, E->auxH, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, nullptr, E->S))) return rc;
+        }
+        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;
+    }
+    (void)flag;
     return NMFX_OK;
 }
 

@@ -225,11 +225,15 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
 int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j);
 int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
                             double tol1, double tol2, int64_t first, int64_t count);
+int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
+                               double tol1, double tol2, int64_t first, int64_t count);
+int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
+                          double tol1, double tol2, int64_t first, int64_t count);
 int nmfx_preload_generic();
 // the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
 inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {
     if (E->kp <= 128) return NMFX_OK;
-    E->err = std::string(what) + ": more than 128 components are supported by the MUR solvers only in this build";
+    E->err = std::string(what) + ": more than 128 components are supported by MUR, AO-ADMM and ADMM (single GPU) only in this build";
     return NMFX_E_ARG;
 }
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);

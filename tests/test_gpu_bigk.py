@@ -59,17 +59,70 @@ def test_aoadmm_beyond_128_components_vs_oracle(shape, k, regs):
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)
 
 
-def test_other_solvers_say_so_beyond_128_components():
+@pytest.mark.parametrize("distance,regs,rho", [
+    ("eu", ((0, "nn"), (0, "l2n")), 1.0),                      # the reference's defaults (reg_h = (0, 'l2n'))
+    ("eu", ((0.02, "l1n"), (0.1, "l2n")), 1.0),
+    ("eu", ((0.05, "l1n"), (0.05, "l1n")), 2.0),
+    ("kl", ((0, "nn"), (0.05, "l1n")), 1.0),
+])
+def test_admm_beyond_128_components_vs_oracle(distance, regs, rho):
+    """ADMM (nmf/admm.py:292-334) for k > 128: the shifted Gram systems by an f64 Gauss-Jordan inversion, every product on the
+    generic exact-f32 MFMA kernel, 'l2n' through its k x k operator, the KL auxiliaries in the epilogue of w_aux h_aux."""
+    from nmf_amd.admm import admm
+    m, n, k = 520, 400, 160
+    v = R.planted_matrix(m, n, 24, seed=m + k, dtype=np.float32)
+    kw = dict(rho=rho, distance_type=distance, reg_w=regs[0], reg_h=regs[1], min_iter=8, max_iter=8, nndsvd_init=(True, "zero"))
+    res = admm(v.copy(), k, **kw)
+    ref = R.admm(v.astype(np.float64), k, **kw)
+    assert res.w.shape == (m, k) and res.h.shape == (k, n)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    rel = np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history))
+    print(f"\nADMM k={k} {distance} {regs}: WH {err:.2e}, objective max rel diff {rel:.2e}")
+    assert err < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=5e-4)
+
+
+def test_admm_l1inf_beyond_128_components_like_the_small_k_path():
+    """'l1inf' (one vector per factor) has no limit on k; 'l1inf_transpose' sorts a column's k entries in one wavefront and says so."""
     from nmf_amd._lib import NmfxError
     from nmf_amd.admm import admm
-    from nmf_amd.anls import anls
+    m, n, k = 300, 260, 160
+    v = R.planted_matrix(m, n, 12, seed=4, dtype=np.float32)
+    kw = dict(rho=1.0, distance_type="eu", reg_w=(0, "nn"), reg_h=(0.1, "l1inf"), min_iter=2, max_iter=2, nndsvd_init=(True, "zero"))
+    res = admm(v.copy(), k, **kw)
+    ref = R.admm(v.astype(np.float64), k, **kw)
+    assert res.i == ref.i
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-3)
+    with pytest.raises(NmfxError, match="l1inf_transpose"):
+        admm(v.copy(), k, rho=1.0, reg_w=(0, "nn"), reg_h=(0.1, "l1inf_transpose"), max_iter=2, nndsvd_init=(False, "zero"))
+
+
+@pytest.mark.parametrize("regs", [((0, "nn"), (0, "nn")), ((0.05, "l1n"), (0.02, "l1n"))])
+def test_aoadmm_kl_beyond_128_components_vs_oracle(regs):
+    """AO-ADMM with the KL loss (nmf/ao_admm.py:71-101) for k > 128: per round W^T (v_aux + dual_v), the Gram solve, prox, and
+    v_aux / dual_v in the epilogue of the product W h_aux; inner round counts equal to the oracle's."""
     from nmf_amd.ao_admm import ao_admm
+    m, n, k = 520, 400, 160
+    v = R.planted_matrix(m, n, 24, seed=m + k + 1, dtype=np.float32)
+    kw = dict(distance_type="kl", reg_w=regs[0], reg_h=regs[1], min_iter=5, max_iter=5, admm_iter=6, nndsvd_init=(True, "zero"))
+    res = ao_admm(v.copy(), k, **kw)
+    ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2
+    assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    rel = np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history))
+    print(f"\nAO-ADMM-KL k={k} {regs}: WH {err:.2e}, objective max rel diff {rel:.2e}")
+    assert err < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
+
+
+def test_anls_says_so_beyond_128_components():
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.anls import anls
     v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
-    for call in (lambda: admm(v.copy(), 160, reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
-                 lambda: ao_admm(v.copy(), 160, distance_type="kl", reg_w=(0, "nn"), reg_h=(0, "nn"), max_iter=2, nndsvd_init=(False, "zero")),
-                 lambda: anls(v.copy(), 160, max_iter=2, nndsvd_init=(False, "zero"))):
-        with pytest.raises(NmfxError, match="more than 128 components"):
-            call()
+    with pytest.raises(NmfxError, match="more than 128 components"):
+        anls(v.copy(), 160, max_iter=2, nndsvd_init=(False, "zero"))
 
 
 def test_mur_eu_16384x8192_k256_vs_oracle():
