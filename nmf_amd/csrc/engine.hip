@@ -226,7 +226,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
-                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys};
+                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;

@@ -866,7 +866,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0 || lam < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
-    { int rc_ = nmfx_small_k_only(E, "ANLS"); if (rc_) return rc_; rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
+    { int rc_ = nmfx_small_k_only(E, "row-sharded ANLS"); if (rc_) return rc_; rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
     NMFX_HIP(hipSetDevice(E->device));
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
@@ -914,8 +914,14 @@ extern "C" int nmfx_anls_run(nmfx_handle_t E, double lambda_w, double lambda_h, 
     if (first < 0 || count < 0 || lambda_w < 0 || lambda_h < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
-    if ((rc = nmfx_small_k_only(E, "ANLS"))) return rc;
     if ((rc = nmfx_enter_family(E, 4))) return rc;
+    if (E->kp > 128) {         // one workgroup per right-hand side, systems in a global f64 work area (kernels_generic.hip)
+        if ((rc = nmfx_ensure_obj_capacity(E, first + count + 2))) return rc;
+        E->wsel = 0;
+        E->w_in_place = true;
+        E->anls_a_ready = false;
+        return nmfx_generic_anls_run(E, lambda_w, lambda_h, min_iter, tol1, tol2, first, count);
+    }
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
         NMFX_HIP(hipMemsetAsync(E->Asum, 0, (size_t)E->mp * E->kp * sizeof(float), E->stream));

@@ -895,6 +895,225 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
     return NMFX_OK;
 }
 
+// ---- ANLS (nmf/anls.py:18-47, 111-122) for k > 128 -------------------------------------------------------------------------------------
+// The tuned NNLS kernels (kernels_anls.hip) keep one k x k system per wavefront in registers / LDS, which ends at k = 128.  Here one
+// WORKGROUP owns one right-hand side and the passive-set system lives in a global f64 work area (L2 / Infinity-Cache resident):
+// the same exact active-set method -- block principal pivoting with the back-up rule, warm-started from the support of the previous
+// iterate, the same rounding-level infeasibility threshold and pivot guard -- with the passive-set solve done by a right-looking
+// Cholesky factorisation in float64 on the gathered system [G_PP; r_P^T] (the extra row makes the forward substitution part of the
+// factorisation) and a back substitution through LDS.  Persistent blocks loop over the right-hand sides.
+namespace {
+
+#define GX_NNLS_TOL 1e-6
+#define GX_NNLS_PIVOT_EPS 1e-6
+
+__device__ __forceinline__ double gx_block_max(double v, double* red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__device__ __forceinline__ int gx_block_sum_i(int v, int* red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ int gx_block_max_i(int v, int* red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// X[:, c] = argmin_{x >= 0} 1/2 x^T (G + diag_add I) x - r_c^T x for every right-hand side c < nprob; variable i of problem c at
+// [i * sj + c * sc] in R and X; X on entry = the warm start (its support).  G is [kp][kp] with zero padding beyond k.
+__global__ __launch_bounds__(256) void gx_nnls_kernel(const float* __restrict__ G, int kp, double diag_add, const float* __restrict__ R,
+                                                      float* __restrict__ X, int64_t sj, int64_t sc, int64_t nprob, int k,
+                                                      double* __restrict__ work, DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gx_nnls_smem[];
+    double* zs = reinterpret_cast<double*>(gx_nnls_smem);      // [kp] right-hand side of the back substitution
+    double* xs = zs + kp;                                      // [kp] solution by POSITION in the passive list
+    double* ldiag = xs + kp;                                   // [kp] diagonal of the Cholesky factor (0: dropped pivot)
+    float* rs = reinterpret_cast<float*>(ldiag + kp);          // [kp] right-hand side by variable
+    int* plist = reinterpret_cast<int*>(rs + kp);              // [kp] passive variables, ascending
+    unsigned char* inF = reinterpret_cast<unsigned char*>(plist + kp);
+    unsigned char* dead = inF + kp;
+    unsigned char* badf = dead + kp;
+    __shared__ double redd[4];
+    __shared__ int redi[4];
+    __shared__ int sh_p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double* M = work + (int64_t)blockIdx.x * ((int64_t)kp + 1) * kp;
+    const int cap = 8 * k + 64;
+    for (int64_t c = blockIdx.x; c < nprob; c += gridDim.x) {
+        __syncthreads();
+        double ar = 0.0;
+        for (int i = tid; i < k; i += 256) {
+            const float rv = R[(int64_t)i * sj + c * sc];
+            rs[i] = rv; ar = fmax(ar, fabs((double)rv));
+            inF[i] = X[(int64_t)i * sj + c * sc] > 0.f ? 1 : 0;
+            dead[i] = 0;
+        }
+        const double toly = GX_NNLS_TOL * gx_block_max(ar, redd, tid);
+        int best = k + 1, spare = 3, p = 0;
+        bool capped = true;
+        for (int iter = 0; iter < cap; ++iter) {
+            // ---- passive list (wave 0: ballot compaction in ascending order) ----
+            __syncthreads();
+            if (tid < 64) {
+                int base = 0;
+                for (int i0 = 0; i0 < k; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool on = i < k && inF[i] && !dead[i];
+                    const unsigned long long m = __ballot(on);
+                    if (on) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                    base += __popcll(m);
+                }
+                if (lane == 0) sh_p = base;
+            }
+            __syncthreads();
+            p = sh_p;
+            // ---- gather [G_PP + diag_add I; r_P^T] (lower triangle and the extra row) ----
+            for (int64_t e = tid; e < (int64_t)(p + 1) * p; e += 256) {
+                const int i = (int)(e / p), l = (int)(e % p);
+                double v;
+                if (i == p) v = (double)rs[plist[l]];
+                else if (l > i) continue;
+                else v = (double)G[(int64_t)plist[i] * kp + plist[l]] + (i == l ? diag_add : 0.0);
+                M[e] = v;
+            }
+            __syncthreads();
+            // ---- right-looking Cholesky; row p carries the forward substitution ----
+            for (int j = 0; j < p; ++j) {
+                const double d = M[(int64_t)j * p + j];
+                const int vj = plist[j];
+                const double gjj = (double)G[(int64_t)vj * kp + vj] + diag_add;
+                if (!(d > GX_NNLS_PIVOT_EPS * gjj)) {              // (block-uniform) dropped pivot: the variable keeps x = 0 for the rest of this solve
+                    for (int i = j + 1 + tid; i <= p; i += 256) M[(int64_t)i * p + j] = 0.0;
+                    if (tid == 0) { ldiag[j] = 0.0; dead[vj] = 1; atomicAdd(&st->nnls_evicted, 1); }
+                    __syncthreads();
+                    continue;
+                }
+                const double sq = sqrt(d), inv = 1.0 / sq;
+                for (int i = j + 1 + tid; i <= p; i += 256) M[(int64_t)i * p + j] *= inv;
+                if (tid == 0) ldiag[j] = sq;
+                __syncthreads();
+                const int nr = p - j, nc = p - 1 - j;              // rows j + 1 .. p, columns j + 1 .. p - 1
+                for (int64_t e = tid; e < (int64_t)nr * nc; e += 256) {
+                    const int i = j + 1 + (int)(e / nc), l = j + 1 + (int)(e % nc);
+                    if (l <= i) M[(int64_t)i * p + l] -= M[(int64_t)i * p + j] * M[(int64_t)l * p + j];
+                }
+                __syncthreads();
+            }
+            // ---- back substitution L^T x = z ----
+            for (int l = tid; l < p; l += 256) zs[l] = M[(int64_t)p * p + l];
+            __syncthreads();
+            for (int j = p - 1; j >= 0; --j) {
+                const double dj = ldiag[j];
+                const double xj = dj > 0.0 ? zs[j] / dj : 0.0;
+                for (int l = tid; l < j; l += 256) zs[l] -= M[(int64_t)j * p + l] * xj;
+                if (tid == 0) xs[j] = xj;
+                __syncthreads();
+            }
+            // ---- infeasible variables: x_i < 0 in the passive set, y_i = (G x - r)_i < 0 outside it ----
+            double ax = 0.0;
+            for (int l = tid; l < p; l += 256) ax = fmax(ax, fabs(xs[l]));
+            const double tolx = GX_NNLS_TOL * gx_block_max(ax, redd, tid);
+            for (int i = tid; i < k; i += 256) badf[i] = 0;
+            __syncthreads();
+            int ninf = 0, hi = -1;
+            for (int l = tid; l < p; l += 256) {
+                const int v = plist[l];
+                if (!dead[v] && xs[l] < -tolx) { badf[v] = 1; ++ninf; hi = max(hi, v); }
+            }
+            for (int i = tid; i < k; i += 256) {
+                if (inF[i] || dead[i]) continue;
+                double y = -(double)rs[i];
+                const float* grow = G + (int64_t)i * kp;
+                for (int l = 0; l < p; ++l) y += (double)grow[plist[l]] * xs[l];
+                if (y < -toly) { badf[i] = 1; ++ninf; hi = max(hi, i); }
+            }
+            const int total = gx_block_sum_i(ninf, redi, tid);
+            if (total == 0) { capped = false; break; }
+            bool full = true;
+            if (total < best) { best = total; spare = 3; }
+            else if (spare > 0) --spare;
+            else full = false;
+            const int top = gx_block_max_i(hi, redi, tid);        // (also orders the badf writes before the reads below)
+            for (int i = tid; i < k; i += 256)
+                if (badf[i] && (full || i == top)) inF[i] ^= 1;
+        }
+        __syncthreads();
+        // ---- write the solution (the passive list of the last solve; everything else is zero) ----
+        for (int i = tid; i < k; i += 256) X[(int64_t)i * sj + c * sc] = 0.f;
+        __syncthreads();
+        for (int l = tid; l < p; l += 256) {
+            const double xv = xs[l];
+            X[(int64_t)plist[l] * sj + c * sc] = xv > 0.0 ? (float)xv : 0.f;
+        }
+        if (capped && tid == 0) atomicAdd(&st->nnls_capped, 1);
+    }
+}
+
+int gx_nnls(nmfx_engine* E, const float* G, double diag_add, const float* R, float* X, int64_t sj, int64_t sc, int64_t nprob) {
+    ProfScope ps(E, "nnls");
+    const int64_t kp = E->kp, per = (kp + 1) * kp;
+    int64_t nb = std::min<int64_t>(std::min<int64_t>(4 * (int64_t)E->ncu, nprob), std::max<int64_t>(1, ((int64_t)1 << 30) / (per * 8)));
+    nb = std::max<int64_t>(nb, 1);
+    if (E->gx_nnls_cap < nb * per) {
+        if (E->gx_nnls_work) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->gx_nnls_work); E->gx_nnls_work = nullptr; }
+        NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->gx_nnls_work), (size_t)(nb * per) * sizeof(double)));
+        E->gx_nnls_cap = nb * per;
+    }
+    const size_t shm = (size_t)kp * (3 * sizeof(double) + sizeof(float) + sizeof(int) + 3);
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gx_nnls_kernel), (int)shm); if (rc) return rc;
+    hipLaunchKernelGGL(gx_nnls_kernel, dim3((unsigned)nb), dim3(256), shm, E->stream, G, (int)kp, diag_add, R, X, sj, sc, nprob, E->k,
+                       E->gx_nnls_work, E->state);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+}  // namespace
+
+// ANLS outer iterations (anls.py:111-126): rows of W from G = H H^T + 2 lw I, r = rows of V H^T; columns of H from G = W^T W + 2 lh I,
+// r = columns of W^T V; the objective (Euclidean or KL, E->anls_dist) of the new pair
+int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2, int64_t first, int64_t count) {
+    int rc;
+    if ((rc = gx_buffers(E, false))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    const bool kl = E->anls_dist == NMFX_KL;
+    float* W = E->W[0];
+    float* xB = E->xf32;
+    float* xG = E->xf32 + kp * np;
+    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;     // obj[0] (anls.py:108)
+    for (int64_t j = first; j < first + count; ++j) {
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");
+          if ((rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1))) return rc; }
+        if ((rc = gx_nnls(E, E->HHt, 2.0 * lam_w, E->A_part, W, 1, kp, E->m))) return rc;
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");
+          if ((rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
+        if ((rc = gx_nnls(E, xG, 2.0 * lam_h, xB, E->H, np, 1, E->n))) return rc;
+        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;
+    }
+    return NMFX_OK;
+}
+
 // The Euclidean objective of the CURRENT pair (W as nmfx_get_factors would return it, H) evaluated entirely in float64 on the
 // device: the referee of the stop rule near the stop (see gx_resid64_kernel).  Synchronises.  Any k.
 extern "C" int nmfx_objective_f64(nmfx_handle_t E, double* out) {

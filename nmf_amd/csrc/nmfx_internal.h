@@ -95,6 +95,7 @@ struct nmfx_engine {
     float* gx_r = nullptr;         // AO-ADMM for k > 128: right-hand side of a round
     double* gx_w64 = nullptr;      // ... the f64 work matrix of the Gauss-Jordan inversion
     double* gx_nrm = nullptr;      // ... norm partials of a round
+    double* gx_nnls_work = nullptr; int64_t gx_nnls_cap = 0;   // ANLS for k > 128: per-block f64 systems of the passive-set solves
     struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
@@ -229,6 +230,7 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
                                double tol1, double tol2, int64_t first, int64_t count);
 int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
                           double tol1, double tol2, int64_t first, int64_t count);
+int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2, int64_t first, int64_t count);
 int nmfx_preload_generic();
 // the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
 inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {

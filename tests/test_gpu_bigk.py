@@ -1,5 +1,5 @@
 """More than 128 components (missing 1): the reference takes any `factors` (nmf/nmf.py:32-35, nmf/mur.py:52).
-MUR (both divergences) composes its iteration from the generic exact-f32 product kernel (kernels_generic.hip) beyond k = 128."""
+All four solvers compose their iterations from the generic exact-f32 product kernel (kernels_generic.hip) beyond k = 128."""
 import numpy as np
 import pytest
 
@@ -117,12 +117,65 @@ def test_aoadmm_kl_beyond_128_components_vs_oracle(regs):
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
 
 
-def test_anls_says_so_beyond_128_components():
-    from nmf_amd._lib import NmfxError
+@pytest.mark.parametrize("shape,k,distance", [((520, 400), 160, "eu"), ((300, 420), 144, "kl")])
+def test_anls_beyond_128_components_vs_oracle(shape, k, distance):
+    """ANLS (nmf/anls.py:18-47) for k > 128: block principal pivoting with one workgroup per right-hand side, the passive-set
+    systems factorised in float64 in a global work area, against the oracle (scipy's Lawson-Hanson NNLS)."""
     from nmf_amd.anls import anls
+    m, n = shape
+    v = R.planted_matrix(m, n, 24, seed=m + k, dtype=np.float32)
+    kw = dict(distance_type=distance, lambda_w=0.05, lambda_h=0.02, min_iter=3, max_iter=3, nndsvd_init=(True, "zero"))     # (the oracle's scipy NNLS sets the run time)
+    res = anls(v.copy(), k, **kw)
+    ref = R.anls(v.astype(np.float64), k, **kw)
+    assert res.w.shape == (m, k) and res.h.shape == (k, n)
+    assert res.i == ref.i and len(res.obj_history) == res.i + 2
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    rel = np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history))
+    print(f"\nANLS k={k} {distance}: WH {err:.2e}, objective max rel diff {rel:.2e}")
+    assert err < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-4)
+
+
+def test_anls_k256_kkt_at_lambda_zero_with_a_dead_component():
+    """k = 256, no regularisation, one component dead in the start (its pivot vanishes on the warm-started passive set and the
+    variable is dropped, as scipy's NNLS leaves it at zero): the returned H is a KKT point of its sub-problem for the returned W,
+    checked in float64 on the host."""
+    from nmf_amd.engine import Engine
+    m, n, k, iters = 640, 520, 256, 2
+    v = R.planted_matrix(m, n, 48, seed=11, dtype=np.float32)
+    rs = np.random.RandomState(2)
+    w0, h0 = rs.rand(m, k), rs.rand(k, n)
+    h0[5] = 0.0
+    with Engine(m, n, k) as eng:
+        eng.upload_v(v)
+        eng.set_factors(w0, h0)
+        eng.anls_set_distance(0)
+        eng.anls_run(0.0, 0.0, 10 ** 9, 1e-3, 1e-3, 0, iters)
+        eng.aoadmm_finish(10 ** 9, 1e-3, 1e-3, iters)
+        w, h = eng.get_factors()
+        _, _, n_obj = eng.state()
+        obj = eng.objectives(0, n_obj)
+        evicted, capped = eng.diagnostics()
+    assert np.isfinite(w).all() and np.isfinite(h).all() and (w >= 0).all() and (h >= 0).all()
+    assert evicted > 0 and capped == 0
+    assert len(obj) == iters + 1 and obj[-1] < obj[0]
+    assert not w[:, 5].any() and not h[5].any()
+    vd = v.astype(np.float64)
+    y = (w.T @ w) @ h - w.T @ vd
+    scale = np.abs(w.T @ vd).max()
+    assert y[h == 0].min() > -2e-4 * scale and np.abs(y[h > 0]).max() < 2e-4 * scale
+
+
+def test_row_sharded_anls_says_so_beyond_128_components():
+    from nmf_amd._lib import NmfxError
+    from nmf_amd.engine import Engine
     v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
-    with pytest.raises(NmfxError, match="more than 128 components"):
-        anls(v.copy(), 160, max_iter=2, nndsvd_init=(False, "zero"))
+    rs = np.random.RandomState(0)
+    with Engine(300, 260, 160) as eng:
+        eng.upload_v(v)
+        eng.set_factors(rs.rand(300, 160), rs.rand(160, 260))
+        with pytest.raises(NmfxError, match="more than 128 components"):
+            eng.anls_phase_objective(0)
 
 
 def test_mur_eu_16384x8192_k256_vs_oracle():
