@@ -37,7 +37,7 @@ typedef struct nmfx_engine* nmfx_handle_t;
 
 enum {
     NMFX_OK = 0,
-    NMFX_E_ARG = -1,     /* bad argument / unsupported request (k > 128 outside the MUR solvers) */
+    NMFX_E_ARG = -1,     /* bad argument / unsupported request (k > 128 in a row-sharded AO-ADMM / ADMM / ANLS phase) */
     NMFX_E_HIP = -2,     /* HIP runtime error, no device                          */
     NMFX_E_NOTPD = -3,   /* Gram + rho I not positive definite (scipy LinAlgError, nmf/ao_admm.py:55) */
     NMFX_E_STATE = -4,   /* call sequence error (no V uploaded, no factors set)   */
@@ -52,9 +52,10 @@ enum { NMFX_PROX_NN = 0, NMFX_PROX_L1N = 1, NMFX_PROX_L2N = 2,      /* reg type 
 
 /* ---- lifecycle ---------------------------------------------------------- */
 /* m, n: rows/cols of the LOCAL block of V held by this handle (all of V on one
- * GPU; a row shard when the caller shards rows over ranks).  k <= 128 for every
- * solver; the MUR entry points also take 128 < k <= 4096 (padded to a multiple of 128: the iteration is then
- * composed from a generic exact-f32 product kernel, kernels_generic.hip -- nmf/nmf.py:32-35 accepts any `factors`). */
+ * GPU; a row shard when the caller shards rows over ranks).  k <= 4096 (nmf/nmf.py:32-35 accepts any `factors`): up to 128
+ * every solver runs its tuned kernels; beyond that (padded to a multiple of 128) the MUR entry points and the whole-loop
+ * entry points nmfx_aoadmm_run / nmfx_admm_run / nmfx_anls_run compose their iterations from a generic exact-f32 product
+ * kernel (kernels_generic.hip); the row-sharded phase entry points of AO-ADMM / ADMM / ANLS stay at k <= 128. */
 int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k);
 int nmfx_destroy(nmfx_handle_t h);
 const char* nmfx_last_error(nmfx_handle_t h);        /* h may be NULL            */
