@@ -243,6 +243,7 @@ int nmfx_comm_info(nmfx_handle_t h, int* rank, int* world, int* merged, int* rcc
 int nmfx_comm_negotiate(nmfx_handle_t h);
 int nmfx_comm_all_reduce(nmfx_handle_t h, int which, int64_t first, int64_t count);
 int nmfx_comm_all_min(nmfx_handle_t h, int64_t* vals, int n);
+int nmfx_comm_barrier(nmfx_handle_t h);     /* the handle's queued work is done and every rank has arrived (one-word all-reduce + stream sync) */
 int nmfx_comm_set_graph(nmfx_handle_t h, int enable);
 int nmfx_comm_graph_replays(nmfx_handle_t h, int64_t* replays);
 int nmfx_mur_run_sharded(nmfx_handle_t h, int distance, double lambda_w, double lambda_h, int64_t min_iter,

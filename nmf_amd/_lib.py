@@ -75,6 +75,7 @@ SIGNATURES = {
     "nmfx_comm_negotiate": (_i32, [_vp]),
     "nmfx_comm_all_reduce": (_i32, [_vp, _i32, _i64, _i64]),
     "nmfx_comm_all_min": (_i32, [_vp, C.POINTER(_i64), _i32]),
+    "nmfx_comm_barrier": (_i32, [_vp]),
     "nmfx_comm_set_graph": (_i32, [_vp, _i32]),
     "nmfx_comm_graph_replays": (_i32, [_vp, C.POINTER(_i64)]),
     "nmfx_mur_run_sharded": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),

@@ -65,6 +65,7 @@ struct nmfx_comm {
     int rank = 0, world = 1;
     hipStream_t side = nullptr;           // the chunked exchange runs its collectives here, behind events of the handle's stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    int64_t* bar = nullptr;               // device word of nmfx_comm_barrier
     // settled by nmfx_comm_negotiate (identical on every rank)
     bool negotiated = false;
     bool merged = false;                  // objective partial inside the f32 buffer: one collective per MUR-eu iteration
@@ -103,6 +104,7 @@ void nmfx_comm_free(nmfx_engine* E) {      // nmfx_destroy
     if (c->side) hipStreamDestroy(c->side);
     if (c->ev_ready) hipEventDestroy(c->ev_ready);
     if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->bar) hipFree(c->bar);
     delete c;
     E->comm = nullptr;
 }
@@ -134,7 +136,8 @@ extern "C" int nmfx_comm_init_rank(nmfx_handle_t E, const void* id128, int rank,
         return NMFX_E_RCCL;
     }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->bar), 64) != hipSuccess || hipMemset(c->bar, 0, 64) != hipSuccess) {
         E->err = "comm_init_rank: stream / event creation failed";
         E->comm = c; nmfx_comm_free(E);
         return NMFX_E_HIP;
@@ -198,6 +201,17 @@ extern "C" int nmfx_comm_all_min(nmfx_handle_t E, int64_t* vals, int n) {
     hipFree(d);
     if (out == NMFX_E_HIP) E->err = "comm_all_min: HIP error";
     return out;
+}
+
+// Every rank's queued work on the handle's stream has completed and every rank has arrived: a one-word all-reduce on the
+// communicator the data path uses (a barrier through ANOTHER communicator -- torch.distributed's -- wakes that one up from idle:
+// ~0.5 ms at the end of a timed region), then a stream synchronisation.
+extern "C" int nmfx_comm_barrier(nmfx_handle_t E) {
+    int rc = have_comm(E); if (rc) return rc;
+    NMFX_HIP(hipSetDevice(E->device));
+    NMFX_RCCL(rccl().AllReduce(E->comm->bar, E->comm->bar, 1, ncclInt64, ncclSum, E->comm->comm, E->stream));
+    NMFX_HIP(hipStreamSynchronize(E->stream));
+    return NMFX_OK;
 }
 
 // Agree on what fixes the SEQUENCE of collectives (see nmf_amd/dist.py: DeviceShard.negotiate): merged objective exchange, chunk

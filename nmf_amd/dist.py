@@ -352,7 +352,7 @@ class NativeComm:
         return None
 
     def barrier(self):
-        self.eng.comm_all_min([0])
+        self.eng.comm_barrier()
 
     def close(self):
         self.eng.comm_destroy()

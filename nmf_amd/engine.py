@@ -375,6 +375,9 @@ class Engine:
         self._ck(self.lib.nmfx_comm_all_min(self.h, arr, len(values)))
         return list(arr)
 
+    def comm_barrier(self):
+        self._ck(self.lib.nmfx_comm_barrier(self.h))
+
     def comm_set_graph(self, enable):
         self._ck(self.lib.nmfx_comm_set_graph(self.h, 1 if enable else 0))
 
