@@ -612,7 +612,9 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 // TOGETHER fit there -- a rank's shard of a strongly scaled problem: 2 x 64 MiB at config 2 over 8 GPUs -- the default policy keeps
 // both resident from one iteration to the next: 62.7 -> 60.4 us per iteration at 2048 rows (tools/lab/ab_iter.py shard8), 81.0 -> 79.9
 // at 4096 rows, 122 -> 134 (worse) at 8192.  Chosen per launch from the size of the two copies (nmfx_bf16_temporal).
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false>
+// WITH_A = false (with WITH_OBJ, Euclidean): only the residual objective of (Z, Y) -- no A-product, no exchange, nothing stored but
+// the objective partials (the closing objective of a run, ADMM's objective of (w, h), ANLS's un-fused objective).
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true>
 __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
@@ -624,13 +626,14 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     if (*flag) return;
     static_assert(KP == 64 || (KP == 128 && !KL && ABL == 0), "KP = 128: Euclidean products only");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
+    static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
     constexpr int YR = KL ? 3 : 2;                     // Y ring (KL: the second product runs one group behind the first)
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
     constexpr int YPW = 2 * (KP / 8) / 4;              // Y pieces (8 rows x 128 B) per loader wave and group
     constexpr bool WITH_D = WITH_OBJ || KL;            // the product Z Y is formed
-    constexpr int NA = 2 * NTP, ND = (WITH_OBJ && !KL) ? NK / 2 : 0, NS = NA + ND;
+    constexpr int NA = WITH_A ? 2 * NTP : 0, ND = (WITH_OBJ && !KL) ? NK / 2 : 0, NS = NA + ND;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
-    const bool do_gram = KP == 64 && !KL && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
+    const bool do_gram = KP == 64 && !KL && WITH_A && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
     const int git = wave >> 1, gj0 = 2 * (wave & 1);
     f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     double osum = 0.0, olog = 0.0;                     // (olog: KL, the sum of x log2(q))
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //    of group g also guarantees V(g + 1), whose reads and split run between the MFMAs of group g into the other
     //    register set (the group loop is unrolled by two, the sets alternate).  The slot of V(g) is free at that barrier
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
-    constexpr bool PIPE = WITH_OBJ && !KL && KP == 64;
+    constexpr bool PIPE = WITH_OBJ && !KL && KP == 64 && WITH_A;
     constexpr bool EARLY = !PIPE;
     constexpr int VAHEAD = KL ? 2 : VRING;             // groups requested before the loop
     Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
@@ -850,8 +853,10 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             read_va(vt, cur.va);
             issue(0, 0);
             NMFX_FENCE();
+            if (WITH_A) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) split8(cur.va[s][0], cur.va[s][1], cur.vh[s], cur.vl[s]);
+                for (int s = 0; s < 2; ++s) split8(cur.va[s][0], cur.va[s][1], cur.vh[s], cur.vl[s]);
+            }
         } else {
             issue(0, 0);
             NMFX_FENCE();
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 
     // ---- the two column halves of a row group exchange partial A tiles: wave (rg, hh) finishes the factor tiles NTP hh .. ----
     __syncthreads();                                   // everybody is done with the LDS tiles
-    {
+    if constexpr (WITH_A) {
         float* xch = reinterpret_cast<float*>(smem);   // slot (rg, tile): [16 registers][64 lanes]
 #pragma unroll
         for (int u = 0; u < NTP; ++u) {
@@ -1778,20 +1783,20 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
     return NMFX_OK;
 }
 
-template <bool OBJ, int TERMS, bool KL = false, int KP = 64>
+template <bool OBJ, int TERMS, bool KL = false, int KP = 64, bool WITH_A = true>
 static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
                           const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                           const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
-    auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP>;
+    auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A>;
     if constexpr (!KL && KP == 64 && TERMS == 3) {
         // V and V^T together small enough to live in the Infinity Cache (see the kernel's TEMPORAL note; NMFX_TEMPORAL=0/1 overrides)
         static const int forced = getenv("NMFX_TEMPORAL") ? atoi(getenv("NMFX_TEMPORAL")) : -1;
         const bool small = 2.0 * (double)E->mp * (double)E->np * 4.0 <= 192.0 * 1024 * 1024;
-        if (forced == 1 || (forced < 0 && small)) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, true>;
+        if (forced == 1 || (forced < 0 && small)) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, true, WITH_A>;
     }
-    if constexpr (OBJ && !KL && KP == 128 && TERMS == 3) {
+    if constexpr (OBJ && !KL && KP == 128 && TERMS == 3 && WITH_A) {
         if (E->pair) kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 2>;     // two stacked problems: one objective each
     }
 #ifdef NMFX_EXP_ABLATE
@@ -1839,6 +1844,11 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
 #define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))
     if (!Apart) {                                      // objective only (Euclidean; three terms: nothing is fed back from it)
         if (!obj || kl) { E->err = "xyt: a launch without the A-product must compute the Euclidean objective"; return NMFX_E_ARG; }
+        static const bool rows16o = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        if (tiled && !rows16o) {                       // the 32-row kernel without its A stages (r3)
+            if (E->kp == 64) return launch_xyt32_t<true, 3, false, 64, false>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+            return launch_xyt32_t<true, 3, false, 128, false>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
+        }
         if (E->kp == 64)
             return launch_xyt_t<64, true, false, 3, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
         return launch_xyt_t<128, true, false, 3, false>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, nullptr, nullptr, ng);
