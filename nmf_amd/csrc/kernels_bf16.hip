@@ -624,10 +624,10 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 {
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
-    static_assert(KP == 64 || (KP == 128 && !KL && ABL == 0), "KP = 128: Euclidean products only");
+    static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
-    constexpr int YR = KL ? 3 : 2;                     // Y ring (KL: the second product runs one group behind the first)
+    constexpr int YR = (KL && KP == 64) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
     constexpr bool PIPE = WITH_OBJ && !KL && KP == 64 && WITH_A;
     constexpr bool EARLY = !PIPE;
-    constexpr int VAHEAD = KL ? 2 : VRING;             // groups requested before the loop
+    constexpr int VAHEAD = (KL && KP == 64) ? 2 : VRING;   // groups requested before the loop
     Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
     if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
@@ -1118,6 +1118,126 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
             vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
         }
     };
+    // ---- KL with KP = 128 (r3; MUR-KL at k = 128 ran the 16-row kernel before): one register set, no cross-group pipeline -- as for the
+    // Euclidean KP = 128 form a second V / product set does not fit next to 64 accumulator and 64 Z registers.  Per group: product
+    // Z Y (8 k-steps), quotient + objective terms where the accumulator stands, bf16 split, second product (2 k-steps x 4 factor
+    // tiles) on the SAME Y(grp) buffer; the two-barrier loop of the objective-free products (V slot refilled as soon as the tile is
+    // in registers).  Fragment reads run one stage ahead on two register sets, D stages first, then the A stages.
+    auto kl128_group = [&](int grp, VRegs& cur) {
+        if (yrole) dma_wait_le<0>();
+        else {
+            const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
+            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+        }
+        __syncthreads();
+        if (yrole) { if (grp + 1 < g1) issue_y(); }
+        const unsigned char* ybuf = smem + ycur * YBUF;
+        const unsigned char* vt = vring + vcur * VSLOT;
+        constexpr int NDK = NK / 2, NAK = 2 * NTP, NSK = NDK + NAK;       // stages: D (two k-steps each), then A (k-step, pair of tiles)
+        auto issue_k = [&](int u, int set) {
+            if (u < NDK) {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int s = 2 * u + ss;
+                    const unsigned char* t0 = ybuf + tro[0] + s * 2048;
+                    const unsigned char* t1 = ybuf + tro[1] + s * 2048;
+                    const uint2 h0 = lds_read_tr(t0), h1 = lds_read_tr(t1);
+                    const uint2 l0 = lds_read_tr(t0 + YT), l1 = lds_read_tr(t1 + YT);
+                    fh[set][ss].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    fl[set][ss].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            } else {
+                const int st = u - NDK;
+                const unsigned char* ys = ybuf + yrow[st / NTP] + (st % NTP) * 8192;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fh[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096);
+                    fl[set][t].u = *reinterpret_cast<const uint4*>(ys + t * 4096 + YT);
+                }
+            }
+        };
+        read_va(vt, cur.va);
+        issue_k(0, 0);
+        NMFX_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!yrole && grp + VRING < g1) issue_v();
+        f32x16& d = cur.d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        float klog = 0.f;
+        f32x2 klin2 = {0.f, 0.f};
+        float4 qa[2][2];
+#pragma unroll
+        for (int u = 0; u < NSK; ++u) {
+            const int set = u & 1;
+            if (u + 1 < NSK) issue_k(u + 1, set ^ 1);
+            NMFX_FENCE();
+            if (u < NDK) {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int s = 2 * u + ss;
+                    d = MFMA32X(fh[set][ss], zh[WITH_D ? s : 0], d);
+                    d = MFMA32X(fl[set][ss], zh[WITH_D ? s : 0], d);
+                    d = MFMA32X(fh[set][ss], zl[WITH_D ? s : 0], d);
+                    if (TERMS >= 4) d = MFMA32X(fl[set][ss], zl[WITH_D ? s : 0], d);
+                }
+                if (u == NDK - 1) {                    // quotient x / (zy + 1e-9) (v_rcp_f32) and the objective terms, as in kl_iter
+                    NMFX_FENCE();
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float4 x4 = cur.va[a >> 1][a & 1];
+                        const f32x2 x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w};
+                        const f32x2 p01 = {d[4 * a], d[4 * a + 1]}, p23 = {d[4 * a + 2], d[4 * a + 3]};
+                        const f32x2 e01 = p01 + 1e-9f, e23 = p23 + 1e-9f;
+                        const f32x2 r01 = {__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};
+                        const f32x2 r23 = {__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
+                        const f32x2 q01 = x01 * r01, q23 = x23 * r23;
+                        qa[a >> 1][a & 1] = make_float4(q01.x, q01.y, q23.x, q23.y);
+                        if (WITH_OBJ) {
+                            const int mn = min(min(__float_as_int(p01.x), __float_as_int(p01.y)), min(__float_as_int(p23.x), __float_as_int(p23.y)));
+                            if (__builtin_amdgcn_ballot_w64(mn < 0x3D000000) != 0ull) {      // small, zero or negative zy: the exact expression
+                                const float vv[4] = {x4.x, x4.y, x4.z, x4.w};
+                                float k0 = 0.f, k1 = 0.f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float pv = d[4 * a + c];
+                                    float t = vv[c] * (__builtin_amdgcn_logf(vv[c] * __builtin_amdgcn_rcpf(pv)) * 0.69314718055994531f);
+                                    t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                                    if (c & 1) k1 += (t - vv[c]) + pv; else k0 += (t - vv[c]) + pv;
+                                }
+                                klin2.x += k0; klin2.y += k1;
+                            } else {                   // zy + 1e-9f == zy: q IS x / zy; x log2(q) with 0 * -inf = 0, zy - x summed in packed f32
+                                klin2 += (p01 - x01) + (p23 - x23);
+                                float t0, t1, t2, t3;
+                                xlog2_legacy4(x4, q01.x, q01.y, q23.x, q23.y, t0, t1, t2, t3);
+                                klog += (t0 + t1) + (t2 + t3);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) split8(qa[s2][0], qa[s2][1], cur.vh[s2], cur.vl[s2]);
+                    NMFX_FENCE();
+                }
+            } else {
+                const int st = u - NDK, ks = st / NTP, t0 = 2 * (st % NTP);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vh[ks], fh[set][t], accA[t0 + t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vl[ks], fh[set][t], accA[t0 + t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vh[ks], fl[set][t], accA[t0 + t]);
+                if (TERMS >= 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) accA[t0 + t] = MFMA32X(cur.vl[ks], fl[set][t], accA[t0 + t]);
+                }
+            }
+            NMFX_FENCE();
+        }
+        if (WITH_OBJ) { olog += (double)klog; osum += (double)(klin2.x + klin2.y); }
+        ycur ^= 1;
+        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+    };
     VRegs P, Q;
     if (PIPE) {
 #pragma unroll
@@ -1137,7 +1257,10 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
-    if (KL) {
+    if (KL && KP == 128) {
+        for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
+        osum += 0.69314718055994531 * olog;
+    } else if (KL) {
         if (g0 < g1) {
             const std::true_type yes; const std::false_type no;
             kl_iter(g0, P, Q, yes, no);
@@ -1871,7 +1994,16 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
         }
         return obj ? NMFX_XYT(64, true, false) : NMFX_XYT(64, false, false);
     }
-    if (kl) return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
+    if (kl) {      // MUR-KL at k padded to 128: the 32-row kernel as well (r3; NMFX_XYT16=1: the 16-row form)
+        static const bool rows16k = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        if (tiled && !rows16k) {
+#define NMFX_X32KB(OBJ_, T_) launch_xyt32_t<OBJ_, T_, true, 128>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, nullptr, ng)
+            if (terms == 3) return obj ? NMFX_X32KB(true, 3) : NMFX_X32KB(false, 3);
+            return obj ? NMFX_X32KB(true, 4) : NMFX_X32KB(false, 4);
+#undef NMFX_X32KB
+        }
+        return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
+    }
     {   // Euclidean products with k padded to 128: the 32-row kernel as well (NMFX_XYT16=1: the 16-row form)
         static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
         if (tiled && !rows16) {

@@ -135,6 +135,28 @@ def test_mur_kl_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)      # (measured: 3.6e-6 split-bf16, 3.6e-7 exact-f32 products)
 
 
+@pytest.mark.parametrize("k", [40, 100])
+def test_mur_kl_zero_and_tiny_entries_take_the_exact_objective_path(k):
+    """KL on data with exact zeros (utils.py:24 zeroes their 0 log 0) and entries far below 2^-5, where W H is small too: the
+    chunks concerned leave the one-transcendental fast path of the split-bf16 KL kernels (k padded to 64: pipelined form; to 128:
+    the one-register-set form) and take the exact expression."""
+    from nmf_amd.mur import mur
+    m, n = 384, 320
+    rs = np.random.RandomState(k)
+    v = R.planted_matrix(m, n, 12, seed=k, dtype=np.float32)
+    v[rs.rand(m, n) < 0.3] = 0.0
+    v[:, : n // 4] *= 1e-3                                   # a block of tiny entries: zy < 2^-5 there
+    v[: m // 8] *= 1e-2
+    kw = dict(distance_type="kl", min_iter=15, max_iter=15, lambda_w=0.0, lambda_h=0.01)
+    np.random.seed(3)
+    res = mur(v.copy(), k, **kw)
+    np.random.seed(3)
+    ref = R.mur(v.astype(np.float64), k, **kw)
+    assert np.isfinite(res.obj_history).all()
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)
+
+
 def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
     from nmf_amd.mur import mur
     v = R.planted_matrix(300, 260, 36, seed=77, dtype=np.float32)
