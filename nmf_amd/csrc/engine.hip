@@ -226,7 +226,8 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->obj_hist, E->state, E->dualW, E->dualH, E->auxW, E->auxH, E->Minv, E->nrm_part,
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
-                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work};
+                    E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work,
+                    E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3]};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -303,6 +304,7 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
     } else { E->err = "upload_v: dtype must be NMFX_F32 or NMFX_F64"; return NMFX_E_ARG; }
     E->have_v = true;
     E->bf_ready = false;
+    E->gxb_v_ready = false;
     return NMFX_OK;
 }
 
@@ -330,6 +332,7 @@ int nmfx_upload_v_device(nmfx_handle_t E, const void* dev, int dtype, int64_t ld
     NMFX_HIP(hipStreamSynchronize(E->stream));
     E->have_v = true;
     E->bf_ready = false;
+    E->gxb_v_ready = false;
     return NMFX_OK;
 }
 
@@ -371,6 +374,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     E->wsel = 0;
     E->have_f = true;
     E->bf_ready = false;
+    E->gxb_img_ready = false;
     E->kl_h_iter = -2;
     E->wimg_ok = false;
     E->family = 0;

@@ -614,8 +614,8 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 // at 4096 rows, 122 -> 134 (worse) at 8192.  Chosen per launch from the size of the two copies (nmfx_bf16_temporal).
 // WITH_A = false (with WITH_OBJ, Euclidean): only the residual objective of (Z, Y) -- no A-product, no exchange, nothing stored but
 // the objective partials (the closing objective of a run, ADMM's objective of (w, h), ANLS's un-fused objective).
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true>
-__global__ __launch_bounds__(512) void xyt32_bf16_kernel(
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
@@ -627,29 +627,31 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
+    static_assert(NW == 8 || (NW == 4 && KP == 64 && !KL && NPROB == 1 && WITH_A), "four-wave blocks: the Euclidean k = 64 products");
+    constexpr int NRG = NW / 2;                        // row groups of 32 rows per block (NW = 4: 64-row blocks, two of them per CU)
     constexpr int YR = (KL && KP == 64) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
-    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL) ? 4 : 3, VSLOT = 8192;
+    constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL && NW == 8) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
-    constexpr int YPW = 2 * (KP / 8) / 4;              // Y pieces (8 rows x 128 B) per loader wave and group
+    constexpr int YPW = 2 * (KP / 8) / NRG;            // Y pieces (8 rows x 128 B) per loader wave and group
     constexpr bool WITH_D = WITH_OBJ || KL;            // the product Z Y is formed
     constexpr int NA = WITH_A ? 2 * NTP : 0, ND = (WITH_OBJ && !KL) ? NK / 2 : 0, NS = NA + ND;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 3, hh = wave >> 2;           // compute role: row group, column half
+    const int rg = wave & (NRG - 1), hh = wave / NRG;  // compute role: row group, column half
     const int n31 = lane & 31, b = lane >> 5;          // 32x32x16 coordinates
     const int x = lane & 15, g = lane >> 4;            // 16x16x32 coordinates (Gram by-product)
     const int S = gridDim.y, sp = blockIdx.y;
     const int g0 = (int)((int64_t)ngroups * sp / S);
     const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
-    const int64_t r0 = (int64_t)blockIdx.x * 128 + rg * 32;
+    const int64_t r0 = (int64_t)blockIdx.x * (32 * NRG) + rg * 32;
 
     // ---- DMA plan (roles by wave as in xyt_bf16_kernel: homogeneous vmcnt queues) ----
     //   waves 4..7: 4 of the 16 pieces (8 rows x 128 B) of the Y tiles of group grp + 1
     //   waves 0..3: the V tile [32][64] of row group lw (8 pieces of 4 rows x 256 B), VRING (- 1) groups ahead
-    const bool yrole = wave >= 4;
-    const int lw = wave & 3;
+    const bool yrole = wave >= NRG;
+    const int lw = wave & (NRG - 1);
     const int ytile = (lw * YPW) / (KP / 8), p0 = (lw * YPW) % (KP / 8);
     const unsigned short* ysrc = ytile == 0 ? Yhi : Ylo;
 #ifdef NMFX_EXP_REVERSE
@@ -668,8 +670,8 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     }
     const unsigned ydst = (unsigned)(ytile * YT + p0 * 1024);
     // X is tile-major: [R/128][ldx/64] tiles of [128 rows][64 cols], 32 KiB contiguous each
-    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)blockIdx.x * (ldx / 64) + gfirst) * 32768ull;
-    unsigned long long vbaseA = tile0 + (unsigned long long)lw * 32 * 256, vbaseB = vbaseA + 16 * 256;
+    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)(blockIdx.x / (4 / NRG)) * (ldx / 64) + gfirst) * 32768ull;
+    unsigned long long vbaseA = tile0 + (unsigned long long)((blockIdx.x % (4 / NRG)) * NRG + lw) * 32 * 256, vbaseB = vbaseA + 16 * 256;
     unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }   // rows 4t+g (< 16): row & 15 = row
@@ -684,17 +686,17 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     };
     auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
         if (yrole) {
-            if (st < 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * st], yoffs[2 * st + 1]);
-            if (st == 1) { ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1; }
+            if (st < YPW / 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * (st < YPW / 2 ? st : 0)], yoffs[2 * (st < YPW / 2 ? st : 0) + 1]);
+            if (st == YPW / 2 - 1) { ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1; }
         } else {
             (TEMPORAL ? dma_run2 : dma_run2_nt)(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
-            if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1; }
+            if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1); }
         }
     };
     auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
-        vbaseA += vstep; vbaseB += vstep; vq = (vq == VRING - 1) ? 0 : vq + 1;
+        vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1);
     };
 
     // ---- loop-invariant LDS read offsets ----
@@ -727,8 +729,11 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
     const bool do_gram = KP == 64 && !KL && WITH_A && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
-    const int git = wave >> 1, gj0 = 2 * (wave & 1);
-    f32x4 gacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    constexpr int NGT = 16 / NW;                       // Gram tiles (16 x 16) per wave: tile row git, tile columns gj0 .. gj0 + NGT - 1
+    const int git = wave / (4 / NGT), gj0 = NGT * (wave % (4 / NGT));
+    f32x4 gacc[NGT];
+#pragma unroll
+    for (int c = 0; c < NGT; ++c) gacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     double osum = 0.0, olog = 0.0;                     // (olog: KL, the sum of x log2(q))
     double osum2 = 0.0;                                // (NPROB = 2: the residual sum of the second problem)
     // Two loop structures.
@@ -810,9 +815,9 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         NMFX_STAMP(ts0);
         if (ABL & 1) { }
         else if (yrole) dma_wait_le<0>();
-        else if (PIPE) {                               // V(grp + 1) must have landed; V(grp + 2), V(grp + 3) may stay in flight
+        else if (PIPE) {                               // V(grp + 1) must have landed; V(grp + 2) (, V(grp + 3): VRING = 4) may stay in flight
             const int ahead = g1 - 2 - grp;
-            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+            if (VRING >= 4 && ahead >= 2) dma_wait_le<16>(); else if (ahead >= 1) dma_wait_le<8>(); else dma_wait_le<0>();
         } else {
             const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
             if (ahead >= 3) dma_wait_le<24>(); else if (ahead == 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
                     ah.u = *reinterpret_cast<const uint4*>(ys + git * 2048);
                     al.u = *reinterpret_cast<const uint4*>(ys + git * 2048 + YT);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NGT; ++c) {
                         Frag8 bh, bl;
                         bh.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048);
                         bl.u = *reinterpret_cast<const uint4*>(ys + (gj0 + c) * 2048 + YT);
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_early += ts3 - ts2; acc_mfma += ts4 - ts3;
 #endif
         ycur ^= 1;
-        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+        vcur = (NW == 4) ? vcur + 1 - 3 * (vcur >> 1) : ((vcur == VRING - 1) ? 0 : vcur + 1);
     };
     // ---- KL: product, quotient, product -- software-pipelined across groups ----
     // In its first form (one register set: product Z Y, quotient + split with the matrix pipe idle, second product with the
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         }
         if (DO_D) {
             ycur = (ycur == YR - 1) ? 0 : ycur + 1;
-            vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+            vcur = (NW == 4) ? vcur + 1 - 3 * (vcur >> 1) : ((vcur == VRING - 1) ? 0 : vcur + 1);
         }
     };
     // ---- KL with KP = 128 (r3; MUR-KL at k = 128 ran the 16-row kernel before): one register set, no cross-group pipeline -- as for the
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         }
         if (WITH_OBJ) { olog += (double)klog; osum += (double)(klin2.x + klin2.y); }
         ycur ^= 1;
-        vcur = (vcur == VRING - 1) ? 0 : vcur + 1;
+        vcur = (NW == 4) ? vcur + 1 - 3 * (vcur >> 1) : ((vcur == VRING - 1) ? 0 : vcur + 1);
     };
     VRegs P, Q;
     if (PIPE) {
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
     if (do_gram) {
         float* go = gram_part + ((int64_t)blockIdx.x * S + sp) * KP * KP;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NGT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 go[(int64_t)(16 * git + 4 * g + r) * KP + 16 * (gj0 + c) + x] = gacc[c][r];
@@ -1329,7 +1334,7 @@ __global__ __launch_bounds__(512) void xyt32_bf16_kernel(
         __syncthreads();
         if (tid == 0) {
             double t = 0.0;
-            for (int w = 0; w < 8; ++w) t += red[w];
+            for (int w = 0; w < NW; ++w) t += red[w];
             objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (KL ? 1.0 : 0.5) * t;
         }
         if (NPROB == 2) {
@@ -1398,8 +1403,9 @@ int nmfx_need_v(nmfx_engine* E) {
 __global__ __launch_bounds__(256) void split_images_kernel(
     const float* __restrict__ M, int64_t rows, int64_t cols, int64_t ld,
     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo)
+    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, const int* __restrict__ flag = nullptr)
 {
+    if (flag && *flag) return;                         // (a stopped run keeps the images of the iterate it stopped at)
     __shared__ unsigned short sh[64][66], sl[64][66];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
@@ -1911,8 +1917,22 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
                           const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
                           const unsigned short* Zlo, float* Apart, float* gram_part, int ng) {
     dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
-    const size_t shm = 160 * 1024;
+    size_t shm = 160 * 1024;
     auto kern = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A>;
+    if constexpr (!KL && KP == 64 && TERMS == 3 && WITH_A) {
+        if (E->xyt_nw == 4) {      // four-wave blocks of 64 rows, two resident per CU (see the kernel's NW note)
+            grid = dim3((unsigned)(R / 64), (unsigned)splits); block = dim3(256); shm = 80 * 1024;
+            static const int forced = getenv("NMFX_TEMPORAL") ? atoi(getenv("NMFX_TEMPORAL")) : -1;
+            const bool small = 2.0 * (double)E->mp * (double)E->np * 4.0 <= 192.0 * 1024 * 1024;
+            auto k4 = (forced == 1 || (forced < 0 && small)) ? xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, true, WITH_A, 4>
+                                                             : xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
+            int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
+            hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
+                               gram_part, R, ngroups, &E->state->flag, ng);
+            NMFX_HIP(hipGetLastError());
+            return NMFX_OK;
+        }
+    }
     if constexpr (!KL && KP == 64 && TERMS == 3) {
         // V and V^T together small enough to live in the Infinity Cache (see the kernel's TEMPORAL note; NMFX_TEMPORAL=0/1 overrides)
         static const int forced = getenv("NMFX_TEMPORAL") ? atoi(getenv("NMFX_TEMPORAL")) : -1;
@@ -1961,7 +1981,10 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
     static const bool force4 = getenv("NMFX_BF16_TERMS") && atoi(getenv("NMFX_BF16_TERMS")) == 4;
     if (force4) terms = 4;
     ProfScope ps(E, name);
-    if (obj) E->obj_count = (R / 128) * splits;
+    const bool nw4 = E->xyt_nw == 4 && E->kp == 64 && !kl && tiled && gram_part && Apart && terms == 3 &&
+                     !(getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1);
+    if (!nw4) E->xyt_nw = 8;
+    if (obj) E->obj_count = (R / (nw4 ? 64 : 128)) * splits;
 #define NMFX_XYT2(KP_, OBJ_, KL_, T_) \
     launch_xyt_t<KP_, OBJ_, KL_, T_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
 #define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))
@@ -2093,6 +2116,16 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     E->bf_ready = true;
     if ((rc = nmfx_bf16_images_w(E, E->W[E->wsel], E->wsel))) return rc;
     return nmfx_bf16_images_h(E, false);
+}
+
+// bf16 hi / lo images of any row-major matrix (and of its transpose): the factor images and the V planes of the k > 128
+// split-bf16 products (kernels_generic.hip)
+int nmfx_split_images(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int64_t ld, unsigned short* hi, unsigned short* lo,
+                      unsigned short* thi, unsigned short* tlo) {
+    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, E->stream,
+                       M, rows, cols, ld, hi, lo, thi, tlo, (const int*)&E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 // ---- building blocks shared by the solvers (kp = 64 or 128); results land where the exact-f32
@@ -2236,7 +2269,7 @@ static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int6
       rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, false>), (int)shm); if (rc_) return rc_; }
     if (from_slabs)
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, true>), grid, block, shm, E->stream, E->Bt_part, E->bt_split,
-                           E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, (int64_t)(E->mp / 128) * E->bf_wsplit, E->H, E->np,
+                           E->G_part, nmfx_bf16_g_slabs(E), E->obj_part, E->obj_count, E->H, E->np,
                            lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo);
     else
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, false>), grid, block, shm, E->stream, E->xf32, 1,
@@ -2418,15 +2451,21 @@ int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
     const float* Wold = E->W[cur];
     float* Wnew = E->W[nxt];
     // W phase: A = V H^T, residual objective of (W_j, H_j), and H H^T as a by-product
-    if ((rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
-                         E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3))) return rc;
+    static const int nw4 = getenv("NMFX_NW4") ? atoi(getenv("NMFX_NW4")) : 0;      // bit 0: W phase, bit 1: H phase on four-wave blocks
+    E->xyt_nw = (nw4 & 1) ? 4 : 8;
+    rc = launch_xyt(E, true, E->Vtile, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np,
+                    E->Whi[cur], E->Wlo[cur], E->A_part, E->HHt_part, "wphase", false, E->gram_ng_w, 3);
+    E->xyt_nw = 8;
+    if (rc) return rc;
     if ((rc = launch_w_update_bf16<64>(E, Wold, Wnew, nxt, E->HHt_part, nmfx_bf16_hht_slabs(E), (float)lambda_w))) return rc;
     // H phase: B^T = V^T W_new, and W_new^T W_new as a by-product
-    if ((rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
-                         nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h, 3))) return rc;
+    E->xyt_nw = (nw4 & 2) ? 4 : 8;
+    rc = launch_xyt(E, false, E->Vt, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp,
+                    nullptr, nullptr, E->Bt_part, E->G_part, "hphase", false, E->gram_ng_h, 3);
+    E->xyt_nw = 8;
+    if (rc) return rc;
     if (E->fused_pack) return NMFX_OK;          // single GPU: h_update reads the slabs itself
-    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, nmfx_bf16_g_slabs(E),
-                                 (int64_t)(E->mp / 128) * E->bf_wsplit);
+    return nmfx_launch_pack_from(E, E->Bt_part, E->bt_split, E->G_part, nmfx_bf16_g_slabs(E), E->obj_count);
 }
 
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2,

@@ -394,6 +394,196 @@ int gx_split_product(nmfx_engine* E, const float* A, int64_t lda, const float* B
     return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
 }
 
+// ---- split-bf16 form of the big products (r3) ------------------------------------------------------------------------------------
+// The exact-f32 product kernel above runs at 0.7-0.8 of the f32 MFMA peak and that is what a k > 128 iteration costs (three V-sized
+// products: 1.8 of 1.94 ms at 16384 x 8192, k = 256).  The same three products in the arithmetic of the tuned k <= 128 kernels --
+// every operand x = hi + lo in bf16, a product = hi hi + lo hi + hi lo with f32 accumulation (kernels_bf16.hip, top: the three-term
+// form MUR runs on) -- on v_mfma_f32_32x32x16_bf16.  Every operand is kept as PLANES that are contiguous along the contraction, so
+// ONE kernel form serves all of them:
+//     C[M][N] = sum_t A[i][t] B[j][t]          A = (Ahi, Alo) [M][K],  B = (Bhi, Blo) [N][K]
+//   objective   1/2 ||V - W H||^2 :  A = W images [mp][kp],   B = H^T images [np][kp],  residual against the f32 V in the epilogue
+//   V H^T                         :  A = V planes [mp][np],   B = H images [kp][np]
+//   W^T V   ([kp][np])            :  A = W^T images [kp][mp], B = V^T planes [np][mp]
+//   H H^T, W^T W                  :  A = B = H images / W^T images
+// (V planes: built once per upload; factor images: rebuilt by split_images_kernel after each update, both layouts in one launch.)
+// Block = 128 x 128 outputs, 4 waves x (2 x 2 tiles of 32 x 32), contraction in chunks of 64: four planes [128 rows][64 bf16] in
+// LDS with a row stride of 144 bytes -- an odd multiple of 16, so the 16 rows of a ds_read_b128 lane group (MI355X_MICROARCH.md,
+// LDS table) fall on 16 distinct bank quadruples, and the 8 lanes of a ds_write_b128 group write one contiguous row --, the
+// next chunk prefetched into registers (16 x 16 bytes per thread) while the current one is multiplied; 72 KiB of LDS: two
+// blocks per CU, so one block's barriers and load latencies are covered by the other's MFMAs.
+typedef __bf16 gxb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gxb_f32x16 __attribute__((ext_vector_type(16)));
+union GxbFrag { uint4 u; gxb_bf16x8 v; };
+#define GXB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).v, (b).v, (c), 0, 0, 0)
+constexpr int GXB_KC = 64, GXB_LDB = 144, GXB_PLANE = 128 * GXB_LDB;      // bytes
+constexpr int GXB_SHM = 4 * GXB_PLANE + 64;
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gxb_gemm_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int64_t lda,
+    const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int64_t ldb,
+    float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t K, const float* __restrict__ X, int64_t ldx,
+    double* __restrict__ part, const int* __restrict__ flag, const int* __restrict__ flag2)
+{
+    if (*flag || (flag2 && *flag2)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gxb_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n31 = lane & 31, b = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.y * GX_T, j0 = (int64_t)blockIdx.x * GX_T;
+    const int64_t kper = K / gridDim.z, kbeg = kper * blockIdx.z;
+    const int wr = 64 * (wave >> 1), wc = 64 * (wave & 1);
+    // staging: piece p = tid + 256 i (i < 4) of a plane = 16 bytes: row p >> 3, bytes 16 (p & 7) of the row's 128-byte chunk
+    const int prow = tid >> 3, pcol = tid & 7;
+    const unsigned short* sAh = Ahi + (i0 + prow) * lda + kbeg + 8 * pcol;
+    const unsigned short* sAl = Alo + (i0 + prow) * lda + kbeg + 8 * pcol;
+    const unsigned short* sBh = Bhi + (j0 + prow) * ldb + kbeg + 8 * pcol;
+    const unsigned short* sBl = Blo + (j0 + prow) * ldb + kbeg + 8 * pcol;
+    unsigned char* dst = gxb_smem + prow * GXB_LDB + 16 * pcol;
+    // (named registers, no arrays behind a lambda: hipcc parks such a staging array in scratch)
+    uint4 ah0, ah1, ah2, ah3, al0, al1, al2, al3, bh0, bh1, bh2, bh3, bl0, bl1, bl2, bl3;
+#define GXB_LD4(p, ld_, koff, r0_, r1_, r2_, r3_) do { \
+        r0_ = *reinterpret_cast<const uint4*>((p) + (koff)); r1_ = *reinterpret_cast<const uint4*>((p) + 32 * (ld_) + (koff)); \
+        r2_ = *reinterpret_cast<const uint4*>((p) + 64 * (ld_) + (koff)); r3_ = *reinterpret_cast<const uint4*>((p) + 96 * (ld_) + (koff)); } while (0)
+#define GXB_FETCH(koff) do { GXB_LD4(sAh, lda, koff, ah0, ah1, ah2, ah3); GXB_LD4(sAl, lda, koff, al0, al1, al2, al3); \
+        GXB_LD4(sBh, ldb, koff, bh0, bh1, bh2, bh3); GXB_LD4(sBl, ldb, koff, bl0, bl1, bl2, bl3); } while (0)
+#define GXB_ST4(pl, r0_, r1_, r2_, r3_) do { \
+        *reinterpret_cast<uint4*>(dst + (pl) * GXB_PLANE) = r0_; *reinterpret_cast<uint4*>(dst + (pl) * GXB_PLANE + 32 * GXB_LDB) = r1_; \
+        *reinterpret_cast<uint4*>(dst + (pl) * GXB_PLANE + 64 * GXB_LDB) = r2_; *reinterpret_cast<uint4*>(dst + (pl) * GXB_PLANE + 96 * GXB_LDB) = r3_; } while (0)
+    gxb_f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+    const unsigned char* fa = gxb_smem + (wr + n31) * GXB_LDB + 16 * b;                    // + 32 rows per tile, + 32 bytes per k-step, + GXB_PLANE: lo
+    const unsigned char* fb = gxb_smem + 2 * GXB_PLANE + (wc + n31) * GXB_LDB + 16 * b;
+    const int nch = (int)(kper / GXB_KC);
+    GXB_FETCH(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                               // the previous chunk has been multiplied
+        GXB_ST4(0, ah0, ah1, ah2, ah3); GXB_ST4(1, al0, al1, al2, al3); GXB_ST4(2, bh0, bh1, bh2, bh3); GXB_ST4(3, bl0, bl1, bl2, bl3);
+        __syncthreads();
+        { const int64_t koff = (int64_t)(ch + 1 < nch ? ch + 1 : ch) * GXB_KC;      // branch-free prefetch (behind the last chunk: that chunk again)
+          GXB_FETCH(koff); }
+#pragma unroll
+        for (int ks = 0; ks < GXB_KC / 16; ++ks) {
+            GxbFrag ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t].u = *reinterpret_cast<const uint4*>(fa + t * 32 * GXB_LDB + 32 * ks);
+                al[t].u = *reinterpret_cast<const uint4*>(fa + t * 32 * GXB_LDB + 32 * ks + GXB_PLANE);
+                bh[t].u = *reinterpret_cast<const uint4*>(fb + t * 32 * GXB_LDB + 32 * ks);
+                bl[t].u = *reinterpret_cast<const uint4*>(fb + t * 32 * GXB_LDB + 32 * ks + GXB_PLANE);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(al[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
+                }
+        }
+    }
+#undef GXB_LD4
+#undef GXB_FETCH
+#undef GXB_ST4
+    // acc[ti][tj][r] = C(i0 + wr + 32 ti + (r & 3) + 8 (r >> 2) + 4 b, j0 + wc + 32 tj + n31)
+    if (MODE == GX_STORE) {
+        float* Cz = C + (int64_t)blockIdx.z * cstride;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    Cz[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + n31] = acc[ti][tj][r];
+        return;
+    }
+    double tot = 0.0;                                  // GX_RESID: 1/2 sum (X - C)^2 of the tile (utils.py:29)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = X[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldx + j0 + wc + 32 * tj + n31] - acc[ti][tj][r];
+                if ((r & 3) == 0) s0 += d * d; else if ((r & 3) == 1) s1 += d * d; else if ((r & 3) == 2) s2 += d * d; else s3 += d * d;
+            }
+            tot += (double)((s0 + s1) + (s2 + s3));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(gxb_smem + 4 * GXB_PLANE);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
+               const unsigned short* Blo, int64_t ldb, float* C, int64_t ldc, int64_t cstride, int64_t M, int64_t N, int64_t K, int S,
+               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr) {
+    if (M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape"; return NMFX_E_ARG; }
+    const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
+    const int* flag = &E->state->flag;
+    int rc;
+    if (mode == GX_STORE) {
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE>), GXB_SHM))) return rc;
+        hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    } else {
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_RESID>), GXB_SHM))) return rc;
+        hipLaunchKernelGGL((gxb_gemm_kernel<GX_RESID>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// split of the contraction that fills the CUs about twice: S divides K / 64
+int gxb_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
+    int64_t want = std::max<int64_t>(1, (2 * (int64_t)E->ncu + tiles - 1) / tiles);
+    want = std::min<int64_t>(want, cap);
+    const int64_t ch = K / GXB_KC;
+    while (want > 1 && ch % want) --want;
+    return (int)want;
+}
+
+// split-K product into the slab buffer gx_s, summed into `out`
+int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
+                      const unsigned short* Blo, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K, int cap) {
+    int rc;
+    const int S = gxb_split(E, (M / GX_T) * (N / GX_T), K, cap);
+    if (S == 1) return gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr);
+    if ((rc = gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr))) return rc;
+    return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
+}
+
+// the split-bf16 products are the default for the Euclidean MUR loop beyond k = 128 (NMFX_PRECISION=f32 keeps the exact-f32 kernel)
+bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
+
+// V planes (once per upload) and the factor images of (W, H) (whenever they are not the ones the loop left)
+int gxb_prepare(nmfx_engine* E, const float* W) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    for (int i = 0; i < 4; ++i) if ((rc = gx_alloc(E, &E->gxb_v[i], mp * np))) return rc;
+    if ((rc = gx_alloc(E, &E->Whi[0], mp * kp)) || (rc = gx_alloc(E, &E->Wlo[0], mp * kp)) || (rc = gx_alloc(E, &E->WThi, mp * kp)) ||
+        (rc = gx_alloc(E, &E->WTlo, mp * kp)) || (rc = gx_alloc(E, &E->Hhi, kp * np)) || (rc = gx_alloc(E, &E->Hlo, kp * np)) ||
+        (rc = gx_alloc(E, &E->HThi, kp * np)) || (rc = gx_alloc(E, &E->HTlo, kp * np))) return rc;
+    if (!E->gxb_v_ready) {
+        ProfScope ps(E, "images");
+        if ((rc = nmfx_split_images(E, E->V, mp, np, np, E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3]))) return rc;
+        E->gxb_v_ready = true;
+    }
+    if (!E->gxb_img_ready) {
+        ProfScope ps(E, "images");
+        if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc;
+        if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
+        E->gxb_img_ready = true;
+    }
+    return NMFX_OK;
+}
+
 }  // namespace
 
 // ---- MUR, Euclidean ----------------------------------------------------------------------------------------------------------
@@ -408,6 +598,29 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
     float* xB = E->xf32;                               // [kp][np]
     float* xG = E->xf32 + kp * np;                     // [kp][kp]
     float* xS = xG + kp * kp;                          // [kp] column sums of W (KL)
+    if (!kl && gxb_on(E)) {                            // the same steps with the V-sized products and the Gram matrices in split bf16
+        if ((rc = gxb_prepare(E, W))) return rc;
+        { ProfScope ps(E, "objective");
+          if ((rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
+        if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gxb_split_product(E, E->Hhi, E->Hlo, np, E->Hhi, E->Hlo, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");                   // A = V H^T
+          if ((rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 1))) return rc; }
+        { ProfScope ps(E, "w_update");
+          if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
+          const int64_t c4 = mp * kp / 4;
+          hipLaunchKernelGGL(gx_eu_update_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, W, (const float*)E->A_part,
+                             (const float*)E->gx_d, (float)lambda, Wn, c4, (const int*)&E->state->flag);
+          NMFX_HIP(hipGetLastError()); }
+        { ProfScope ps(E, "images");
+          if ((rc = nmfx_split_images(E, Wn, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->WThi, E->WTlo, mp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");                   // B = W^T V
+          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8))) return rc; }
+        return NMFX_OK;
+    }
     if (!kl) {
         { ProfScope ps(E, "objective");                // 1/2 ||V - W H||^2 of the pair entering the iteration
           if ((rc = gx_launch<true, false>(E, GX_RESID, W, kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
@@ -428,6 +641,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
           if ((rc = gx_split_product<false, false>(E, Wn, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
         return NMFX_OK;
     }
+    E->gxb_img_ready = false;                          // (the KL loop rewrites W and H without their images)
     { ProfScope ps(E, "objective");                    // Q = V / (W H + 1e-9) and the KL objective of the pair entering the iteration
       if ((rc = gx_launch<true, false>(E, GX_KLQ, W, kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
     if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
@@ -466,6 +680,9 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
         const int64_t c4 = kp * np / 4;
         hipLaunchKernelGGL(gx_eu_update_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->H, (const float*)xB,
                            (const float*)E->gx_d, (float)lambda, E->H, c4, (const int*)&E->state->flag);
+        NMFX_HIP(hipGetLastError());
+        if (gxb_on(E) && E->gxb_img_ready &&           // (images of the new H for the next iteration's split-bf16 products)
+            (rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
     } else {
         const int64_t cnt = kp * np;
         hipLaunchKernelGGL((gx_kl_update_kernel<true>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->H, (const float*)xB,
@@ -483,7 +700,10 @@ int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j) {
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     const int64_t nblk = (mp / GX_T) * (np / GX_T);
     { ProfScope ps(E, "objective");
-      if (!kl) rc = gx_launch<true, false>(E, GX_RESID, E->W[j & 1], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
+      if (!kl && gxb_on(E)) {
+          if ((rc = gxb_prepare(E, E->W[j & 1]))) return rc;
+          rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
+      } else if (!kl) rc = gx_launch<true, false>(E, GX_RESID, E->W[j & 1], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       else rc = gx_launch<true, false>(E, GX_KLQ, E->W[j & 1], kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       if (rc) return rc; }
     return nmfx_launch_obj_reduce(E, nblk, E->gx_part);
@@ -668,6 +888,7 @@ int gx_objective_partial(nmfx_engine* E) {            // 1/2 ||V - W H||^2 of th
 
 int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
                             double tol1, double tol2, int64_t first, int64_t count) {
+    E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
     if ((rc = gx_buffers(E, false))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
@@ -817,6 +1038,7 @@ int gx_admm_prox(nmfx_engine* E, bool hside, int prox, double rho, double lam) {
 
 int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h, int admm_iter, int64_t min_iter,
                                double tol1, double tol2, int64_t first, int64_t count) {
+    E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
     if ((rc = gx_admm_buffers(E))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
@@ -842,6 +1064,7 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
 // The caller (nmfx_admm_run) has allocated the ADMM state and, for the first iteration, set w_aux = w, h_aux = h.
 int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
                           double tol1, double tol2, int64_t first, int64_t count) {
+    E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
     if (prox_w == NMFX_PROX_L1INF_T || prox_h == NMFX_PROX_L1INF_T) {
         E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components"; return NMFX_E_ARG; }
@@ -1087,6 +1310,7 @@ int gx_nnls(nmfx_engine* E, const float* G, double diag_add, const float* R, flo
 // ANLS outer iterations (anls.py:111-126): rows of W from G = H H^T + 2 lw I, r = rows of V H^T; columns of H from G = W^T W + 2 lh I,
 // r = columns of W^T V; the objective (Euclidean or KL, E->anls_dist) of the new pair
 int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2, int64_t first, int64_t count) {
+    E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
     if ((rc = gx_buffers(E, false))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;

@@ -96,6 +96,10 @@ struct nmfx_engine {
     double* gx_w64 = nullptr;      // ... the f64 work matrix of the Gauss-Jordan inversion
     double* gx_nrm = nullptr;      // ... norm partials of a round
     double* gx_nnls_work = nullptr; int64_t gx_nnls_cap = 0;   // ANLS for k > 128: per-block f64 systems of the passive-set solves
+    // k > 128, split-bf16 products (kernels_generic.hip, gxb_*): bf16 hi / lo planes of V [mp][np] and of V^T [np][mp]
+    unsigned short* gxb_v[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool gxb_v_ready = false;      // the planes are those of the current V
+    bool gxb_img_ready = false;    // Whi/Wlo[0], WThi/WTlo, Hhi/Hlo, HThi/HTlo are the images of the current (W, H) of the k > 128 MUR loop
     struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
     int64_t obj_cap = 0;
@@ -115,6 +119,7 @@ struct nmfx_engine {
     int ncu = 256, bt_split = 1, bf_wsplit = 1;
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
+    int xyt_nw = 8;                // waves per block of the next 32-row product launch (4: 64-row blocks, two per CU; set and reset by the caller)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     bool wimg_ok = false;          // Whi/Wlo[0] and WThi/WTlo are the images of the current W[0] (AO-ADMM: left by the fused W-side launches)
     bool ao_images = false;        // the fused round kernels being launched write the images of the factor they update
@@ -192,6 +197,8 @@ inline int nmfx_bf16_hht_slabs(const nmfx_engine* E) { return E->gram_ng_w * E->
 inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt_split; }      // W^T W by-product slabs
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
+int nmfx_split_images(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int64_t ld, unsigned short* hi, unsigned short* lo,
+                      unsigned short* thi, unsigned short* tlo);   // bf16 hi / lo images of M [rows][cols] (and of its transpose, optional)
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
 int nmfx_mur_eu_phase_a_head_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_a_cols_bf16(nmfx_engine* E, int64_t c0, int64_t c1);
