@@ -196,8 +196,12 @@ __global__ __launch_bounds__(KP * 4 + 64) void ao_prepare_mfma_kernel(
     const float* __restrict__ src, int k, float* __restrict__ Minv, DevState* __restrict__ st,
     int record_obj, const double* __restrict__ xf64, long long j, long long min_iter,
     double tol1, double tol2, double* __restrict__ obj_hist, double fixed_rho,
-    double* __restrict__ out64 = nullptr, int* __restrict__ soft_bad = nullptr)
+    double* __restrict__ out64 = nullptr, int* __restrict__ soft_bad = nullptr,
+    const double* __restrict__ src64 = nullptr, int64_t ld64 = 0)
 {
+    // src64 != nullptr (with out64; a diagonal block of the blocked Gauss-Jordan inversion beyond k = 128, kernels_generic.hip): the
+    // matrix is the KP x KP f64 block at src64 (row stride ld64), nothing is added to its diagonal, its f64 inverse goes to out64
+    // [KP][KP]; a pivot <= 0 is the run's "not positive definite" unless soft_bad is given.
     // out64 != nullptr (ANLS, nnls_cinv_kernel): the f64 inverse of src + fixed_rho I goes to out64 [KP][KP] instead of the
     // f32 one to Minv, padded variables (index >= k) get a unit diagonal, the solver state is left alone, and
     // "not positive definite" or "too ill-conditioned for an explicit inverse" (max diag(inverse) x mean diag(matrix)
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(KP * 4 + 64) void ao_prepare_mfma_kernel(
 
     if (w == 0) {                                       // rho = trace(G) / k (ao_admm.py:54), or the fixed one (ADMM)
         double tr = 0.0;
-        for (int i = lane; i < k; i += 64) tr += (double)src[(int64_t)i * KP + i];
+        if (src64) { for (int i = lane; i < k; i += 64) tr += src64[(int64_t)i * ld64 + i]; }
+        else for (int i = lane; i < k; i += 64) tr += (double)src[(int64_t)i * KP + i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
         if (lane == 0) {
@@ -242,7 +247,8 @@ __global__ __launch_bounds__(KP * 4 + 64) void ao_prepare_mfma_kernel(
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[jb][r] = (double)src[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c];
+            for (int r = 0; r < 4; ++r)
+                t[jb][r] = src64 ? src64[(int64_t)(16 * w + q + 4 * r) * ld64 + 16 * jb + c] : (double)src[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c];
     }
     __syncthreads();
     PREP_STAMP(1);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(KP * 4 + 64) void ao_prepare_mfma_kernel(
         __syncthreads();                                // (dinv is free: every wave is behind the last step)
         if (lane == 0 && !helper) dinv[w] = dmax;
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && soft_bad) {
             double mx = 0.0;
             for (int i = 0; i < NB; ++i) mx = fmax(mx, dinv[i]);
             *soft_bad = (mx * misc[2] > 1e9 || !(mx == mx)) ? 1 : 0;
@@ -1311,6 +1317,18 @@ static int launch_prepare(nmfx_engine* E, const float* src, int record_obj, int6
     constexpr int NT = (KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4);
     hipLaunchKernelGGL((ao_prepare_kernel<KP>), dim3(1), dim3(NT), 0, E->stream, src, E->k, E->Minv, E->state,
                        record_obj, E->xf64, (long long)j, (long long)min_iter, tol1, tol2, E->obj_hist, fixed_rho);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// f64 inverse of the 128 x 128 f64 block at src64 (row stride ld) -> out64 [128][128]: a diagonal block of the blocked Gauss-Jordan
+// inversion beyond k = 128 (kernels_generic.hip: gx_prepare); a pivot <= 0 sets the run's notpd / flag like the k <= 128 prepare
+int nmfx_launch_inverse64_block(nmfx_engine* E, const double* src64, int64_t ld, double* out64) {
+    constexpr int KP = 128, NB = KP / 16;
+    constexpr size_t shm = (size_t)(2 * 16 * 17 + 3 * 16 * (KP + 2) + NB * 16 * 17 + 4) * sizeof(double);
+    { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_prepare_mfma_kernel<KP>), (int)shm); if (rc_) return rc_; }
+    hipLaunchKernelGGL((ao_prepare_mfma_kernel<KP>), dim3(1), dim3(KP * 4 + 64), shm, E->stream, (const float*)nullptr, KP, (float*)nullptr,
+                       E->state, 0, (const double*)nullptr, 0ll, 0ll, 0.0, 0.0, (double*)nullptr, 0.0, out64, (int*)nullptr, src64, ld);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

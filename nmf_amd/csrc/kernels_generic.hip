@@ -458,13 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned char* fa = gxb_smem + (wr + n31) * GXB_LDB + 16 * b;                    // + 32 rows per tile, + 32 bytes per k-step, + GXB_PLANE: lo
     const unsigned char* fb = gxb_smem + 2 * GXB_PLANE + (wc + n31) * GXB_LDB + 16 * b;
     const int nch = (int)(kper / GXB_KC);
-    GXB_FETCH(0);
-    for (int ch = 0; ch < nch; ++ch) {
-        __syncthreads();                               // the previous chunk has been multiplied
-        GXB_ST4(0, ah0, ah1, ah2, ah3); GXB_ST4(1, al0, al1, al2, al3); GXB_ST4(2, bh0, bh1, bh2, bh3); GXB_ST4(3, bl0, bl1, bl2, bl3);
-        __syncthreads();
-        { const int64_t koff = (int64_t)(ch + 1 < nch ? ch + 1 : ch) * GXB_KC;      // branch-free prefetch (behind the last chunk: that chunk again)
-          GXB_FETCH(koff); }
+    auto multiply = [&]() {
 #pragma unroll
         for (int ks = 0; ks < GXB_KC / 16; ++ks) {
             GxbFrag ah[2], al[2], bh[2], bl[2];
@@ -484,11 +478,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
                 }
         }
+    };
+    GXB_FETCH(0);
+    for (int ch = 0; ch + 1 < nch; ++ch) {
+        __syncthreads();                               // the previous chunk has been multiplied
+        GXB_ST4(0, ah0, ah1, ah2, ah3); GXB_ST4(1, al0, al1, al2, al3); GXB_ST4(2, bh0, bh1, bh2, bh3); GXB_ST4(3, bl0, bl1, bl2, bl3);
+        __syncthreads();
+        { const int64_t koff = (int64_t)(ch + 1) * GXB_KC; GXB_FETCH(koff); }      // the next chunk, while this one is multiplied
+        multiply();
     }
+    __syncthreads();                                   // the last chunk: nothing left to prefetch but the epilogue's operand
+    GXB_ST4(0, ah0, ah1, ah2, ah3); GXB_ST4(1, al0, al1, al2, al3); GXB_ST4(2, bh0, bh1, bh2, bh3); GXB_ST4(3, bl0, bl1, bl2, bl3);
+    __syncthreads();
+    // acc[ti][tj][r] = C(i0 + wr + 32 ti + (r & 3) + 8 (r >> 2) + 4 b, j0 + wc + 32 tj + n31)
+    float xv[MODE == GX_RESID ? 64 : 1];
+    if constexpr (MODE == GX_RESID) {                  // the residual's X tile is requested here and lands under the last chunk's MFMAs
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xv[(2 * ti + tj) * 16 + r] = X[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldx + j0 + wc + 32 * tj + n31];
+    }
+    multiply();
 #undef GXB_LD4
 #undef GXB_FETCH
 #undef GXB_ST4
-    // acc[ti][tj][r] = C(i0 + wr + 32 ti + (r & 3) + 8 (r >> 2) + 4 b, j0 + wc + 32 tj + n31)
     if (MODE == GX_STORE) {
         float* Cz = C + (int64_t)blockIdx.z * cstride;
 #pragma unroll
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float d = X[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldx + j0 + wc + 32 * tj + n31] - acc[ti][tj][r];
+                const float d = xv[MODE == GX_RESID ? (2 * ti + tj) * 16 + r : 0] - acc[ti][tj][r];
                 if ((r & 3) == 0) s0 += d * d; else if ((r & 3) == 1) s1 += d * d; else if ((r & 3) == 2) s2 += d * d; else s3 += d * d;
             }
             tot += (double)((s0 + s1) + (s2 + s3));
@@ -553,7 +569,9 @@ int gxb_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
 int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
                       const unsigned short* Blo, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K, int cap) {
     int rc;
-    const int S = gxb_split(E, (M / GX_T) * (N / GX_T), K, cap);
+    int S = gxb_split(E, (M / GX_T) * (N / GX_T), K, cap);
+    const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);   // gx_buffers: gx_s
+    while (S > 1 && ((int64_t)S * M * N > slab_cap || (K / GXB_KC) % S)) --S;
     if (S == 1) return gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr);
     if ((rc = gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr))) return rc;
     return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
@@ -606,7 +624,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
         { ProfScope ps(E, "gram_nt");
           if ((rc = gxb_split_product(E, E->Hhi, E->Hlo, np, E->Hhi, E->Hlo, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");                   // A = V H^T
-          if ((rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 1))) return rc; }
+          if ((rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4))) return rc; }
         { ProfScope ps(E, "w_update");
           if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
           const int64_t c4 = mp * kp / 4;
@@ -840,8 +858,122 @@ __global__ void gx_close_kernel(DevState* __restrict__ st, int32_t* __restrict__
 }
 
 // M^-1 = (G + rho I)^-1 -> E->Minv, st->rho (fixed_rho < 0: trace(G) / k), the inner-round state reset
+// ---- the same inverse by BLOCKS of 128 (r3) --------------------------------------------------------------------------------------
+// The one-workgroup kernel above walks the whole kp x kp f64 matrix in global memory once per pivot: 6.0 ms at kp = 256, twice per
+// outer iteration -- 12 of the 13.8 ms of an AO-ADMM iteration at 16384 x 8192.  Block Gauss-Jordan over 128-wide blocks instead:
+// per block step p the diagonal block T[p][p] is inverted by the k = 128 solvers' blocked f64-MFMA kernel (kernels_aoadmm.hip,
+// ao_prepare_mfma_kernel: one workgroup, ~40 us; its pivots are those of the unblocked elimination, so "not positive definite"
+// fires on the same condition), and the rest of the step is f64 matrix products spread over the chip (v_mfma_f64_16x16x4_f64, one
+// 16 x 16 tile per wave, operands straight from the L2-resident matrices):
+//     C = -T[:, p] D^-1;     T'[p][p] = D^-1,  T'[p][J] = D^-1 T[p][J],  T'[I][p] = C[I],  T'[I][J] = T[I][J] + C[I] T[p][J]
+// from the old matrix into the other of two buffers.  3 launches per block step, kp / 128 steps.
+__device__ __forceinline__ gx_f64x4 gx_tile64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                              gx_f64x4 acc, int c, int q)
+{   // acc[r] (row q + 4 r, column c) += sum_t A[row][t] B[t][column], t < 128
+#pragma unroll 8
+    for (int s4 = 0; s4 < 32; ++s4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(int64_t)c * lda + 4 * s4 + q], B[(int64_t)(4 * s4 + q) * ldb + c], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void gx_bgj_init_kernel(const float* __restrict__ G, int kp, int k, double* __restrict__ T,
+                                                           DevState* __restrict__ st, double fixed_rho)
+{
+    if (st->flag) return;
+    __shared__ double part[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double tr = 0.0;
+    for (int i = tid; i < k; i += nt) tr += (double)G[(int64_t)i * kp + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = tr;
+    __syncthreads();
+    double rho = 0.0;
+    for (int w = 0; w < nt / 64; ++w) rho += part[w];
+    rho /= (double)k;
+    if (fixed_rho >= 0.0) rho = fixed_rho;
+    const int64_t kk = (int64_t)kp * kp;
+    for (int64_t e = tid; e < kk; e += nt) T[e] = (double)G[e] + ((e / kp) == (e % kp) ? rho : 0.0);
+    if (tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
+}
+
+// C[kp][128] = -T[:, block p] D^-1
+__global__ __launch_bounds__(256) void gx_bgj_col_kernel(const double* __restrict__ T, int kp, int p, const double* __restrict__ Dinv,
+                                                         double* __restrict__ C, const DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), it = tile >> 3, jt = tile & 7;
+    gx_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = gx_tile64(T + (int64_t)16 * it * kp + 128 * p, kp, Dinv + 16 * jt, 128, acc, c, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(int64_t)(16 * it + q + 4 * r) * 128 + 16 * jt + c] = -acc[r];
+}
+
+__global__ __launch_bounds__(256) void gx_bgj_update_kernel(const double* __restrict__ T, double* __restrict__ Tn, int kp, int p,
+                                                            const double* __restrict__ Dinv, const double* __restrict__ C,
+                                                            const DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int nt16 = kp / 16;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), it = tile / nt16, jt = tile % nt16;
+    const int I = it >> 3, J = jt >> 3;
+    gx_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (I == p && J == p) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Dinv[(16 * (it - 8 * p) + q + 4 * r) * 128 + 16 * (jt - 8 * p) + c];
+    } else if (J == p) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = C[(int64_t)(16 * it + q + 4 * r) * 128 + 16 * (jt - 8 * p) + c];
+    } else if (I == p) {
+        acc = gx_tile64(Dinv + 16 * (it - 8 * p) * 128, 128, T + (int64_t)128 * p * kp + 16 * jt, kp, acc, c, q);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = T[(int64_t)(16 * it + q + 4 * r) * kp + 16 * jt + c];
+        acc = gx_tile64(C + (int64_t)16 * it * 128, 128, T + (int64_t)128 * p * kp + 16 * jt, kp, acc, c, q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tn[(int64_t)(16 * it + q + 4 * r) * kp + 16 * jt + c] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void gx_bgj_finish_kernel(const double* __restrict__ T, int64_t kk, float* __restrict__ Minv,
+                                                            const DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < kk) Minv[e] = (float)T[e];
+}
+
+// work area gx_w64: two kp x kp matrices, D^-1 [128][128], C [kp][128]
+int64_t gx_w64_count(int64_t kp) { return 2 * kp * kp + 128 * 128 + kp * 128; }
+
 int gx_prepare(nmfx_engine* E, const float* G, double fixed_rho) {
     ProfScope ps(E, "prepare");
+    static const bool scalar = getenv("NMFX_PREPARE_SCALAR") != nullptr;      // the one-workgroup kernel (A/B runs)
+    if (!scalar) {
+        int rc;
+        const int kp = (int)E->kp, nb = kp / 128;
+        const int64_t kk = (int64_t)kp * kp;
+        double* Tb[2] = {E->gx_w64, E->gx_w64 + kk};
+        double* Dinv = E->gx_w64 + 2 * kk;
+        double* C = Dinv + 128 * 128;
+        hipLaunchKernelGGL(gx_bgj_init_kernel, dim3(1), dim3(1024), 0, E->stream, G, kp, E->k, Tb[0], E->state, fixed_rho);
+        NMFX_HIP(hipGetLastError());
+        for (int p = 0; p < nb; ++p) {
+            const double* T = Tb[p & 1];
+            if ((rc = nmfx_launch_inverse64_block(E, T + (int64_t)128 * p * kp + 128 * p, kp, Dinv))) return rc;
+            hipLaunchKernelGGL(gx_bgj_col_kernel, dim3((unsigned)(kp / 16 * 8 / 4)), dim3(256), 0, E->stream, T, kp, p, (const double*)Dinv, C,
+                               (const DevState*)E->state);
+            hipLaunchKernelGGL(gx_bgj_update_kernel, dim3((unsigned)((kp / 16) * (kp / 16) / 4)), dim3(256), 0, E->stream, T, Tb[(p + 1) & 1], kp, p,
+                               (const double*)Dinv, (const double*)C, (const DevState*)E->state);
+            NMFX_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(gx_bgj_finish_kernel, dim3((unsigned)((kk + 255) / 256)), dim3(256), 0, E->stream, (const double*)Tb[nb & 1], kk, E->Minv,
+                           (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
     const size_t shm = (size_t)(2 * E->kp + 16) * sizeof(double);
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gx_prepare_kernel), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(gx_prepare_kernel, dim3(1), dim3(1024), shm, E->stream, G, (int)E->kp, E->k, E->gx_w64, E->Minv, E->state, fixed_rho);
@@ -876,11 +1008,13 @@ int gx_ao_subproblem(nmfx_engine* E, bool hside, const float* G, const float* B,
     return NMFX_OK;
 }
 
-int gx_objective_partial(nmfx_engine* E) {            // 1/2 ||V - W H||^2 of the current pair -> xf64[0]
+int gx_objective_partial(nmfx_engine* E, bool bf = false) {      // 1/2 ||V - W H||^2 of the current pair -> xf64[0]  (bf: from the images of W[0] and H^T)
     int rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     { ProfScope ps(E, "objective");
-      if ((rc = gx_launch<true, false>(E, GX_RESID, E->W[0], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
+      if (bf) rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
+      else rc = gx_launch<true, false>(E, GX_RESID, E->W[0], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
+      if (rc) return rc; }
     return nmfx_launch_obj_reduce(E, (mp / GX_T) * (np / GX_T), E->gx_part);
 }
 
@@ -893,12 +1027,17 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
     if ((rc = gx_buffers(E, false))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     if ((rc = gx_alloc(E, &E->gx_r, std::max(mp, np) * kp))) return rc;
-    if ((rc = gx_alloc(E, &E->gx_w64, kp * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_w64, gx_w64_count(kp)))) return rc;
     if ((rc = gx_alloc(E, &E->gx_nrm, std::max(mp, np) * kp / 1024 * 4 + 64))) return rc;
     float* W = E->W[0];
     float* xB = E->xf32;
     float* xG = E->xf32 + kp * np;
-    if (first == 0 && count > 0 && (rc = gx_objective_partial(E))) return rc;      // obj[0] (ao_admm.py:256)
+    // split-bf16 runs: the three V-sized products (W^T V, V H^T, the objective's W H) from the V planes and the factor images, three
+    // terms as in the tuned AO-ADMM (kernels_bf16.hip, top); the Gram matrices, whose shifted inverse the rounds apply, stay exact f32
+    const bool bf = gxb_on(E);
+    if (bf && (rc = gxb_prepare(E, W))) return rc;
+    E->gxb_img_ready = false;                          // (valid inside this call only: the MUR loop keeps the images of W[j & 1])
+    if (first == 0 && count > 0 && (rc = gx_objective_partial(E, bf))) return rc;      // obj[0] (ao_admm.py:256)
     for (int64_t j = first; j < first + count; ++j) {
         hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
                            E->state, E->obj_hist);
@@ -907,15 +1046,23 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
         { ProfScope ps(E, "gram_tn");
           if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");
-          if ((rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
+          if (bf) rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8);
+          else rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8);
+          if (rc) return rc; }
         if ((rc = gx_ao_subproblem(E, true, xG, xB, E->H, E->dualH, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc; }
         // W sub-problem on the transposed data: G = H H^T, B^T = V H^T
         { ProfScope ps(E, "gram_nt");
           if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");
-          if ((rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1))) return rc; }
+          if (bf) rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4);
+          else rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1);
+          if (rc) return rc; }
         if ((rc = gx_ao_subproblem(E, false, E->HHt, E->A_part, W, E->dualW, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
-        if ((rc = gx_objective_partial(E))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+        if ((rc = gx_objective_partial(E, bf))) return rc;
     }
     return NMFX_OK;
 }
@@ -962,7 +1109,7 @@ int gx_admm_buffers(nmfx_engine* E) {
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     if ((rc = gx_buffers(E, false))) return rc;
     if ((rc = gx_alloc(E, &E->gx_r, std::max(mp, np) * kp))) return rc;
-    if ((rc = gx_alloc(E, &E->gx_w64, kp * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_w64, gx_w64_count(kp)))) return rc;
     return gx_alloc(E, &E->gx_nrm, std::max(mp, np) * kp / 1024 * 4 + 64);
 }
 

@@ -172,6 +172,7 @@ int nmfx_launch_wphase(nmfx_engine* E, const float* W, bool with_a, bool with_ob
 int nmfx_bf16_gram_tn(nmfx_engine* E, int* slabs);   // W^T W from the transposed bf16 images of W (fresh after a W epilogue): G_part[*slabs][kp][kp]
 int nmfx_bf16_gram_h(nmfx_engine* E, int* slabs);
 int nmfx_launch_inverse64(nmfx_engine* E, const float* src, double diag_add, double* out64, int* soft_bad);   // f64 (src + diag_add I)^-1, kp 64 / 128
+int nmfx_launch_inverse64_block(nmfx_engine* E, const double* src64, int64_t ld, double* out64);   // 128 x 128 f64 block -> its f64 inverse
 int nmfx_launch_kl_vaux(nmfx_engine* E, const float* Wsrc, const float* Hsrc, const int* flag2 = nullptr);
 // B_part[sr] = W^T V over the rows of split sr.
 int nmfx_launch_hphase(nmfx_engine* E, const float* W, bool with_g, const float* Vsrc = nullptr,
