@@ -423,8 +423,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int64_t lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int64_t ldb,
     float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t K, const float* __restrict__ X, int64_t ldx,
-    double* __restrict__ part, const int* __restrict__ flag, const int* __restrict__ flag2)
+    double* __restrict__ part, const int* __restrict__ flag, const int* __restrict__ flag2,
+    unsigned short* __restrict__ Qhi = nullptr, unsigned short* __restrict__ Qlo = nullptr)
 {
+    // MODE GX_KLQ (MUR with the KL divergence, mur.py:25,41): the quotient Q = X / (C + 1e-9) leaves as bf16 hi / lo PLANES
+    // [M][N] (row stride ldc) -- the operand layout of the product that consumes it -- and, with part != nullptr, part[block] =
+    // the KL objective of the tile (utils.py:23-26), both exactly as gx_gemm_kernel<.., GX_KLQ> forms them
     if (*flag || (flag2 && *flag2)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char gxb_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n31 = lane & 31, b = lane >> 5;
@@ -491,8 +495,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     GXB_ST4(0, ah0, ah1, ah2, ah3); GXB_ST4(1, al0, al1, al2, al3); GXB_ST4(2, bh0, bh1, bh2, bh3); GXB_ST4(3, bl0, bl1, bl2, bl3);
     __syncthreads();
     // acc[ti][tj][r] = C(i0 + wr + 32 ti + (r & 3) + 8 (r >> 2) + 4 b, j0 + wc + 32 tj + n31)
-    float xv[MODE == GX_RESID ? 64 : 1];
-    if constexpr (MODE == GX_RESID) {                  // the residual's X tile is requested here and lands under the last chunk's MFMAs
+    float xv[MODE != GX_STORE ? 64 : 1];
+    if constexpr (MODE != GX_STORE) {                  // the epilogue's X tile is requested here and lands under the last chunk's MFMAs
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -524,23 +528,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float d = xv[MODE == GX_RESID ? (2 * ti + tj) * 16 + r : 0] - acc[ti][tj][r];
-                if ((r & 3) == 0) s0 += d * d; else if ((r & 3) == 1) s1 += d * d; else if ((r & 3) == 2) s2 += d * d; else s3 += d * d;
+                const float x1 = xv[MODE != GX_STORE ? (2 * ti + tj) * 16 + r : 0], cv = acc[ti][tj][r];
+                float d2;
+                if (MODE == GX_RESID) { const float d = x1 - cv; d2 = d * d; }
+                else {
+                    // (v_rcp_f32 / v_log_f32 as in the tuned MUR-KL kernels, kernels_bf16.hip: the inf / nan cases of utils.py:24 come
+                    //  out the same and are zeroed the same way)
+                    const float qv = x1 * __builtin_amdgcn_rcpf(cv + 1e-9f);
+                    unsigned hi, lo;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(qv), "v"(0.f));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(qv - __uint_as_float(hi << 16)), "v"(0.f));
+                    // two adjacent lanes hold adjacent columns: the even lane stores the pair of the hi plane, the odd lane the pair
+                    // of the lo plane -- one 4-byte store per lane instead of two 2-byte stores
+                    const unsigned other = (unsigned)__shfl_xor((int)((n31 & 1) ? hi : lo), 1, 64);
+                    const int64_t at = (i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + (n31 & ~1);
+                    if (n31 & 1) *reinterpret_cast<unsigned*>(Qlo + at) = (other & 0xffffu) | (lo << 16);
+                    else *reinterpret_cast<unsigned*>(Qhi + at) = (hi & 0xffffu) | (other << 16);
+                    d2 = 0.f;
+                    if (part) {
+                        float t = x1 * (__builtin_amdgcn_logf(x1 * __builtin_amdgcn_rcpf(cv)) * 0.69314718055994531f);
+                        t = (t != t || t == __builtin_inff() || t == -__builtin_inff()) ? 0.f : t;
+                        d2 = (t - x1) + cv;
+                    }
+                }
+                if ((r & 3) == 0) s0 += d2; else if ((r & 3) == 1) s1 += d2; else if ((r & 3) == 2) s2 += d2; else s3 += d2;
             }
             tot += (double)((s0 + s1) + (s2 + s3));
         }
+    if (MODE == GX_KLQ && !part) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     __syncthreads();
     double* red = reinterpret_cast<double*>(gxb_smem + 4 * GXB_PLANE);
     if (lane == 0) red[wave] = tot;
     __syncthreads();
-    if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (MODE == GX_RESID ? 0.5 : 1.0) * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
                const unsigned short* Blo, int64_t ldb, float* C, int64_t ldc, int64_t cstride, int64_t M, int64_t N, int64_t K, int S,
-               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr) {
+               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr) {
     if (M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape"; return NMFX_E_ARG; }
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
@@ -548,6 +575,9 @@ int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsign
     if (mode == GX_STORE) {
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE>), GXB_SHM))) return rc;
         hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    } else if (mode == GX_KLQ) {                       // (ldc = the row stride of the Q planes)
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_KLQ>), GXB_SHM))) return rc;
+        hipLaunchKernelGGL((gxb_gemm_kernel<GX_KLQ>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2, Qhi, Qlo);
     } else {
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_RESID>), GXB_SHM))) return rc;
         hipLaunchKernelGGL((gxb_gemm_kernel<GX_RESID>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
@@ -580,10 +610,31 @@ int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
 // the split-bf16 products are the default for the Euclidean MUR loop beyond k = 128 (NMFX_PRECISION=f32 keeps the exact-f32 kernel)
 bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
 
-// V planes (once per upload) and the factor images of (W, H) (whenever they are not the ones the loop left)
-int gxb_prepare(nmfx_engine* E, const float* W) {
+// out [cols][rows] = in [rows][cols]^T (f32, 64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void gx_transpose_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, float* __restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = in[(r0 + r) * cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) out[(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+// V planes (once per upload) and the factor images of (W, H) (whenever they are not the ones the loop left); kl: also V^T in f32
+// and the two quotient planes
+int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
     int rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if (kl) {
+        if ((rc = gx_alloc(E, &E->gxb_vt, mp * np)) || (rc = gx_alloc(E, &E->gxb_q[0], mp * np)) || (rc = gx_alloc(E, &E->gxb_q[1], mp * np))) return rc;
+        if (!E->gxb_vt_ready) {
+            ProfScope ps(E, "images");
+            hipLaunchKernelGGL(gx_transpose_kernel, dim3((unsigned)(np / 64), (unsigned)(mp / 64)), dim3(256), 0, E->stream, (const float*)E->V, mp, np, E->gxb_vt);
+            NMFX_HIP(hipGetLastError());
+            E->gxb_vt_ready = true;
+        }
+    }
     for (int i = 0; i < 4; ++i) if ((rc = gx_alloc(E, &E->gxb_v[i], mp * np))) return rc;
     if ((rc = gx_alloc(E, &E->Whi[0], mp * kp)) || (rc = gx_alloc(E, &E->Wlo[0], mp * kp)) || (rc = gx_alloc(E, &E->WThi, mp * kp)) ||
         (rc = gx_alloc(E, &E->WTlo, mp * kp)) || (rc = gx_alloc(E, &E->Hhi, kp * np)) || (rc = gx_alloc(E, &E->Hlo, kp * np)) ||
@@ -608,7 +659,7 @@ int gxb_prepare(nmfx_engine* E, const float* W) {
 int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j) {
     int rc;
     const bool kl = distance == NMFX_KL;
-    if ((rc = gx_buffers(E, kl))) return rc;
+    if ((rc = gx_buffers(E, kl && !gxb_on(E)))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     const float* W = E->W[j & 1];
     float* Wn = E->W[(j + 1) & 1];
@@ -659,7 +710,36 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
           if ((rc = gx_split_product<false, false>(E, Wn, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
         return NMFX_OK;
     }
-    E->gxb_img_ready = false;                          // (the KL loop rewrites W and H without their images)
+    if (gxb_on(E)) {
+        // split bf16: the quotient leaves its product as bf16 planes in the layout the next product contracts over -- Q [mp][np] from
+        // (W images) x (H^T images) for A = Q H^T, and the H side's Q'^T [np][mp] from (H^T images) x (W_new images) against V^T for
+        // B = W_new^T Q' -- so all four V-sized products are the one NT kernel (three terms, like the tuned MUR-KL kernels)
+        if ((rc = gxb_prepare(E, W, true))) return rc;
+        { ProfScope ps(E, "objective");
+          if ((rc = gxb_launch(E, GX_KLQ, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, np, 0, mp, np, kp, 1, E->V, np, E->gx_part, nullptr,
+                               E->gxb_q[0], E->gxb_q[1]))) return rc; }
+        if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
+        { ProfScope ps(E, "wphase");                   // Q H^T
+          if ((rc = gxb_split_product(E, E->gxb_q[0], E->gxb_q[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4))) return rc; }
+        { ProfScope ps(E, "w_update");
+          hipLaunchKernelGGL(gx_rowsum_kernel, dim3((unsigned)kp), dim3(256), 0, E->stream, (const float*)E->H, np, E->HHt, (const int*)&E->state->flag);
+          const int64_t cnt = mp * kp;
+          hipLaunchKernelGGL((gx_kl_update_kernel<false>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, E->stream, W, (const float*)E->A_part,
+                             (const float*)E->HHt, (float)lambda, Wn, mp, kp, E->k, (const int*)&E->state->flag);
+          NMFX_HIP(hipGetLastError()); }
+        { ProfScope ps(E, "images");
+          if ((rc = nmfx_split_images(E, Wn, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+        { ProfScope ps(E, "hphase");                   // Q'^T = V^T / (H^T W_new^T + 1e-9), B = W_new^T Q', d = W_new^T 1
+          if ((rc = gxb_launch(E, GX_KLQ, E->HThi, E->HTlo, kp, E->Whi[0], E->Wlo[0], kp, nullptr, mp, 0, np, mp, kp, 1, E->gxb_vt, mp, nullptr, nullptr,
+                               E->gxb_q[0], E->gxb_q[1]))) return rc;
+          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_q[0], E->gxb_q[1], mp, xB, kp, np, mp, 8))) return rc;
+          const int rb = (int)(mp / 64);
+          hipLaunchKernelGGL(gx_colsum_part_kernel, dim3((unsigned)rb), dim3(256), 0, E->stream, (const float*)Wn, kp, 64, E->gx_s, (const int*)&E->state->flag);
+          NMFX_HIP(hipGetLastError());
+          if ((rc = nmfx_launch_sum_partials(E, E->gx_s, rb, kp, xS))) return rc; }
+        return NMFX_OK;
+    }
+    E->gxb_img_ready = false;                          // (the exact-f32 KL loop rewrites W and H without their images)
     { ProfScope ps(E, "objective");                    // Q = V / (W H + 1e-9) and the KL objective of the pair entering the iteration
       if ((rc = gx_launch<true, false>(E, GX_KLQ, W, kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
     if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
@@ -684,7 +764,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
 int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     const bool kl = distance == NMFX_KL;
-    if ((rc = gx_buffers(E, kl))) return rc;
+    if ((rc = gx_buffers(E, kl && !gxb_on(E)))) return rc;
     const int64_t np = E->np, kp = E->kp;
     float* xB = E->xf32;
     float* xG = E->xf32 + kp * np;
@@ -705,6 +785,9 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
         const int64_t cnt = kp * np;
         hipLaunchKernelGGL((gx_kl_update_kernel<true>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->H, (const float*)xB,
                            (const float*)xS, (float)lambda, E->H, kp, np, E->k, (const int*)&E->state->flag);
+        NMFX_HIP(hipGetLastError());
+        if (gxb_on(E) && E->gxb_img_ready &&
+            (rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -714,7 +797,7 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
 int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j) {
     int rc;
     const bool kl = distance == NMFX_KL;
-    if ((rc = gx_buffers(E, kl))) return rc;
+    if ((rc = gx_buffers(E, kl && !gxb_on(E)))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     const int64_t nblk = (mp / GX_T) * (np / GX_T);
     { ProfScope ps(E, "objective");
@@ -722,7 +805,11 @@ int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j) {
           if ((rc = gxb_prepare(E, E->W[j & 1]))) return rc;
           rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       } else if (!kl) rc = gx_launch<true, false>(E, GX_RESID, E->W[j & 1], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
-      else rc = gx_launch<true, false>(E, GX_KLQ, E->W[j & 1], kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part);
+      else if (gxb_on(E)) {
+          if ((rc = gxb_prepare(E, E->W[j & 1], true))) return rc;
+          rc = gxb_launch(E, GX_KLQ, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, np, 0, mp, np, kp, 1, E->V, np, E->gx_part, nullptr,
+                          E->gxb_q[0], E->gxb_q[1]);
+      } else rc = gx_launch<true, false>(E, GX_KLQ, E->W[j & 1], kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       if (rc) return rc; }
     return nmfx_launch_obj_reduce(E, nblk, E->gx_part);
 }

@@ -99,6 +99,9 @@ struct nmfx_engine {
     // k > 128, split-bf16 products (kernels_generic.hip, gxb_*): bf16 hi / lo planes of V [mp][np] and of V^T [np][mp]
     unsigned short* gxb_v[4] = {nullptr, nullptr, nullptr, nullptr};
     bool gxb_v_ready = false;      // the planes are those of the current V
+    float* gxb_vt = nullptr;       // MUR-KL beyond k = 128: V^T [np][mp] in f32 (the quotient of the H side is formed transposed)
+    bool gxb_vt_ready = false;
+    unsigned short* gxb_q[2] = {nullptr, nullptr};   // ... bf16 hi / lo planes of the quotient V / (W H + 1e-9): [mp][np], then [np][mp]
     bool gxb_img_ready = false;    // Whi/Wlo[0], WThi/WTlo, Hhi/Hlo, HThi/HTlo are the images of the current (W, H) of the k > 128 MUR loop
     struct nmfx_comm* comm = nullptr;      // RCCL communicator of a row-sharded run (comm.hip), or none
     double* obj_hist = nullptr;    // device, capacity obj_cap
