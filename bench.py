@@ -42,6 +42,7 @@ HOST_THREADS = limit_blas_threads()      # BLAS pool = the CPUs the container ma
 M, N, K = 16384, 8192, 64
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 matrix peak (no sparsity)
 
 
 def parse():
@@ -368,6 +369,8 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
         rs = np.random.RandomState(0)
         if init == "randn":                      # nmf/mur.py:108-109
             w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+        elif init == "randn_small":              # |randn| scaled so that W H starts at the data's scale (from |randn| itself AO-ADMM's first
+            w0, h0 = 0.05 * np.abs(rs.randn(m, k)), 0.05 * np.abs(rs.randn(k, n))      # Gram system at k = 256 is not positive definite: LinAlgError)
         elif init == "rand":                     # nmf/anls.py:104-105
             w0, h0 = rs.rand(m, k), rs.rand(k, n)
         else:                                    # NNDSVD 'zero' (nmf/utils.py:36-93) from the device's singular triplets
@@ -422,6 +425,13 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                                      "algorithmic_bytes_per_launch": m * n * 4.0, "bound": "hbm",
                                      "achieved_gbs": m * n * 4.0 / dsec / 1e9, "frac": m * n * 4.0 / dsec / 1e9 / PEAK_HBM_GBS}
                                     if bound == "hbm" else
+                                    # split bf16: every algorithmic product is three bf16 MFMA terms (hi hi + lo hi + hi lo)
+                                    {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (split bf16: 3 executed terms per product)",
+                                     "algorithmic_tflops": 2.0 * m * n * (-(-k // 128) * 128) / dsec / 1e12,
+                                     "executed_tflops": 6.0 * m * n * (-(-k // 128) * 128) / dsec / 1e12,
+                                     "peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                                     "frac": 6.0 * m * n * (-(-k // 128) * 128) / dsec / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+                                    if bound == "mfma_bf16x3" else
                                     {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (f32 inputs)",
                                      "tflops": 2.0 * m * n * (-(-k // 128) * 128 if k > 128 else k) / dsec / 1e12,
                                      "peak_tflops": PEAK_F32_MFMA_TFLOPS,
@@ -469,12 +479,27 @@ def other_configs(torch, dev, only=None):
              m=16384, n=8192, k=64, steps=20, warmup=3, init="randn", precision="f32", bound="mfma",
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
              flops=4.0 * 16384 * 8192 * 64 + 4.0 * 64 * 64 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 64 * 4),
-        # beyond 128 components (nmf/nmf.py:32-35 takes any `factors`): the iteration composed from the generic exact-f32 product
-        # kernel (kernels_generic.hip)
-        dict(name="mur_k256_on_cfg2_shape", workload="MUR Euclidean, V=16384x8192 f32, k=256 (generic exact-f32 path for k > 128)",
-             m=16384, n=8192, k=256, steps=10, warmup=2, init="randn", bound="mfma",
+        # beyond 128 components (nmf/nmf.py:32-35 takes any `factors`): the iteration composed from one split-bf16 NT product kernel
+        # over operand planes (kernels_generic.hip, gxb_*; r3 -- the exact-f32 form of the same composition is the leg after it)
+        dict(name="mur_k256_on_cfg2_shape", workload="MUR Euclidean, V=16384x8192 f32, k=256 (composed path for k > 128, split-bf16 products)",
+             m=16384, n=8192, k=256, steps=10, warmup=2, init="randn", bound="mfma_bf16x3",
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
              flops=4.0 * 16384 * 8192 * 256 + 4.0 * 256 * 256 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 256 * 4),
+        dict(name="mur_k256_exact_f32", workload="MUR Euclidean, V=16384x8192 f32, k=256 with the exact-f32 product kernel (NMFX_PRECISION=f32)",
+             m=16384, n=8192, k=256, steps=5, warmup=1, init="randn", bound="mfma", precision="f32",
+             queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
+             flops=4.0 * 16384 * 8192 * 256 + 4.0 * 256 * 256 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 256 * 4),
+        dict(name="mur_kl_k256_on_cfg2_shape", workload="MUR KL-divergence, V=16384x8192 f32, k=256 (composed path, split-bf16 products, quotient as bf16 planes)",
+             m=16384, n=8192, k=256, steps=8, warmup=2, init="randn", bound="mfma_bf16x3",
+             queue=lambda e, f, c: e.mur_run(1, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
+             flops=8.0 * 16384 * 8192 * 256, nbytes=4.0 * 16384 * 8192 * 4),
+        dict(name="aoadmm_k256_on_cfg2_shape", workload="AO-ADMM Euclidean, reg_w = reg_h = (0.1, 'l1n'), V=16384x8192 f32, k=256, admm_iter=10, "
+                                                        "0.05 |randn| start (composed path: split-bf16 V-sized products, Gram systems by blocks of 128)",
+             m=16384, n=8192, k=256, steps=6, warmup=2, init="randn_small", admm_iter=T, bound="mfma_bf16x3",
+             queue=lambda e, f, c: e.aoadmm_run(0, 1, 0.1, 1, 0.1, T, NEVER, 1e-3, 1e-3, f, c),
+             flops=lambda t: 4.0 * 16384 * 8192 * 256 + 2.0 * 256 * 256 * (16384 + 8192) + 2.0 * 256 * 256 * (t[0] * 8192 + t[1] * 16384)
+             + 2.0 * 256 ** 3 / 3,
+             nbytes=lambda t: 2.0 * 16384 * 8192 * 4 + 8.0 * 256 * 4 * (t[0] * 8192 + t[1] * 16384)),
     ]
     for sp in specs:
         if only and sp["name"] not in only:
