@@ -418,7 +418,7 @@ union GxbFrag { uint4 u; gxb_bf16x8 v; };
 constexpr int GXB_KC = 64, GXB_LDB = 144, GXB_PLANE = 128 * GXB_LDB;      // bytes
 constexpr int GXB_SHM = 4 * GXB_PLANE + 64;
 
-template <int MODE>
+template <int MODE, int TERMS = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gxb_gemm_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int64_t lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int64_t ldb,
@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[ti][tj] = GXB_MFMA(ah[ti], bh[tj], acc[ti][tj]);
                     acc[ti][tj] = GXB_MFMA(al[ti], bh[tj], acc[ti][tj]);
                     acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
+                    if (TERMS >= 4) acc[ti][tj] = GXB_MFMA(al[ti], bl[tj], acc[ti][tj]);      // (ADMM: its systems carry the caller's fixed rho, kernels_bf16.hip top)
                 }
         }
     };
@@ -567,12 +568,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
                const unsigned short* Blo, int64_t ldb, float* C, int64_t ldc, int64_t cstride, int64_t M, int64_t N, int64_t K, int S,
-               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr) {
+               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr,
+               int terms = 3) {
     if (M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape"; return NMFX_E_ARG; }
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
     int rc;
-    if (mode == GX_STORE) {
+    if (mode == GX_STORE && terms == 4) {
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE, 4>), GXB_SHM))) return rc;
+        hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE, 4>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
+    } else if (mode == GX_STORE) {
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE>), GXB_SHM))) return rc;
         hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
     } else if (mode == GX_KLQ) {                       // (ldc = the row stride of the Q planes)
@@ -597,13 +602,13 @@ int gxb_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
 
 // split-K product into the slab buffer gx_s, summed into `out`
 int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
-                      const unsigned short* Blo, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K, int cap) {
+                      const unsigned short* Blo, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3) {
     int rc;
     int S = gxb_split(E, (M / GX_T) * (N / GX_T), K, cap);
     const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);   // gx_buffers: gx_s
     while (S > 1 && ((int64_t)S * M * N > slab_cap || (K / GXB_KC) % S)) --S;
-    if (S == 1) return gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr);
-    if ((rc = gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr))) return rc;
+    if (S == 1) return gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, terms);
+    if ((rc = gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr, nullptr, nullptr, nullptr, terms))) return rc;
     return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
 }
 
@@ -1310,7 +1315,12 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
     float* xG = E->xf32 + kp * np;
     const float* data = kl ? E->S : E->V;              // (KL: v_aux + dual_v, admm.py:224)
     const int* flag = &E->state->flag;
-    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;     // (admm.py:289)
+    // Euclidean loss, split-bf16 runs: the V-sized products from the V planes and images of the auxiliaries (FOUR terms: the Gram
+    // systems carry the caller's fixed rho, kernels_bf16.hip top), the objective's W H from the images of (w, h) (three terms)
+    const bool bf = !kl && gxb_on(E);
+    if (bf && (rc = gxb_prepare(E, W))) return rc;
+    E->gxb_img_ready = false;
+    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;     // (admm.py:289)
     for (int64_t j = first; j < first + count; ++j) {
         hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
                            E->state, E->obj_hist);
@@ -1319,7 +1329,11 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
         { ProfScope ps(E, "gram_tn");
           if ((rc = gx_split_product<false, false>(E, E->auxW, kp, E->auxW, kp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");
-          if ((rc = gx_split_product<false, false>(E, E->auxW, kp, data, np, xB, kp, np, mp, 8))) return rc; }
+          if (bf) {
+              if ((rc = nmfx_split_images(E, E->auxW, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc;
+              rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8, 4);
+          } else rc = gx_split_product<false, false>(E, E->auxW, kp, data, np, xB, kp, np, mp, 8);
+          if (rc) return rc; }
         if ((rc = gx_prepare(E, xG, rho))) return rc;
         { ProfScope ps(E, "inner_h");
           const int64_t c4 = kp * np / 4;
@@ -1331,7 +1345,11 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
         { ProfScope ps(E, "gram_nt");
           if ((rc = gx_split_product<true, true>(E, E->auxH, np, E->auxH, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");
-          if ((rc = gx_split_product<true, true>(E, data, np, E->auxH, np, E->A_part, mp, kp, np, 1))) return rc; }
+          if (bf) {
+              if ((rc = nmfx_split_images(E, E->auxH, kp, np, np, E->Hhi, E->Hlo, nullptr, nullptr))) return rc;
+              rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4, 4);
+          } else rc = gx_split_product<true, true>(E, data, np, E->auxH, np, E->A_part, mp, kp, np, 1);
+          if (rc) return rc; }
         if ((rc = gx_prepare(E, E->HHt, rho))) return rc;
         { ProfScope ps(E, "inner_w");
           const int64_t c4 = mp * kp / 4;
@@ -1346,7 +1364,10 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
             ProfScope ps(E, "kl_vaux");
             if ((rc = gx_launch<true, false>(E, GX_VAUX, E->auxW, kp, E->auxH, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, nullptr, E->S))) return rc;
         }
-        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;
+        if (bf) { ProfScope ps(E, "images");          // images of the new (w, h) for the objective
+                  if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], nullptr, nullptr))) return rc;
+                  if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc; }
+        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;
     }
     (void)flag;
     return NMFX_OK;

@@ -69,3 +69,21 @@ for k in (256,):
         e.state()                                       # (raises on "not positive definite")
         print(json.dumps({"k": k, "solver": "ao_admm eu nn/l1n", "ms_per_iter": dt * 1e3, "iter_per_s": 1 / dt,
                           "inner_rounds": (e.inner_counts(3, steps) & 0xFFFF).tolist(), "kernels_us": prof}), flush=True)
+
+# ADMM (Euclidean, fixed rho, prox nn / l1n) beyond 128 components
+for k in (256,):
+    rs = np.random.RandomState(0)
+    w0, h0 = 0.05 * np.abs(rs.randn(m, k)), 0.05 * np.abs(rs.randn(k, n))
+    with Engine(m, n, k) as e:
+        e.upload_v(v)
+        e.set_factors(w0, h0)
+        e.admm_run(L.EU, 1.0, L.PROX['nn'], 0.0, L.PROX['l1n'], 0.1, NEVER, 1e-5, 1e-5, 0, 3)
+        e.synchronize()
+        steps = 8
+        t0 = time.perf_counter()
+        e.admm_run(L.EU, 1.0, L.PROX['nn'], 0.0, L.PROX['l1n'], 0.1, NEVER, 1e-5, 1e-5, 3, steps)
+        e.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        e.state()
+        print(json.dumps({"k": k, "solver": "admm eu nn/l1n rho=1", "ms_per_iter": dt * 1e3, "iter_per_s": 1 / dt,
+                          "objective": e.objectives(3 + steps, 1).tolist()}), flush=True)
