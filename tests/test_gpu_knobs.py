@@ -47,6 +47,14 @@ CASES = [
     ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_CINV": "0"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),      # elimination kernels only
     ({"NMFX_NNLS_CINV": "0"}, "anls", (260, 400, 100), dict(min_iter=3, max_iter=3, lambda_w=0.05, lambda_h=0.02, nndsvd_init=NNDSVD)),
+    ({"NMFX_NW4": "3"}, "mur", (384, 256, 40), dict(distance_type="eu", min_iter=15, max_iter=15)),        # four-wave blocks, both phases
+    ({"NMFX_NW4": "1"}, "mur", (640, 384, 64), dict(distance_type="eu", lambda_w=0.1, lambda_h=0.2, min_iter=12, max_iter=12)),
+    # beyond 128 components: the exact-f32 product kernel and the one-workgroup Gram inversion behind the split-bf16 / blocked defaults
+    ({"NMFX_PRECISION": "f32"}, "mur", (384, 256, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
+    ({"NMFX_PRECISION": "f32"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
+    ({"NMFX_PRECISION": "f32"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
+    ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
+    ({"NMFX_PRECISION": "f32"}, "admm", (384, 320, 160), dict(rho=1.0, reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
 ]
 
 

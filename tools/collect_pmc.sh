@@ -8,7 +8,7 @@ tag=${1:-r03}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
-for probe in cfg2 k128 kl cfg3 pair; do
+for probe in ${PROBES:-cfg2 k128 kl cfg3 pair k256}; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"; do
     name=${probe}_$(echo "$ctr" | tr ' ' '+')
     if [ "$probe" = cfg2 ]; then
@@ -29,7 +29,7 @@ for f in sorted(glob.glob(out + "/*.csv")):
     probe = os.path.basename(f).split("_")[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k:
+        if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k and "gxb_gemm_kernel" not in k:
             continue
         short = k.split("(")[0].replace("void ", "")
         acc[probe + ": " + short][r["Counter_Name"]].append(float(r["Counter_Value"]))

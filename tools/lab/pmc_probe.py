@@ -2,7 +2,8 @@
     python3 tools/lab/pmc_probe.py k128   MUR-eu, one rank's shard of config 5 (16384 x 16384, k = 128)
     python3 tools/lab/pmc_probe.py kl     MUR-kl, config 4 (32768 x 16384, k = 64)
     python3 tools/lab/pmc_probe.py cfg3   AO-ADMM, config 3 (16384 x 8192, k = 128, planted start)
-    python3 tools/lab/pmc_probe.py pair   two k = 64 MUR-eu problems per pass, config-2 shape"""
+    python3 tools/lab/pmc_probe.py pair   two k = 64 MUR-eu problems per pass, config-2 shape
+    python3 tools/lab/pmc_probe.py k256   MUR-eu beyond 128 components (16384 x 8192, k = 256): the split-bf16 NT kernel over operand planes"""
 import os
 import sys
 
@@ -14,7 +15,8 @@ from nmf_amd.synth import planted_matrix  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "k128"
 NEVER = 10 ** 12
-m, n, k = {"k128": (16384, 16384, 128), "kl": (32768, 16384, 64), "cfg3": (16384, 8192, 128), "pair": (16384, 8192, 128)}[mode]
+m, n, k = {"k128": (16384, 16384, 128), "kl": (32768, 16384, 64), "cfg3": (16384, 8192, 128), "pair": (16384, 8192, 128),
+           "k256": (16384, 8192, 256)}[mode]
 v = planted_matrix(m, n, 32, seed=0, dtype=np.float32)
 rs = np.random.RandomState(0)
 with Engine(m, n, k) as eng:
