@@ -1,5 +1,6 @@
 """More than 128 components (missing 1): the reference takes any `factors` (nmf/nmf.py:32-35, nmf/mur.py:52).
-All four solvers compose their iterations from the generic exact-f32 product kernel (kernels_generic.hip) beyond k = 128."""
+All four solvers compose their iterations from one tiled product kernel (kernels_generic.hip) beyond k = 128: split bf16 over operand
+planes for MUR, AO-ADMM-LS and ADMM-LS (the default), exact f32 for the rest (tests/test_gpu_knobs.py runs the exact-f32 forms)."""
 import numpy as np
 import pytest
 
@@ -24,6 +25,59 @@ def test_mur_beyond_128_components_vs_oracle(shape, k, distance):
     assert res.i == ref.i and len(res.obj_history) == res.i + 2
     assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)
+
+
+def test_mur_kl_k160_zero_and_tiny_entries():
+    """KL beyond k = 128 on data with exact zeros (utils.py:24 zeroes their 0 log 0), tiny entries and all-zero rows: the quotient
+    planes and the objective of the split-bf16 product kernel's KL epilogue (x rcp(zy + 1e-9), x log(x / zy) with inf / nan -> 0)."""
+    from nmf_amd.mur import mur
+    m, n, k = 400, 360, 160
+    rs = np.random.RandomState(k)
+    v = R.planted_matrix(m, n, 12, seed=k, dtype=np.float32)
+    v[rs.rand(m, n) < 0.3] = 0.0
+    v[:, : n // 4] *= 1e-3
+    v[: m // 8] *= 1e-2
+    v[m - 3:] = 0.0
+    kw = dict(distance_type="kl", min_iter=12, max_iter=12, lambda_w=0.0, lambda_h=0.01)
+    np.random.seed(3)
+    res = mur(v.copy(), k, **kw)
+    np.random.seed(3)
+    ref = R.mur(v.astype(np.float64), k, **kw)
+    assert np.isfinite(res.obj_history).all() and np.isfinite(res.w).all() and np.isfinite(res.h).all()
+    assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)
+
+
+def test_solvers_alternate_on_one_engine_beyond_128_components():
+    """One handle, k = 160: MUR-eu iterations, then AO-ADMM on new factors, then MUR-eu again -- the bf16 images the MUR loop keeps
+    of (W, H) must be rebuilt after another solver (or set_factors) has rewritten the factors (gxb_img_ready)."""
+    from nmf_amd.engine import Engine
+    from nmf_amd import _lib as L
+    m, n, k = 384, 512, 160
+    v = R.planted_matrix(m, n, 20, seed=9, dtype=np.float32)
+    rs = np.random.RandomState(1)
+    w0, h0 = 0.3 * np.abs(rs.randn(m, k)), 0.3 * np.abs(rs.randn(k, n))
+    NEVER = 10 ** 12
+
+    def mur_from(e, w, h, iters):
+        e.set_factors(w, h)
+        e.mur_run(L.EU, 0.0, 0.0, NEVER, 1e-9, 1e-9, 0, iters)
+        e.synchronize()
+        return e.get_factors(), e.objectives(0, iters)
+
+    with Engine(m, n, k) as fresh:
+        fresh.upload_v(v)
+        (w_a, h_a), obj_a = mur_from(fresh, w0, h0, 6)
+    with Engine(m, n, k) as e:
+        e.upload_v(v)
+        mur_from(e, w0 * 1.5, h0 * 0.5, 3)                        # leaves images of OTHER factors behind
+        e.set_factors(w0, h0)
+        e.aoadmm_run(L.EU, L.PROX['nn'], 0.0, L.PROX['nn'], 0.0, 4, NEVER, 1e-9, 1e-9, 0, 2)
+        e.synchronize()
+        (w_b, h_b), obj_b = mur_from(e, w0, h0, 6)
+    np.testing.assert_array_equal(w_a, w_b)
+    np.testing.assert_array_equal(h_a, h_b)
+    np.testing.assert_array_equal(obj_a, obj_b)
 
 
 def test_mur_eu_k160_stop_rule_and_negative_data():
