@@ -418,7 +418,12 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             prof[dom]["us_per_launch"] = round(eng.profile_repeat(dom, 20, repeat_dist) * 1e3, 2)
         dsec = prof[dom]["us_per_launch"] * 1e-6
         return {"config": name, "workload": workload, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
-                "warmup": warmup, "precision": eng.precision(), "host_ms_to_queue_all_steps": t_queued * 1e3,
+                "warmup": warmup,
+                # (nmfx_get_precision speaks of the tuned k <= 128 kernels; beyond 128 components the composed path runs its V-sized products
+                #  in split bf16 unless NMFX_PRECISION=f32 / set_precision('f32'), kernels_generic.hip gxb_on)
+                "precision": (eng.precision() if k <= 128 else
+                              "f32" if (precision == "f32" or os.environ.get("NMFX_PRECISION", "") in ("f32", "fp32")) else "bf16"),
+                "host_ms_to_queue_all_steps": t_queued * 1e3,
                 "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
                 "dominant_kernel": ({"name": dom, "us_per_launch": prof[dom]["us_per_launch"],

@@ -665,6 +665,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
     int rc;
     const bool kl = distance == NMFX_KL;
     if ((rc = gx_buffers(E, kl && !gxb_on(E)))) return rc;
+    if (!gxb_on(E)) E->gxb_img_ready = false;          // (exact-f32 iterations rewrite W and H without their images)
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     const float* W = E->W[j & 1];
     float* Wn = E->W[(j + 1) & 1];

@@ -80,6 +80,39 @@ def test_solvers_alternate_on_one_engine_beyond_128_components():
     np.testing.assert_array_equal(obj_a, obj_b)
 
 
+def test_precision_switched_on_one_engine_beyond_128_components():
+    """k = 160, one handle: split-bf16 iterations, exact-f32 iterations (set_precision), split bf16 again -- equal to the same three
+    legs on fresh engines handing the factors over (the exact-f32 leg rewrites W and H without the bf16 images of the MUR loop)."""
+    from nmf_amd.engine import Engine
+    from nmf_amd import _lib as L
+    m, n, k = 384, 512, 160
+    v = R.planted_matrix(m, n, 20, seed=11, dtype=np.float32)
+    rs = np.random.RandomState(2)
+    w, h = 0.3 * np.abs(rs.randn(m, k)), 0.3 * np.abs(rs.randn(k, n))
+    NEVER = 10 ** 12
+    legs = (("bf16", 3), ("f32", 2), ("bf16", 3))
+    with Engine(m, n, k) as e:
+        e.upload_v(v)
+        e.set_factors(w, h)
+        first = 0
+        for mode, count in legs:
+            e.set_precision(mode)
+            e.mur_run(L.EU, 0.01, 0.0, NEVER, 1e-9, 1e-9, first, count)
+            first += count
+        e.synchronize()
+        w_a, h_a = e.get_factors()
+    for mode, count in legs:
+        with Engine(m, n, k) as e:
+            e.upload_v(v)
+            e.set_precision(mode)
+            e.set_factors(w, h)
+            e.mur_run(L.EU, 0.01, 0.0, NEVER, 1e-9, 1e-9, 0, count)
+            e.synchronize()
+            w, h = e.get_factors()
+    np.testing.assert_array_equal(w_a, w)
+    np.testing.assert_array_equal(h_a, h)
+
+
 def test_mur_eu_k160_stop_rule_and_negative_data():
     """k = 160 with the stop rule firing (same index and rule as the oracle) on data with negative entries (lifted in place,
     nmf/mur.py:99-101)."""
