@@ -735,9 +735,10 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
           NMFX_HIP(hipGetLastError()); }
         { ProfScope ps(E, "images");
           if ((rc = nmfx_split_images(E, Wn, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
-        { ProfScope ps(E, "hphase");                   // Q'^T = V^T / (H^T W_new^T + 1e-9), B = W_new^T Q', d = W_new^T 1
+        { ProfScope ps(E, "objective");                // Q'^T = V^T / (H^T W_new^T + 1e-9)  (the second quotient product of the iteration, no objective)
           if ((rc = gxb_launch(E, GX_KLQ, E->HThi, E->HTlo, kp, E->Whi[0], E->Wlo[0], kp, nullptr, mp, 0, np, mp, kp, 1, E->gxb_vt, mp, nullptr, nullptr,
-                               E->gxb_q[0], E->gxb_q[1]))) return rc;
+                               E->gxb_q[0], E->gxb_q[1]))) return rc; }
+        { ProfScope ps(E, "hphase");                   // B = W_new^T Q', d = W_new^T 1
           if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_q[0], E->gxb_q[1], mp, xB, kp, np, mp, 8))) return rc;
           const int rb = (int)(mp / 64);
           hipLaunchKernelGGL(gx_colsum_part_kernel, dim3((unsigned)rb), dim3(256), 0, E->stream, (const float*)Wn, kp, 64, E->gx_s, (const int*)&E->state->flag);
