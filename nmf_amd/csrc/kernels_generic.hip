@@ -882,9 +882,13 @@ __global__ __launch_bounds__(256) void gx_rhs_kernel(const float* __restrict__ B
     reinterpret_cast<float4*>(rhs)[i] = make_float4(b.x + rho * (x.x + u.x), b.y + rho * (x.y + u.y), b.z + rho * (x.z + u.z), b.w + rho * (x.w + u.w));
 }
 
-// X = prox(aux, U); U += X - aux; the four sums of squares `terminate` needs (ao_admm.py:60-62, 33-43): part[block][4]
+// X = prox(aux, U); U += X - aux; the four sums of squares `terminate` needs (ao_admm.py:60-62, 33-43): part[block][4].
+// With Bm != nullptr it also leaves the NEXT round's right-hand side rhs = Bm + rho (X + U) -- the expression of gx_rhs_kernel on
+// the values it has just stored -- so only the first round of a sub-problem launches gx_rhs_kernel (r3: one launch and two array
+// reads less per round).
 __global__ __launch_bounds__(256) void gx_prox_kernel(const float* __restrict__ aux, float* __restrict__ X, float* __restrict__ U, int prox, float lam,
-                                                      int64_t count4, double* __restrict__ part, const DevState* __restrict__ st)
+                                                      int64_t count4, double* __restrict__ part, const DevState* __restrict__ st,
+                                                      const float* __restrict__ Bm = nullptr, float* __restrict__ rhs = nullptr)
 {
     if (st->flag || st->inner_stop) return;
     __shared__ double sh[4][4];
@@ -905,6 +909,12 @@ __global__ __launch_bounds__(256) void gx_prox_kernel(const float* __restrict__ 
         }
         reinterpret_cast<float4*>(X)[i] = make_float4(xn[0], xn[1], xn[2], xn[3]);
         reinterpret_cast<float4*>(U)[i] = make_float4(un[0], un[1], un[2], un[3]);
+        if (Bm) {
+            const float rho = (float)st->rho;
+            const float4 b = reinterpret_cast<const float4*>(Bm)[i];
+            reinterpret_cast<float4*>(rhs)[i] = make_float4(b.x + rho * (xn[0] + un[0]), b.y + rho * (xn[1] + un[1]), b.z + rho * (xn[2] + un[2]),
+                                                            b.w + rho * (xn[3] + un[3]));
+        }
     }
     double v[4] = {(double)n0, (double)n1, (double)n2, (double)n3};
 #pragma unroll
@@ -1086,14 +1096,16 @@ int gx_ao_subproblem(nmfx_engine* E, bool hside, const float* G, const float* B,
     const int nblk = (int)((cnt4 + 255) / 256);
     const int* stop = &E->state->inner_stop;
     for (int r = 0; r < admm_iter; ++r) {
-        hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, B, (const float*)X, (const float*)U, E->gx_r, cnt4,
-                           (const DevState*)E->state);
-        NMFX_HIP(hipGetLastError());
+        if (r == 0) {                                  // (later rounds: the prox launch of the round before has left the right-hand side)
+            hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, B, (const float*)X, (const float*)U, E->gx_r, cnt4,
+                               (const DevState*)E->state);
+            NMFX_HIP(hipGetLastError());
+        }
         if (hside) rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, cols, E->gx_d, cols, 0, kp, cols, kp, 1, nullptr, 0, nullptr, stop);
         else rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->gx_d, kp, 0, rows, kp, kp, 1, nullptr, 0, nullptr, stop);
         if (rc) return rc;
         hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, X, U, prox, lam, cnt4, E->gx_nrm,
-                           (const DevState*)E->state);
+                           (const DevState*)E->state, r + 1 < admm_iter ? B : (const float*)nullptr, E->gx_r);
         hipLaunchKernelGGL(gx_decide_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->state);
         NMFX_HIP(hipGetLastError());
     }
