@@ -613,7 +613,8 @@ int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
 }
 
 // the split-bf16 products are the default for the Euclidean MUR loop beyond k = 128 (NMFX_PRECISION=f32 keeps the exact-f32 kernel)
-bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
+bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && !E->gxb_disabled && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
+constexpr int GXB_NOFIT = 1;       // gxb_prepare: not an error -- the planes do not fit, the handle falls back to the exact-f32 product kernel
 
 // out [cols][rows] = in [rows][cols]^T (f32, 64 x 64 tiles through LDS)
 __global__ __launch_bounds__(256) void gx_transpose_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, float* __restrict__ out)
@@ -631,6 +632,23 @@ __global__ __launch_bounds__(256) void gx_transpose_kernel(const float* __restri
 int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
     int rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    {   // what is still to be allocated must fit beside what the handle holds (like nmfx_create's fall back for k <= 128: visible in nmfx_get_note)
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (int i = 0; i < 4; ++i) if (!E->gxb_v[i]) need += (size_t)mp * np * 2;
+        if (!E->WThi) need += (size_t)4 * mp * kp * 2;
+        if (!E->HThi) need += (size_t)4 * kp * np * 2;
+        if (kl && !E->gxb_vt) need += (size_t)mp * np * 8;
+        static const bool pretend = getenv("NMFX_GXB_NOFIT") != nullptr;          // (tests: take the fall back without filling the device)
+        if (need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (pretend || free_b < need + ((size_t)256 << 20))) {
+            E->gxb_disabled = true;
+            E->gxb_img_ready = false;
+            char buf[256];
+            snprintf(buf, sizeof buf, "%sk > 128: %.1f GiB free, the bf16 operand planes need %.1f GiB more: exact-f32 product kernel on this handle",
+                     E->note.empty() ? "" : "; ", (double)free_b / (1 << 30), (double)need / (1 << 30));
+            E->note += buf;
+            return GXB_NOFIT;
+        }
+    }
     if (kl) {
         if ((rc = gx_alloc(E, &E->gxb_vt, mp * np)) || (rc = gx_alloc(E, &E->gxb_q[0], mp * np)) || (rc = gx_alloc(E, &E->gxb_q[1], mp * np))) return rc;
         if (!E->gxb_vt_ready) {
@@ -673,8 +691,12 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
     float* xB = E->xf32;                               // [kp][np]
     float* xG = E->xf32 + kp * np;                     // [kp][kp]
     float* xS = xG + kp * kp;                          // [kp] column sums of W (KL)
+    if (gxb_on(E)) {                                   // (operands of the split-bf16 products; if they do not fit: exact f32 from here on, and its m x n quotient buffer for KL)
+        rc = gxb_prepare(E, W, kl);
+        if (rc == GXB_NOFIT) { if ((rc = gx_buffers(E, kl))) return rc; }
+        else if (rc) return rc;
+    }
     if (!kl && gxb_on(E)) {                            // the same steps with the V-sized products and the Gram matrices in split bf16
-        if ((rc = gxb_prepare(E, W))) return rc;
         { ProfScope ps(E, "objective");
           if ((rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
         if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
@@ -720,7 +742,6 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
         // split bf16: the quotient leaves its product as bf16 planes in the layout the next product contracts over -- Q [mp][np] from
         // (W images) x (H^T images) for A = Q H^T, and the H side's Q'^T [np][mp] from (H^T images) x (W_new images) against V^T for
         // B = W_new^T Q' -- so all four V-sized products are the one NT kernel (three terms, like the tuned MUR-KL kernels)
-        if ((rc = gxb_prepare(E, W, true))) return rc;
         { ProfScope ps(E, "objective");
           if ((rc = gxb_launch(E, GX_KLQ, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, np, 0, mp, np, kp, 1, E->V, np, E->gx_part, nullptr,
                                E->gxb_q[0], E->gxb_q[1]))) return rc; }
@@ -807,13 +828,16 @@ int nmfx_generic_mur_finish_a(nmfx_engine* E, int distance, int64_t j) {
     if ((rc = gx_buffers(E, kl && !gxb_on(E)))) return rc;
     const int64_t mp = E->mp, np = E->np, kp = E->kp;
     const int64_t nblk = (mp / GX_T) * (np / GX_T);
+    if (gxb_on(E)) {
+        rc = gxb_prepare(E, E->W[j & 1], kl);
+        if (rc == GXB_NOFIT) { if ((rc = gx_buffers(E, kl))) return rc; }
+        else if (rc) return rc;
+    }
     { ProfScope ps(E, "objective");
       if (!kl && gxb_on(E)) {
-          if ((rc = gxb_prepare(E, E->W[j & 1]))) return rc;
           rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       } else if (!kl) rc = gx_launch<true, false>(E, GX_RESID, E->W[j & 1], kp, E->H, np, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part);
       else if (gxb_on(E)) {
-          if ((rc = gxb_prepare(E, E->W[j & 1], true))) return rc;
           rc = gxb_launch(E, GX_KLQ, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, np, 0, mp, np, kp, 1, E->V, np, E->gx_part, nullptr,
                           E->gxb_q[0], E->gxb_q[1]);
       } else rc = gx_launch<true, false>(E, GX_KLQ, E->W[j & 1], kp, E->H, np, E->S, np, 0, mp, np, kp, 1, E->V, np, E->gx_part);
@@ -1140,8 +1164,8 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
     float* xG = E->xf32 + kp * np;
     // split-bf16 runs: the three V-sized products (W^T V, V H^T, the objective's W H) from the V planes and the factor images, three
     // terms as in the tuned AO-ADMM (kernels_bf16.hip, top); the Gram matrices, whose shifted inverse the rounds apply, stay exact f32
-    const bool bf = gxb_on(E);
-    if (bf && (rc = gxb_prepare(E, W))) return rc;
+    bool bf = gxb_on(E);
+    if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
     E->gxb_img_ready = false;                          // (valid inside this call only: the MUR loop keeps the images of W[j & 1])
     if (first == 0 && count > 0 && (rc = gx_objective_partial(E, bf))) return rc;      // obj[0] (ao_admm.py:256)
     for (int64_t j = first; j < first + count; ++j) {
@@ -1331,8 +1355,8 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
     const int* flag = &E->state->flag;
     // Euclidean loss, split-bf16 runs: the V-sized products from the V planes and images of the auxiliaries (FOUR terms: the Gram
     // systems carry the caller's fixed rho, kernels_bf16.hip top), the objective's W H from the images of (w, h) (three terms)
-    const bool bf = !kl && gxb_on(E);
-    if (bf && (rc = gxb_prepare(E, W))) return rc;
+    bool bf = !kl && gxb_on(E);
+    if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
     E->gxb_img_ready = false;
     if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;     // (admm.py:289)
     for (int64_t j = first; j < first + count; ++j) {

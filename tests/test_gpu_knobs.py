@@ -55,6 +55,9 @@ CASES = [
     ({"NMFX_PRECISION": "f32"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_PRECISION": "f32"}, "admm", (384, 320, 160), dict(rho=1.0, reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
+    # the bf16 operand planes "do not fit": the handle falls back to the exact-f32 product kernel (and says so in nmfx_get_note)
+    ({"NMFX_GXB_NOFIT": "1"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
+    ({"NMFX_GXB_NOFIT": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
 ]
 
 
