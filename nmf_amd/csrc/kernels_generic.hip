@@ -612,6 +612,161 @@ int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
     return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
 }
 
+// ---- the V-sized products with a long contraction on TILED planes filled by LDS-DMA (r3, experiment: NMFX_GXT=1) -------------------
+// gxb_gemm_kernel stages its operands through registers: per CU and chunk the ds_write_b128 path (~79 B/clk), the texture path and
+// the matrix pipe carry loads within 30 % of each other.  Here the planes are stored as TILES in the image the LDS wants --
+//     tile (row tile rt of 128, chunk c of 32) = 8 KiB contiguous at ((rt (K / 32) + c) 4096) elements:
+//     element (row rr, k) at rr 32 + 8 ((k / 8) ^ ((rr >> 2) & 3)) + k % 8
+// (the 16 rows of a ds_read_b128 lane group then fall on 16 distinct bank quadruples: 4 (rr & 3) + (chunk ^ (rr >> 2 & 3))) -- so a
+// stage is filled by plain linear copies global -> LDS (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs, no
+// ds_write), three stages of a 256 x 128 block tile (48 KiB each: two chunks in flight), eight waves x (2 x 2 tiles of 32 x 32), one
+// barrier per chunk, counted vmcnt.  C[M][N] = sum_t A[i][t] B[j][t], STORE only.
+__device__ __forceinline__ unsigned gxt_lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void gxt_dma(unsigned long long base, unsigned dst, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(voff) : "memory");
+}
+constexpr int GXT_STAGE = 6 * 8192, GXT_SHM = 3 * GXT_STAGE;
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void gxt_gemm_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, const unsigned short* __restrict__ Bhi,
+    const unsigned short* __restrict__ Blo, float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t M, int64_t K,
+    const int* __restrict__ flag, const int* __restrict__ flag2)
+{
+    if (*flag || (flag2 && *flag2)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gxt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, n31 = lane & 31, b = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t kch = K / 32, nch = kch / gridDim.z, c0 = nch * blockIdx.z;
+    const int64_t mt = M / 128;
+    const int64_t rt0 = 2 * (int64_t)blockIdx.y, rt1 = (rt0 + 1 < mt) ? rt0 + 1 : rt0;          // (an odd number of row tiles: the last block loads its tile twice)
+    const bool second = rt0 + 1 < mt;
+    // DMA: per chunk six units of 8 KiB (A hi t0, A hi t1, A lo t0, A lo t1, B hi, B lo); wave w copies piece w (1 KiB) of each
+    unsigned long long src[6];
+    src[0] = (unsigned long long)(Ahi + (rt0 * kch + c0) * 4096) + wave * 1024ull;
+    src[1] = (unsigned long long)(Ahi + (rt1 * kch + c0) * 4096) + wave * 1024ull;
+    src[2] = (unsigned long long)(Alo + (rt0 * kch + c0) * 4096) + wave * 1024ull;
+    src[3] = (unsigned long long)(Alo + (rt1 * kch + c0) * 4096) + wave * 1024ull;
+    src[4] = (unsigned long long)(Bhi + ((int64_t)blockIdx.x * kch + c0) * 4096) + wave * 1024ull;
+    src[5] = (unsigned long long)(Blo + ((int64_t)blockIdx.x * kch + c0) * 4096) + wave * 1024ull;
+    const unsigned smem0 = __builtin_amdgcn_readfirstlane(gxt_lds_off(gxt_smem));
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int64_t c, int stage) {
+        const unsigned dst = smem0 + stage * GXT_STAGE + wave * 1024;
+        const unsigned long long adv = (unsigned long long)c * 8192ull;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) gxt_dma(src[u] + adv, dst + u * 8192, voff);
+    };
+    // fragment offsets inside a stage: wave = (row group of 64 of the 256, column group of 64 of the 128)
+    const int wr = 64 * (wave >> 1), wc = 64 * (wave & 1);
+    int aoff[2][2], boff[2][2];                       // [tile][k-step]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = (wr & 127) + 32 * t + n31, rb = wc + 32 * t + n31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            aoff[t][ks] = (wr >> 7) * 8192 + ra * 64 + 16 * ((2 * ks + b) ^ ((ra >> 2) & 3));        // + 16384: lo
+            boff[t][ks] = 4 * 8192 + rb * 64 + 16 * ((2 * ks + b) ^ ((rb >> 2) & 3));                // + 8192: lo
+        }
+    }
+    gxb_f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    int stage = 0;
+    for (int64_t c = 0; c < nch; ++c) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // chunk c has landed everywhere; everybody is done with the stage chunk c + 2 goes to
+        if (c + 2 < nch) issue(c + 2, stage >= 1 ? stage - 1 : 2);      // (c + 2) % 3
+        const unsigned char* st = gxt_smem + stage * GXT_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            GxbFrag ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t].u = *reinterpret_cast<const uint4*>(st + aoff[t][ks]);
+                al[t].u = *reinterpret_cast<const uint4*>(st + aoff[t][ks] + 16384);
+                bh[t].u = *reinterpret_cast<const uint4*>(st + boff[t][ks]);
+                bl[t].u = *reinterpret_cast<const uint4*>(st + boff[t][ks] + 8192);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(al[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
+                    if (TERMS >= 4) acc[ti][tj] = GXB_MFMA(al[ti], bl[tj], acc[ti][tj]);
+                }
+        }
+        stage = (stage == 2) ? 0 : stage + 1;
+    }
+    if (wr >= 128 && !second) return;                  // (the duplicated tile of an odd last block)
+    float* Cz = C + (int64_t)blockIdx.z * cstride;
+    const int64_t i0 = (int64_t)blockIdx.y * 256, j0 = (int64_t)blockIdx.x * 128;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                Cz[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + n31] = acc[ti][tj][r];
+}
+
+// row-major plane [R][K] (bf16) -> the tiled image above
+__global__ __launch_bounds__(256) void gxt_retile_kernel(const unsigned short* __restrict__ in, int64_t R, int64_t K, unsigned short* __restrict__ out,
+                                                         const int* __restrict__ flag)
+{
+    if (flag && *flag) return;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk (8 k) per thread
+    if (id >= R * K / 8) return;
+    const int64_t r = id / (K / 8), k8 = id % (K / 8);
+    const int rr = (int)(r & 127), cc = (int)(k8 & 3);
+    const int64_t tile = (r >> 7) * (K / 32) + (k8 >> 2);
+    const uint4 v = *reinterpret_cast<const uint4*>(in + r * K + 8 * k8);
+    *reinterpret_cast<uint4*>(out + tile * 4096 + rr * 32 + 8 * (cc ^ ((rr >> 2) & 3))) = v;
+}
+
+int gxt_retile(nmfx_engine* E, const unsigned short* in, int64_t R, int64_t K, unsigned short* out, bool check_flag) {
+    const int64_t n = R * K / 8;
+    hipLaunchKernelGGL(gxt_retile_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, E->stream, in, R, K, out,
+                       check_flag ? (const int*)&E->state->flag : (const int*)nullptr);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// split-K product on the tiled planes into the slab buffer gx_s, summed into `out` (M: rows of A, N: rows of B, K: contraction)
+int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi, const unsigned short* Blo,
+                      float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3) {
+    int rc;
+    const int64_t blocks = ((M / 128 + 1) / 2) * (N / 128), ch = K / 32;
+    int64_t S = std::max<int64_t>(1, std::min<int64_t>(cap, ((int64_t)E->ncu + blocks - 1) / blocks));
+    const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);
+    while (S > 1 && (S * M * N > slab_cap || ch % S)) --S;
+    const dim3 grid((unsigned)(N / 128), (unsigned)((M / 128 + 1) / 2), (unsigned)S), block(512);
+    float* C = S == 1 ? out : E->gx_s;
+    const int* flag = &E->state->flag;
+    if (terms == 4) {
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt_gemm_kernel<4>), GXT_SHM))) return rc;
+        hipLaunchKernelGGL((gxt_gemm_kernel<4>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr);
+    } else {
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt_gemm_kernel<3>), GXT_SHM))) return rc;
+        hipLaunchKernelGGL((gxt_gemm_kernel<3>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr);
+    }
+    NMFX_HIP(hipGetLastError());
+    if (S == 1) return NMFX_OK;
+    return nmfx_launch_sum_partials(E, E->gx_s, (int)S, M * N, out);
+}
+
+bool gxt_on() { static const bool on = getenv("NMFX_GXT") && atoi(getenv("NMFX_GXT")) == 1; return on; }
+
 // the split-bf16 products are the default for the Euclidean MUR loop beyond k = 128 (NMFX_PRECISION=f32 keeps the exact-f32 kernel)
 bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && !E->gxb_disabled && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
 constexpr int GXB_NOFIT = 1;       // gxb_prepare: not an error -- the planes do not fit, the handle falls back to the exact-f32 product kernel
@@ -702,8 +857,22 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
         if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
         { ProfScope ps(E, "gram_nt");
           if ((rc = gxb_split_product(E, E->Hhi, E->Hlo, np, E->Hhi, E->Hlo, np, E->HHt, kp, kp, np, 64))) return rc; }
+        if (gxt_on()) {                                // experiment: tiled planes + LDS-DMA product kernel for the two long contractions
+            for (int i = 0; i < 4; ++i) if ((rc = gx_alloc(E, &E->gxt_v[i], mp * np))) return rc;
+            if ((rc = gx_alloc(E, &E->gxt_f[0], kp * np)) || (rc = gx_alloc(E, &E->gxt_f[1], kp * np)) || (rc = gx_alloc(E, &E->gxt_f[2], mp * kp)) ||
+                (rc = gx_alloc(E, &E->gxt_f[3], mp * kp))) return rc;
+            ProfScope ps(E, "images");
+            if (!E->gxt_v_ready) {
+                if ((rc = gxt_retile(E, E->gxb_v[0], mp, np, E->gxt_v[0], false)) || (rc = gxt_retile(E, E->gxb_v[1], mp, np, E->gxt_v[1], false)) ||
+                    (rc = gxt_retile(E, E->gxb_v[2], np, mp, E->gxt_v[2], false)) || (rc = gxt_retile(E, E->gxb_v[3], np, mp, E->gxt_v[3], false))) return rc;
+                E->gxt_v_ready = true;
+            }
+            if ((rc = gxt_retile(E, E->Hhi, kp, np, E->gxt_f[0], true)) || (rc = gxt_retile(E, E->Hlo, kp, np, E->gxt_f[1], true))) return rc;
+        }
         { ProfScope ps(E, "wphase");                   // A = V H^T
-          if ((rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4))) return rc; }
+          if (gxt_on()) rc = gxt_split_product(E, E->gxt_v[0], E->gxt_v[1], E->gxt_f[0], E->gxt_f[1], E->A_part, mp, kp, np, 4);
+          else rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4);
+          if (rc) return rc; }
         { ProfScope ps(E, "w_update");
           if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
           const int64_t c4 = mp * kp / 4;
@@ -715,7 +884,11 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
         { ProfScope ps(E, "gram_tn");
           if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->WThi, E->WTlo, mp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");                   // B = W^T V
-          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8))) return rc; }
+          if (gxt_on()) {
+              if ((rc = gxt_retile(E, E->WThi, kp, mp, E->gxt_f[2], true)) || (rc = gxt_retile(E, E->WTlo, kp, mp, E->gxt_f[3], true))) return rc;
+              rc = gxt_split_product(E, E->gxt_f[2], E->gxt_f[3], E->gxt_v[2], E->gxt_v[3], xB, kp, np, mp, 8);
+          } else rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8);
+          if (rc) return rc; }
         return NMFX_OK;
     }
     if (!kl) {
