@@ -227,8 +227,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
                     E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work,
-                    E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1],
-                    E->gxt_v[0], E->gxt_v[1], E->gxt_v[2], E->gxt_v[3], E->gxt_f[0], E->gxt_f[1], E->gxt_f[2], E->gxt_f[3]};
+                    E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -307,7 +306,6 @@ int nmfx_upload_v(nmfx_handle_t E, const void* host, int dtype, int64_t ld, int6
     E->bf_ready = false;
     E->gxb_v_ready = false;
     E->gxb_vt_ready = false;
-    E->gxt_v_ready = false;
     return NMFX_OK;
 }
 
@@ -337,7 +335,6 @@ int nmfx_upload_v_device(nmfx_handle_t E, const void* dev, int dtype, int64_t ld
     E->bf_ready = false;
     E->gxb_v_ready = false;
     E->gxb_vt_ready = false;
-    E->gxt_v_ready = false;
     return NMFX_OK;
 }
 

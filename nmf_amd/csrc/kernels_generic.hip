@@ -542,7 +542,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // two adjacent lanes hold adjacent columns: the even lane stores the pair of the hi plane, the odd lane the pair
                     // of the lo plane -- one 4-byte store per lane instead of two 2-byte stores
                     const unsigned other = (unsigned)__shfl_xor((int)((n31 & 1) ? hi : lo), 1, 64);
-                    const int64_t at = (i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + (n31 & ~1);
+                    // (the planes in the TILED image of gxt_gemm_kernel, contraction along the columns: row I, columns J, J + 1)
+                    const int64_t I = i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b, J = j0 + wc + 32 * tj + (n31 & ~1);
+                    const int rr = (int)(I & 127);
+                    const int64_t at = ((I >> 7) * (ldc / 32) + (J >> 5)) * 4096 + rr * 32 + 8 * ((int)((J & 31) >> 3) ^ ((rr >> 2) & 3)) + (J & 7);
                     if (n31 & 1) *reinterpret_cast<unsigned*>(Qlo + at) = (other & 0xffffu) | (lo << 16);
                     else *reinterpret_cast<unsigned*>(Qhi + at) = (hi & 0xffffu) | (other << 16);
                     d2 = 0.f;
@@ -591,28 +594,7 @@ int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsign
     return NMFX_OK;
 }
 
-// split of the contraction that fills the CUs about twice: S divides K / 64
-int gxb_split(const nmfx_engine* E, int64_t tiles, int64_t K, int cap) {
-    int64_t want = std::max<int64_t>(1, (2 * (int64_t)E->ncu + tiles - 1) / tiles);
-    want = std::min<int64_t>(want, cap);
-    const int64_t ch = K / GXB_KC;
-    while (want > 1 && ch % want) --want;
-    return (int)want;
-}
-
-// split-K product into the slab buffer gx_s, summed into `out`
-int gxb_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
-                      const unsigned short* Blo, int64_t ldb, float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3) {
-    int rc;
-    int S = gxb_split(E, (M / GX_T) * (N / GX_T), K, cap);
-    const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);   // gx_buffers: gx_s
-    while (S > 1 && ((int64_t)S * M * N > slab_cap || (K / GXB_KC) % S)) --S;
-    if (S == 1) return gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, out, N, 0, M, N, K, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, terms);
-    if ((rc = gxb_launch(E, GX_STORE, Ahi, Alo, lda, Bhi, Blo, ldb, E->gx_s, N, M * N, M, N, K, S, nullptr, 0, nullptr, nullptr, nullptr, nullptr, terms))) return rc;
-    return nmfx_launch_sum_partials(E, E->gx_s, S, M * N, out);
-}
-
-// ---- the V-sized products with a long contraction on TILED planes filled by LDS-DMA (r3, experiment: NMFX_GXT=1) -------------------
+// ---- the products with a long contraction (V H^T, W^T V, Q H^T, W^T Q', the Gram matrices) on TILED planes filled by LDS-DMA (r3) ------
 // gxb_gemm_kernel stages its operands through registers: per CU and chunk the ds_write_b128 path (~79 B/clk), the texture path and
 // the matrix pipe carry loads within 30 % of each other.  Here the planes are stored as TILES in the image the LDS wants --
 //     tile (row tile rt of 128, chunk c of 32) = 8 KiB contiguous at ((rt (K / 32) + c) 4096) elements:
@@ -720,26 +702,64 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
                 Cz[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + n31] = acc[ti][tj][r];
 }
 
-// row-major plane [R][K] (bf16) -> the tiled image above
-__global__ __launch_bounds__(256) void gxt_retile_kernel(const unsigned short* __restrict__ in, int64_t R, int64_t K, unsigned short* __restrict__ out,
-                                                         const int* __restrict__ flag)
+// bf16 hi / lo images of M [rows][cols] (f32, row-major) in the formats the product kernels read.  Natural orientation (operand rows =
+// rows of M, contraction along the columns) and transposed orientation (operand rows = columns of M, contraction along the rows),
+// each 0 = not wanted, 1 = row-major planes (gxb_gemm_kernel: the short contractions), 2 = the tiled image above (gxt_gemm_kernel).
+// One 64 x 64 tile per block through LDS; every global store is a 16-byte chunk of eight contraction indices.
+__global__ __launch_bounds__(256) void gxt_split_kernel(const float* __restrict__ M, int64_t rows, int64_t cols, int fmt_n,
+                                                        unsigned short* __restrict__ nhi, unsigned short* __restrict__ nlo, int fmt_t,
+                                                        unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, const int* __restrict__ flag)
 {
-    if (flag && *flag) return;
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk (8 k) per thread
-    if (id >= R * K / 8) return;
-    const int64_t r = id / (K / 8), k8 = id % (K / 8);
-    const int rr = (int)(r & 127), cc = (int)(k8 & 3);
-    const int64_t tile = (r >> 7) * (K / 32) + (k8 >> 2);
-    const uint4 v = *reinterpret_cast<const uint4*>(in + r * K + 8 * k8);
-    *reinterpret_cast<uint4*>(out + tile * 4096 + rr * 32 + 8 * (cc ^ ((rr >> 2) & 3))) = v;
+    if (flag && *flag) return;                         // (a stopped run keeps the images of the iterate it stopped at)
+    __shared__ __attribute__((aligned(16))) unsigned short sh[64][72], sl[64][72];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    for (int r = ty; r < 64; r += 4) {
+        const float v = M[(r0 + r) * cols + c0 + tx];
+        unsigned hi, lo;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v), "v"(0.f));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v - __uint_as_float(hi << 16)), "v"(0.f));
+        sh[r][tx] = (unsigned short)hi; sl[r][tx] = (unsigned short)lo;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, a = q >> 3, e8 = q & 7;
+        if (fmt_n) {                                   // row r0 + a, contraction indices c0 + 8 e8 ..
+            const uint4 h = *reinterpret_cast<const uint4*>(&sh[a][8 * e8]), l = *reinterpret_cast<const uint4*>(&sl[a][8 * e8]);
+            const int64_t R = r0 + a, Kc = c0 + 8 * e8;
+            int64_t at;
+            if (fmt_n == 1) at = R * cols + Kc;
+            else { const int rr = (int)(R & 127); at = ((R >> 7) * (cols / 32) + (Kc >> 5)) * 4096 + rr * 32 + 8 * ((int)((Kc & 31) >> 3) ^ ((rr >> 2) & 3)); }
+            *reinterpret_cast<uint4*>(nhi + at) = h; *reinterpret_cast<uint4*>(nlo + at) = l;
+        }
+        if (fmt_t) {                                   // operand row c0 + a (a column of M), contraction indices r0 + 8 e8 ..
+            union { unsigned short s[8]; uint4 u; } h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { h.s[e] = sh[8 * e8 + e][a]; l.s[e] = sl[8 * e8 + e][a]; }
+            const int64_t R = c0 + a, Kc = r0 + 8 * e8;
+            int64_t at;
+            if (fmt_t == 1) at = R * rows + Kc;
+            else { const int rr = (int)(R & 127); at = ((R >> 7) * (rows / 32) + (Kc >> 5)) * 4096 + rr * 32 + 8 * ((int)((Kc & 31) >> 3) ^ ((rr >> 2) & 3)); }
+            *reinterpret_cast<uint4*>(thi + at) = h.u; *reinterpret_cast<uint4*>(tlo + at) = l.u;
+        }
+    }
 }
 
-int gxt_retile(nmfx_engine* E, const unsigned short* in, int64_t R, int64_t K, unsigned short* out, bool check_flag) {
-    const int64_t n = R * K / 8;
-    hipLaunchKernelGGL(gxt_retile_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, E->stream, in, R, K, out,
-                       check_flag ? (const int*)&E->state->flag : (const int*)nullptr);
+int gxt_split(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int fmt_n, unsigned short* nhi, unsigned short* nlo, int fmt_t,
+              unsigned short* thi, unsigned short* tlo, bool check_flag) {
+    hipLaunchKernelGGL(gxt_split_kernel, dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, E->stream, M, rows, cols, fmt_n, nhi, nlo,
+                       fmt_t, thi, tlo, check_flag ? (const int*)&E->state->flag : (const int*)nullptr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+// the factor images of the composed path: W -> Whi / Wlo [mp][kp] row-major (short contractions: objective, quotient) and W^T tiled
+// (W^T V, W^T W); H -> tiled (V H^T, H H^T) and H^T [np][kp] row-major
+int gxb_images_w(nmfx_engine* E, const float* W) {
+    return gxt_split(E, W, E->mp, E->kp, 1, E->Whi[0], E->Wlo[0], 2, E->WThi, E->WTlo, true);
+}
+int gxb_images_h(nmfx_engine* E, const float* H) {
+    return gxt_split(E, H, E->kp, E->np, 2, E->Hhi, E->Hlo, 1, E->HThi, E->HTlo, true);
 }
 
 // split-K product on the tiled planes into the slab buffer gx_s, summed into `out` (M: rows of A, N: rows of B, K: contraction)
@@ -764,8 +784,6 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
     if (S == 1) return NMFX_OK;
     return nmfx_launch_sum_partials(E, E->gx_s, (int)S, M * N, out);
 }
-
-bool gxt_on() { static const bool on = getenv("NMFX_GXT") && atoi(getenv("NMFX_GXT")) == 1; return on; }
 
 // the split-bf16 products are the default for the Euclidean MUR loop beyond k = 128 (NMFX_PRECISION=f32 keeps the exact-f32 kernel)
 bool gxb_on(const nmfx_engine* E) { return E->precision == 1 && !E->gxb_disabled && E->mp % 128 == 0 && E->np % 128 == 0 && E->kp % 128 == 0; }
@@ -819,13 +837,12 @@ int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
         (rc = gx_alloc(E, &E->HThi, kp * np)) || (rc = gx_alloc(E, &E->HTlo, kp * np))) return rc;
     if (!E->gxb_v_ready) {
         ProfScope ps(E, "images");
-        if ((rc = nmfx_split_images(E, E->V, mp, np, np, E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3]))) return rc;
+        if ((rc = gxt_split(E, E->V, mp, np, 2, E->gxb_v[0], E->gxb_v[1], 2, E->gxb_v[2], E->gxb_v[3], false))) return rc;      // both TILED: V (contraction n), V^T (contraction m)
         E->gxb_v_ready = true;
     }
     if (!E->gxb_img_ready) {
         ProfScope ps(E, "images");
-        if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc;
-        if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
+        if ((rc = gxb_images_w(E, W)) || (rc = gxb_images_h(E, E->H))) return rc;
         E->gxb_img_ready = true;
     }
     return NMFX_OK;
@@ -856,23 +873,9 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
           if ((rc = gxb_launch(E, GX_RESID, E->Whi[0], E->Wlo[0], kp, E->HThi, E->HTlo, kp, nullptr, 0, 0, mp, np, kp, 1, E->V, np, E->gx_part))) return rc; }
         if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
         { ProfScope ps(E, "gram_nt");
-          if ((rc = gxb_split_product(E, E->Hhi, E->Hlo, np, E->Hhi, E->Hlo, np, E->HHt, kp, kp, np, 64))) return rc; }
-        if (gxt_on()) {                                // experiment: tiled planes + LDS-DMA product kernel for the two long contractions
-            for (int i = 0; i < 4; ++i) if ((rc = gx_alloc(E, &E->gxt_v[i], mp * np))) return rc;
-            if ((rc = gx_alloc(E, &E->gxt_f[0], kp * np)) || (rc = gx_alloc(E, &E->gxt_f[1], kp * np)) || (rc = gx_alloc(E, &E->gxt_f[2], mp * kp)) ||
-                (rc = gx_alloc(E, &E->gxt_f[3], mp * kp))) return rc;
-            ProfScope ps(E, "images");
-            if (!E->gxt_v_ready) {
-                if ((rc = gxt_retile(E, E->gxb_v[0], mp, np, E->gxt_v[0], false)) || (rc = gxt_retile(E, E->gxb_v[1], mp, np, E->gxt_v[1], false)) ||
-                    (rc = gxt_retile(E, E->gxb_v[2], np, mp, E->gxt_v[2], false)) || (rc = gxt_retile(E, E->gxb_v[3], np, mp, E->gxt_v[3], false))) return rc;
-                E->gxt_v_ready = true;
-            }
-            if ((rc = gxt_retile(E, E->Hhi, kp, np, E->gxt_f[0], true)) || (rc = gxt_retile(E, E->Hlo, kp, np, E->gxt_f[1], true))) return rc;
-        }
+          if ((rc = gxt_split_product(E, E->Hhi, E->Hlo, E->Hhi, E->Hlo, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");                   // A = V H^T
-          if (gxt_on()) rc = gxt_split_product(E, E->gxt_v[0], E->gxt_v[1], E->gxt_f[0], E->gxt_f[1], E->A_part, mp, kp, np, 4);
-          else rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4);
-          if (rc) return rc; }
+          if ((rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4))) return rc; }
         { ProfScope ps(E, "w_update");
           if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
           const int64_t c4 = mp * kp / 4;
@@ -880,15 +883,11 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
                              (const float*)E->gx_d, (float)lambda, Wn, c4, (const int*)&E->state->flag);
           NMFX_HIP(hipGetLastError()); }
         { ProfScope ps(E, "images");
-          if ((rc = nmfx_split_images(E, Wn, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+          if ((rc = gxb_images_w(E, Wn))) return rc; }
         { ProfScope ps(E, "gram_tn");
-          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->WThi, E->WTlo, mp, xG, kp, kp, mp, 64))) return rc; }
+          if ((rc = gxt_split_product(E, E->WThi, E->WTlo, E->WThi, E->WTlo, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");                   // B = W^T V
-          if (gxt_on()) {
-              if ((rc = gxt_retile(E, E->WThi, kp, mp, E->gxt_f[2], true)) || (rc = gxt_retile(E, E->WTlo, kp, mp, E->gxt_f[3], true))) return rc;
-              rc = gxt_split_product(E, E->gxt_f[2], E->gxt_f[3], E->gxt_v[2], E->gxt_v[3], xB, kp, np, mp, 8);
-          } else rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8);
-          if (rc) return rc; }
+          if ((rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8))) return rc; }
         return NMFX_OK;
     }
     if (!kl) {
@@ -920,7 +919,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
                                E->gxb_q[0], E->gxb_q[1]))) return rc; }
         if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
         { ProfScope ps(E, "wphase");                   // Q H^T
-          if ((rc = gxb_split_product(E, E->gxb_q[0], E->gxb_q[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4))) return rc; }
+          if ((rc = gxt_split_product(E, E->gxb_q[0], E->gxb_q[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4))) return rc; }
         { ProfScope ps(E, "w_update");
           hipLaunchKernelGGL(gx_rowsum_kernel, dim3((unsigned)kp), dim3(256), 0, E->stream, (const float*)E->H, np, E->HHt, (const int*)&E->state->flag);
           const int64_t cnt = mp * kp;
@@ -928,12 +927,12 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
                              (const float*)E->HHt, (float)lambda, Wn, mp, kp, E->k, (const int*)&E->state->flag);
           NMFX_HIP(hipGetLastError()); }
         { ProfScope ps(E, "images");
-          if ((rc = nmfx_split_images(E, Wn, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+          if ((rc = gxb_images_w(E, Wn))) return rc; }
         { ProfScope ps(E, "objective");                // Q'^T = V^T / (H^T W_new^T + 1e-9)  (the second quotient product of the iteration, no objective)
           if ((rc = gxb_launch(E, GX_KLQ, E->HThi, E->HTlo, kp, E->Whi[0], E->Wlo[0], kp, nullptr, mp, 0, np, mp, kp, 1, E->gxb_vt, mp, nullptr, nullptr,
                                E->gxb_q[0], E->gxb_q[1]))) return rc; }
         { ProfScope ps(E, "hphase");                   // B = W_new^T Q', d = W_new^T 1
-          if ((rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_q[0], E->gxb_q[1], mp, xB, kp, np, mp, 8))) return rc;
+          if ((rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_q[0], E->gxb_q[1], xB, kp, np, mp, 8))) return rc;
           const int rb = (int)(mp / 64);
           hipLaunchKernelGGL(gx_colsum_part_kernel, dim3((unsigned)rb), dim3(256), 0, E->stream, (const float*)Wn, kp, 64, E->gx_s, (const int*)&E->state->flag);
           NMFX_HIP(hipGetLastError());
@@ -981,14 +980,14 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
                            (const float*)E->gx_d, (float)lambda, E->H, c4, (const int*)&E->state->flag);
         NMFX_HIP(hipGetLastError());
         if (gxb_on(E) && E->gxb_img_ready &&           // (images of the new H for the next iteration's split-bf16 products)
-            (rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
+            (rc = gxb_images_h(E, E->H))) return rc;
     } else {
         const int64_t cnt = kp * np;
         hipLaunchKernelGGL((gx_kl_update_kernel<true>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->H, (const float*)xB,
                            (const float*)xS, (float)lambda, E->H, kp, np, E->k, (const int*)&E->state->flag);
         NMFX_HIP(hipGetLastError());
         if (gxb_on(E) && E->gxb_img_ready &&
-            (rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc;
+            (rc = gxb_images_h(E, E->H))) return rc;
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -1349,22 +1348,22 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
         { ProfScope ps(E, "gram_tn");
           if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");
-          if (bf) rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8);
+          if (bf) rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8);
           else rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8);
           if (rc) return rc; }
         if ((rc = gx_ao_subproblem(E, true, xG, xB, E->H, E->dualH, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2))) return rc;
         if (bf) { ProfScope ps(E, "images");
-                  if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc; }
+                  if ((rc = gxb_images_h(E, E->H))) return rc; }
         // W sub-problem on the transposed data: G = H H^T, B^T = V H^T
         { ProfScope ps(E, "gram_nt");
           if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");
-          if (bf) rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4);
+          if (bf) rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4);
           else rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1);
           if (rc) return rc; }
         if ((rc = gx_ao_subproblem(E, false, E->HHt, E->A_part, W, E->dualW, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
         if (bf) { ProfScope ps(E, "images");
-                  if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc; }
+                  if ((rc = gxb_images_w(E, W))) return rc; }
         if ((rc = gx_objective_partial(E, bf))) return rc;
     }
     return NMFX_OK;
@@ -1541,8 +1540,8 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
           if ((rc = gx_split_product<false, false>(E, E->auxW, kp, E->auxW, kp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");
           if (bf) {
-              if ((rc = nmfx_split_images(E, E->auxW, mp, kp, kp, E->Whi[0], E->Wlo[0], E->WThi, E->WTlo))) return rc;
-              rc = gxb_split_product(E, E->WThi, E->WTlo, mp, E->gxb_v[2], E->gxb_v[3], mp, xB, kp, np, mp, 8, 4);
+              if ((rc = gxb_images_w(E, E->auxW))) return rc;
+              rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8, 4);
           } else rc = gx_split_product<false, false>(E, E->auxW, kp, data, np, xB, kp, np, mp, 8);
           if (rc) return rc; }
         if ((rc = gx_prepare(E, xG, rho))) return rc;
@@ -1557,8 +1556,8 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
           if ((rc = gx_split_product<true, true>(E, E->auxH, np, E->auxH, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");
           if (bf) {
-              if ((rc = nmfx_split_images(E, E->auxH, kp, np, np, E->Hhi, E->Hlo, nullptr, nullptr))) return rc;
-              rc = gxb_split_product(E, E->gxb_v[0], E->gxb_v[1], np, E->Hhi, E->Hlo, np, E->A_part, mp, kp, np, 4, 4);
+              if ((rc = gxb_images_h(E, E->auxH))) return rc;
+              rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 4);
           } else rc = gx_split_product<true, true>(E, data, np, E->auxH, np, E->A_part, mp, kp, np, 1);
           if (rc) return rc; }
         if ((rc = gx_prepare(E, E->HHt, rho))) return rc;
@@ -1576,8 +1575,8 @@ int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, 
             if ((rc = gx_launch<true, false>(E, GX_VAUX, E->auxW, kp, E->auxH, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, nullptr, E->S))) return rc;
         }
         if (bf) { ProfScope ps(E, "images");          // images of the new (w, h) for the objective
-                  if ((rc = nmfx_split_images(E, W, mp, kp, kp, E->Whi[0], E->Wlo[0], nullptr, nullptr))) return rc;
-                  if ((rc = nmfx_split_images(E, E->H, kp, np, np, E->Hhi, E->Hlo, E->HThi, E->HTlo))) return rc; }
+                  if ((rc = gxb_images_w(E, W))) return rc;
+                  if ((rc = gxb_images_h(E, E->H))) return rc; }
         if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;
     }
     (void)flag;

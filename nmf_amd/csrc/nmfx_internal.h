@@ -96,12 +96,9 @@ struct nmfx_engine {
     double* gx_w64 = nullptr;      // ... the f64 work matrix of the Gauss-Jordan inversion
     double* gx_nrm = nullptr;      // ... norm partials of a round
     double* gx_nnls_work = nullptr; int64_t gx_nnls_cap = 0;   // ANLS for k > 128: per-block f64 systems of the passive-set solves
-    // k > 128, split-bf16 products (kernels_generic.hip, gxb_*): bf16 hi / lo planes of V [mp][np] and of V^T [np][mp]
+    // k > 128, split-bf16 products (kernels_generic.hip, gxb_* / gxt_*): bf16 hi / lo planes of V (rows m) and of V^T (rows n), TILED for the LDS-DMA kernel
     unsigned short* gxb_v[4] = {nullptr, nullptr, nullptr, nullptr};
     bool gxb_v_ready = false;      // the planes are those of the current V
-    unsigned short* gxt_v[4] = {nullptr, nullptr, nullptr, nullptr};   // the V / V^T planes once more, TILED for the LDS-DMA product kernel (gxt_*)
-    unsigned short* gxt_f[4] = {nullptr, nullptr, nullptr, nullptr};   // tiled images of H (hi, lo) and of W^T (hi, lo)
-    bool gxt_v_ready = false;
     bool gxb_disabled = false;     // the planes did not fit beside V: this handle keeps the exact-f32 product kernel beyond k = 128 (noted)
     float* gxb_vt = nullptr;       // MUR-KL beyond k = 128: V^T [np][mp] in f32 (the quotient of the H side is formed transposed)
     bool gxb_vt_ready = false;
