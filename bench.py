@@ -484,8 +484,9 @@ def other_configs(torch, dev, only=None):
              m=16384, n=8192, k=64, steps=20, warmup=3, init="randn", precision="f32", bound="mfma",
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
              flops=4.0 * 16384 * 8192 * 64 + 4.0 * 64 * 64 * (16384 + 8192), nbytes=2.0 * 16384 * 8192 * 4 + 3.0 * (16384 + 8192) * 64 * 4),
-        # beyond 128 components (nmf/nmf.py:32-35 takes any `factors`): the iteration composed from one split-bf16 NT product kernel
-        # over operand planes (kernels_generic.hip, gxb_*; r3 -- the exact-f32 form of the same composition is the leg after it)
+        # beyond 128 components (nmf/nmf.py:32-35 takes any `factors`): the iteration composed from split-bf16 NT product kernels over
+        # operand planes (kernels_generic.hip: gxt_* on tiled planes filled by LDS-DMA for the long contractions, gxb_* for the short
+        # ones; r3 -- the exact-f32 form of the same composition is the leg after it)
         dict(name="mur_k256_on_cfg2_shape", workload="MUR Euclidean, V=16384x8192 f32, k=256 (composed path for k > 128, split-bf16 products)",
              m=16384, n=8192, k=256, steps=10, warmup=2, init="randn", bound="mfma_bf16x3",
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),

@@ -1403,9 +1403,8 @@ int nmfx_need_v(nmfx_engine* E) {
 __global__ __launch_bounds__(256) void split_images_kernel(
     const float* __restrict__ M, int64_t rows, int64_t cols, int64_t ld,
     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, const int* __restrict__ flag = nullptr)
+    unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo)
 {
-    if (flag && *flag) return;                         // (a stopped run keeps the images of the iterate it stopped at)
     __shared__ unsigned short sh[64][66], sl[64][66];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
@@ -2116,16 +2115,6 @@ int nmfx_bf16_prepare(nmfx_engine* E) {
     E->bf_ready = true;
     if ((rc = nmfx_bf16_images_w(E, E->W[E->wsel], E->wsel))) return rc;
     return nmfx_bf16_images_h(E, false);
-}
-
-// bf16 hi / lo images of any row-major matrix (and of its transpose): the factor images and the V planes of the k > 128
-// split-bf16 products (kernels_generic.hip)
-int nmfx_split_images(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int64_t ld, unsigned short* hi, unsigned short* lo,
-                      unsigned short* thi, unsigned short* tlo) {
-    hipLaunchKernelGGL(split_images_kernel, dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, E->stream,
-                       M, rows, cols, ld, hi, lo, thi, tlo, (const int*)&E->state->flag);
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
 }
 
 // ---- building blocks shared by the solvers (kp = 64 or 128); results land where the exact-f32

@@ -405,7 +405,9 @@ int gx_split_product(nmfx_engine* E, const float* A, int64_t lda, const float* B
 //   V H^T                         :  A = V planes [mp][np],   B = H images [kp][np]
 //   W^T V   ([kp][np])            :  A = W^T images [kp][mp], B = V^T planes [np][mp]
 //   H H^T, W^T W                  :  A = B = H images / W^T images
-// (V planes: built once per upload; factor images: rebuilt by split_images_kernel after each update, both layouts in one launch.)
+// (V planes: built once per upload; factor images: rebuilt by gxt_split_kernel after each update, both orientations in one launch.)
+// Since the later part of r3 this kernel carries the SHORT contractions only (objective, KL quotient: contraction over the factor index,
+// row-major images of W and H^T); every product with a long contraction runs on gxt_gemm_kernel further down, on tiled planes.
 // Block = 128 x 128 outputs, 4 waves x (2 x 2 tiles of 32 x 32), contraction in chunks of 64: four planes [128 rows][64 bf16] in
 // LDS with a row stride of 144 bytes -- an odd multiple of 16, so the 16 rows of a ds_read_b128 lane group (MI355X_MICROARCH.md,
 // LDS table) fall on 16 distinct bank quadruples, and the 8 lanes of a ds_write_b128 group write one contiguous row --, the
@@ -571,19 +573,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
                const unsigned short* Blo, int64_t ldb, float* C, int64_t ldc, int64_t cstride, int64_t M, int64_t N, int64_t K, int S,
-               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr,
-               int terms = 3) {
-    if (M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape"; return NMFX_E_ARG; }
+               const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr) {
+    // (GX_RESID / GX_KLQ only: the long contractions -- every GX_STORE product -- run on gxt_gemm_kernel below)
+    if (mode == GX_STORE || M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape / mode"; return NMFX_E_ARG; }
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
     int rc;
-    if (mode == GX_STORE && terms == 4) {
-        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE, 4>), GXB_SHM))) return rc;
-        hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE, 4>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
-    } else if (mode == GX_STORE) {
-        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_STORE>), GXB_SHM))) return rc;
-        hipLaunchKernelGGL((gxb_gemm_kernel<GX_STORE>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2);
-    } else if (mode == GX_KLQ) {                       // (ldc = the row stride of the Q planes)
+    if (mode == GX_KLQ) {                              // (ldc = the contraction length of the product that consumes the Q planes)
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxb_gemm_kernel<GX_KLQ>), GXB_SHM))) return rc;
         hipLaunchKernelGGL((gxb_gemm_kernel<GX_KLQ>), grid, block, GXB_SHM, E->stream, Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, cstride, K, X, ldx, part, flag, flag2, Qhi, Qlo);
     } else {
@@ -596,13 +592,18 @@ int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsign
 
 // ---- the products with a long contraction (V H^T, W^T V, Q H^T, W^T Q', the Gram matrices) on TILED planes filled by LDS-DMA (r3) ------
 // gxb_gemm_kernel stages its operands through registers: per CU and chunk the ds_write_b128 path (~79 B/clk), the texture path and
-// the matrix pipe carry loads within 30 % of each other.  Here the planes are stored as TILES in the image the LDS wants --
+// the matrix pipe carry loads within 30 % of each other (matrix pipe 0.47 busy, V H^T 217 us at 16384 x 8192, k = 256).  Here the planes
+// are stored as TILES in the image the LDS wants --
 //     tile (row tile rt of 128, chunk c of 32) = 8 KiB contiguous at ((rt (K / 32) + c) 4096) elements:
 //     element (row rr, k) at rr 32 + 8 ((k / 8) ^ ((rr >> 2) & 3)) + k % 8
 // (the 16 rows of a ds_read_b128 lane group then fall on 16 distinct bank quadruples: 4 (rr & 3) + (chunk ^ (rr >> 2 & 3))) -- so a
 // stage is filled by plain linear copies global -> LDS (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs, no
 // ds_write), three stages of a 256 x 128 block tile (48 KiB each: two chunks in flight), eight waves x (2 x 2 tiles of 32 x 32), one
-// barrier per chunk, counted vmcnt.  C[M][N] = sum_t A[i][t] B[j][t], STORE only.
+// barrier per chunk, counted vmcnt; 98 VGPRs.  C[M][N] = sum_t A[i][t] B[j][t], stored (V H^T 175-181 us on the same boxes = 1.2 PFLOP/s
+// of executed bf16 MFMA work = 0.48 of the dense peak).  The short contractions stay on gxb_gemm_kernel: built on this kernel too
+// (X tile requested in front of the first chunk, one 256 x 128 tile per block) they were no faster -- eight chunks per block do not
+// amortise the head of the DMA ring with one block per CU, and register loads of the next tile's X cannot ride in the same
+// in-order vmcnt queue as the DMA stream without serialising with it.
 __device__ __forceinline__ unsigned gxt_lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ void gxt_dma(unsigned long long base, unsigned dst, unsigned voff) {
     unsigned keep;

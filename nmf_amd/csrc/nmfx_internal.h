@@ -202,8 +202,6 @@ inline int nmfx_bf16_hht_slabs(const nmfx_engine* E) { return E->gram_ng_w * E->
 inline int nmfx_bf16_g_slabs(const nmfx_engine* E) { return E->gram_ng_h * E->bt_split; }      // W^T W by-product slabs
 int nmfx_bf16_prepare(nmfx_engine* E);
 int nmfx_bf16_images_w(nmfx_engine* E, const float* W, int buf);
-int nmfx_split_images(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int64_t ld, unsigned short* hi, unsigned short* lo,
-                      unsigned short* thi, unsigned short* tlo);   // bf16 hi / lo images of M [rows][cols] (and of its transpose, optional)
 int nmfx_bf16_images_h(nmfx_engine* E, bool transposed, const float* src = nullptr);
 int nmfx_mur_eu_phase_a_head_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_a_cols_bf16(nmfx_engine* E, int64_t c0, int64_t c1);
