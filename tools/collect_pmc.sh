@@ -29,9 +29,9 @@ for f in sorted(glob.glob(out + "/*.csv")):
     probe = os.path.basename(f).split("_")[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k and "gxb_gemm_kernel" not in k:
+        if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k and "gxb_gemm_kernel" not in k and "gxt_gemm_kernel" not in k:
             continue
-        short = k.split("(")[0].replace("void ", "")
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         acc[probe + ": " + short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
