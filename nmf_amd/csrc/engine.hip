@@ -66,7 +66,7 @@ __global__ void cvt_f64_rows_kernel(const double* __restrict__ src, int64_t lds,
 
 __global__ void init_state_kernel(DevState* st) {
     st->flag = 0; st->stop_i = -1; st->n_obj = 0; st->obj_prev = 0.0;
-    st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->rho = 0.0; st->j_base = 0;
+    st->inner_stop = 0; st->inner_count = 0; st->notpd = 0; st->notpd_pending = 0; st->rho = 0.0; st->j_base = 0;
     st->nnls_evicted = 0; st->nnls_capped = 0; st->nnls_fallback = 0; st->nnls_noinv = 0;
     for (int i = 0; i < 4; ++i) { st->ao_hint[i >> 1][i & 1] = 0; st->ao_paths[i] = 0; }
     st->ao_continued = 0;
@@ -182,7 +182,8 @@ int nmfx_create(nmfx_handle_t* out, int device, int64_t m, int64_t n, int k) {
     TRY(dev_alloc(E, &E->G_part, std::max<int64_t>(std::max(gs, hs), 4 * std::max<int64_t>(hs, (int64_t)ncu) + 8) * kp * kp));
     TRY(dev_alloc(E, &E->A_part, ws * mp * kp));
     TRY(dev_alloc(E, &E->B_part, hs * kp * np));
-    TRY(dev_alloc(E, &E->obj_part, 2 * (std::max<int64_t>(rb * ws, cb * hs) + 64)));      // (x 2: pair mode keeps two partials per block)
+    E->obj_part_cap = 2 * (std::max<int64_t>(rb * ws, cb * hs) + 64) + 2 * (int64_t)ncu;      // (+ 2 ncu: the segments of a stream-K plan, at most workers + row blocks)
+    TRY(dev_alloc(E, &E->obj_part, E->obj_part_cap));      // (x 2: pair mode keeps two partials per block)
     TRY(dev_alloc(E, &E->xf32, kp * np + kp * kp + kp + NMFX_XTAIL));
     TRY(dev_alloc(E, &E->xf64, 8 + 4 * NMFX_MAX_FUSED_ROUNDS));
     TRY(dev_alloc(E, &E->state, 1));
@@ -227,7 +228,8 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->inner_hist, E->Pw, E->Ph, E->Asum, E->S, E->DV, E->Vt, E->Vtile, E->Bt_part, E->Whi[0], E->Whi[1],
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
                     E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work,
-                    E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1]};
+                    E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1],
+                    E->sk[0].seg, E->sk[0].first, E->sk[0].cnt, E->sk[0].slabs, E->sk[1].seg, E->sk[1].first, E->sk[1].cnt, E->sk[1].slabs};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -718,10 +720,15 @@ int nmfx_profile_get(nmfx_handle_t E, const char* name, double* total_ms, int64_
 // every launch, which costs the W phase ~10 us that no real iteration pays.
 int nmfx_profile_repeat(nmfx_handle_t E, const char* which, int distance, int reps, double* ms_per_launch) {
     if (!E || !which || reps <= 0 || !ms_per_launch) return NMFX_E_ARG;
-    int rc = check_ready(E, 0, 0); if (rc) return rc;
     const std::string w(which);
+    int rc = check_ready(E, 0, 0, !(w.rfind("ao_", 0) == 0 || w.rfind("sk_", 0) == 0)); if (rc) return rc;
     const bool wph = w == "wphase";
-    if (!wph && w != "hphase") { E->err = "profile_repeat: which must be wphase or hphase"; return NMFX_E_ARG; }
+    // r4, the two V-sized products of AO-ADMM at k padded to 128 (after at least one nmfx_aoadmm_run on the handle, so that the images
+    // and Gram slabs exist): "ao_hphase" / "ao_wphase" = the (row block) x (split) launches, "sk_hphase" / "sk_wphase" = the stream-K
+    // form without a side job, "..._side" = with the inversion of the Gram slabs beside it
+    const bool ao = w.rfind("ao_", 0) == 0 || w.rfind("sk_", 0) == 0;
+    if (ao && !(E->precision == 1 && E->kp == 128 && E->bf_ready && E->HThi)) { E->err = "profile_repeat: AO-ADMM products need a split-bf16 k = 128 run first"; return NMFX_E_STATE; }
+    if (!ao && !wph && w != "hphase") { E->err = "profile_repeat: which must be wphase or hphase"; return NMFX_E_ARG; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown distance type."; return NMFX_E_ARG; }
     const bool bf = E->precision == 1 && nmfx_bf16_supported(E);
     const bool kl = distance == NMFX_KL;
@@ -743,7 +750,13 @@ int nmfx_profile_repeat(nmfx_handle_t E, const char* which, int distance, int re
 #ifdef NMFX_EXP_REVERSE
         nmfx_debug_set_reverse(E->stream, altrev ? (i & 1) : 0);          // (the setter launch is there in both variants)
 #endif
-        if (bf) rc = wph ? nmfx_bf16_vht(E, true, E->wsel, "wphase", kl, 3) : nmfx_bf16_vtw(E, false, "hphase", kl, 3);
+        if (ao) {
+            const bool side = w.find("_side") != std::string::npos, hside = w.find("hphase") != std::string::npos;
+            if (w.rfind("ao_", 0) == 0) rc = hside ? nmfx_bf16_vtw(E, true, "hphase", false, 3) : nmfx_bf16_vht(E, false, 0, "wphase_noobj", false, 3);
+            else rc = nmfx_bf16_sk_product(E, hside ? 0 : 1, hside, side ? (hside ? E->G_part : E->HHt_part) : nullptr, hside ? 64 : 32, -1.0,
+                                           hside ? "hphase" : "wphase_noobj");
+        }
+        else if (bf) rc = wph ? nmfx_bf16_vht(E, true, E->wsel, "wphase", kl, 3) : nmfx_bf16_vtw(E, false, "hphase", kl, 3);
         else if (kl) { E->err = "profile_repeat: KL only in the split-bf16 mode"; rc = NMFX_E_ARG; }
         else rc = wph ? nmfx_launch_wphase(E, E->W[E->wsel], true, true) : nmfx_launch_hphase(E, E->W[E->wsel], nmfx_hphase_can_fuse_gram(E));
     }

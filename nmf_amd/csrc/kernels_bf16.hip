@@ -17,6 +17,7 @@
 // and the small update kernels emit the bf16 hi/lo images of the factors they have just
 // produced (W: [m][64] for the residual and [64][m] for the H phase; H: [64][n]).
 #include "nmfx_internal.h"
+#include "prepare_body.h"
 #include "kernels_small.h"
 #include <cstdlib>
 #include <type_traits>
@@ -614,16 +615,30 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 // at 4096 rows, 122 -> 134 (worse) at 8192.  Chosen per launch from the size of the two copies (nmfx_bf16_temporal).
 // WITH_A = false (with WITH_OBJ, Euclidean): only the residual objective of (Z, Y) -- no A-product, no exchange, nothing stored but
 // the objective partials (the closing objective of a run, ADMM's objective of (w, h), ANLS's un-fused objective).
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true, int NW = 8>
+// SK = true (r4; Euclidean products at k padded to 128 -- AO-ADMM's two V-sized products): a STREAM-K partition instead of the
+// (row block) x (split) grid.  The (row block, group) units of the product, row block major, are dealt to `sk_workers` workgroups in
+// contiguous runs of (nearly) equal length; a run that crosses a row block boundary is two SEGMENTS (seg[]: row block, first group,
+// end group, slab), each with its own accumulators, epilogue and slab -- a static plan (nmfx_sk_plan), so the sums stay in a fixed
+// order.  What it buys: the number of workers is free, and with one CU left over the grid carries a SIDE JOB in block `sk_workers`:
+// the one-workgroup f64 inversion of the sub-problem's shifted Gram matrix (ao_prepare_body), which otherwise is a launch of its
+// own -- 38 us twice per outer iteration of config 3 with 255 CUs idle, since nothing fits on a CU beside a block of this kernel.
+// (Two streams were measured first, tools/lab/overlap_probe.hip: workgroups are bound to an (XCC, SE) slot round-robin at dispatch,
+// so a second dispatch's single workgroup waits for ITS slot even with other CUs idle, and the fork / join events cost 15 us.)
+struct XytSide {                 // the side job: Minv = (sum of gslabs slabs of gsrc + rho I)^-1, rho = trace / k (fixed_rho < 0) -- nmf/ao_admm.py:53-55
+    const float* gsrc; int gslabs; int k; float* Minv; DevState* st; double fixed_rho;
+};
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true, int NW = 8, bool SK = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
-    int ngroups, const int* __restrict__ flag, int ng)
+    int ngroups, const int* __restrict__ flag, int ng,
+    const int4* __restrict__ sk_seg = nullptr, const int* __restrict__ sk_first = nullptr, int sk_workers = 0, XytSide side = XytSide())
 {
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
+    static_assert(!SK || (KP == 128 && !KL && NPROB == 1 && NW == 8 && WITH_A && ABL == 0), "stream-K: the Euclidean k = 128 products");
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
@@ -642,10 +657,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const int rg = wave & (NRG - 1), hh = wave / NRG;  // compute role: row group, column half
     const int n31 = lane & 31, b = lane >> 5;          // 32x32x16 coordinates
     const int x = lane & 15, g = lane >> 4;            // 16x16x32 coordinates (Gram by-product)
-    const int S = gridDim.y, sp = blockIdx.y;
-    const int g0 = (int)((int64_t)ngroups * sp / S);
-    const int g1 = (int)((int64_t)ngroups * (sp + 1) / S);
-    const int64_t r0 = (int64_t)blockIdx.x * (32 * NRG) + rg * 32;
+#ifdef NMFX_EXP_BLOCKTIME
+    if (SK && threadIdx.x == 0 && blockIdx.x < 1024) nmfx_dbg_times[WITH_OBJ][0][blockIdx.x] = wall_clock64();
+#endif
+    if constexpr (SK) {
+        if ((int)blockIdx.x == sk_workers) {           // the side job (see above); its LDS use (72 KiB at KP = 128) is inside this kernel's
+            ao_prepare_body<KP, false>(reinterpret_cast<double*>(smem), side.gsrc, side.gslabs, side.k, side.Minv, side.st,
+                                       side.fixed_rho, true);
+#ifdef NMFX_EXP_BLOCKTIME
+            if (threadIdx.x == 0 && blockIdx.x < 1024) nmfx_dbg_times[WITH_OBJ][1][blockIdx.x] = wall_clock64();
+#endif
+            return;
+        }
+    }
+    int seg_lo = 0, seg_hi = 1;
+    if constexpr (SK) {
+        seg_lo = __builtin_amdgcn_readfirstlane(sk_first[blockIdx.x]);
+        seg_hi = __builtin_amdgcn_readfirstlane(sk_first[blockIdx.x + 1]);
+    }
+    // (the body below is one segment; not re-indented)
+#pragma nounroll
+    for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    const int S = gridDim.y;
+    int bx_ = blockIdx.x, sp_ = blockIdx.y;
+    int g0_ = (int)((int64_t)ngroups * sp_ / S), g1_ = (int)((int64_t)ngroups * (sp_ + 1) / S);
+    if constexpr (SK) {
+        const int4 pl = sk_seg[seg];
+        bx_ = __builtin_amdgcn_readfirstlane(pl.x); g0_ = __builtin_amdgcn_readfirstlane(pl.y);
+        g1_ = __builtin_amdgcn_readfirstlane(pl.z); sp_ = __builtin_amdgcn_readfirstlane(pl.w);
+    }
+    // SK: the segment's groups are visited CYCLICALLY from group sk_start (slab | start << 8 in the plan): every worker is then at a
+    // group index congruent to its own clock modulo the common run length, i.e. the whole grid reads the same few Y tiles at the same
+    // time, as the (row block) x (split) grid does by construction -- with plain runs the workers' group indices drift apart and all
+    // of Y (4 / 8 MiB at config 3) cycles through every XCD's L2: +16 / +11 us on the two products
+    const int sk_start = SK ? (sp_ >> 8) : 0;
+    if constexpr (SK) sp_ &= 255;
+    const int bx = bx_, sp = sp_, g0 = g0_, g1 = g1_;
+    const int64_t oidx = SK ? (int64_t)seg : (int64_t)blockIdx.y * gridDim.x + blockIdx.x;     // objective partial of this segment
+    const int64_t r0 = (int64_t)bx * (32 * NRG) + rg * 32;
 
     // ---- DMA plan (roles by wave as in xyt_bf16_kernel: homogeneous vmcnt queues) ----
     //   waves 4..7: 4 of the 16 pieces (8 rows x 128 B) of the Y tiles of group grp + 1
@@ -659,7 +708,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #else
     constexpr bool rev = false;
 #endif
-    const int gfirst = rev ? g1 - 1 : g0;
+    const int gfirst = SK ? sk_start : rev ? g1 - 1 : g0;
+    int y_left = g1 - gfirst, v_left = g1 - gfirst;     // (SK) requests until the wrap back to group g0
+    const long long span_y = (long long)(g1 - g0) * 128ll, span_v = (long long)(g1 - g0) * 32768ll;
     const long long ystep = rev ? -128ll : 128ll, vstep = rev ? -32768ll : 32768ll;
     unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)gfirst * 128ull;
     unsigned yoffs[YPW];
@@ -670,8 +721,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     }
     const unsigned ydst = (unsigned)(ytile * YT + p0 * 1024);
     // X is tile-major: [R/128][ldx/64] tiles of [128 rows][64 cols], 32 KiB contiguous each
-    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)(blockIdx.x / (4 / NRG)) * (ldx / 64) + gfirst) * 32768ull;
-    unsigned long long vbaseA = tile0 + (unsigned long long)((blockIdx.x % (4 / NRG)) * NRG + lw) * 32 * 256, vbaseB = vbaseA + 16 * 256;
+    const unsigned long long tile0 = (unsigned long long)X + ((unsigned long long)(bx / (4 / NRG)) * (ldx / 64) + gfirst) * 32768ull;
+    unsigned long long vbaseA = tile0 + (unsigned long long)((bx % (4 / NRG)) * NRG + lw) * 32 * 256, vbaseB = vbaseA + 16 * 256;
     unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }   // rows 4t+g (< 16): row & 15 = row
@@ -683,6 +734,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         for (int i = 0; i < YPW; i += 4)
             dma_run4(ybase, smem0 + yq * YBUF + ydst + i * 1024, yoffs[i], yoffs[i + 1], yoffs[i + 2], yoffs[i + 3]);
         ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1;
+        if (SK && --y_left == 0) ybase -= span_y;
     };
     auto dma_step = [&](int st) {                      // a quarter (V loaders) / half (Y loaders, stages 0 and 1) of a group's requests
         if (yrole) {
@@ -697,6 +749,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1);
+        if (SK && --v_left == 0) { vbaseA -= span_v; vbaseB -= span_v; }
     };
 
     // ---- loop-invariant LDS read offsets ----
@@ -728,7 +781,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[t][r] = 0.f;
-    const bool do_gram = KP == 64 && !KL && WITH_A && (int)blockIdx.x < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
+    const bool do_gram = KP == 64 && !KL && WITH_A && bx < ng;  // Gram by-product: as in xyt_bf16_kernel (16x16x32 tiles)
     constexpr int NGT = 16 / NW;                       // Gram tiles (16 x 16) per wave: tile row git, tile columns gj0 .. gj0 + NGT - 1
     const int git = wave / (4 / NGT), gj0 = NGT * (wave % (4 / NGT));
     f32x4 gacc[NGT];
@@ -934,7 +987,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 }
             }
             NMFX_FENCE();
-            if (st == NA - 1 && do_gram && ((grp - g0) % ng) == (int)blockIdx.x) {
+            if (st == NA - 1 && do_gram && ((grp - g0) % ng) == bx) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const unsigned char* ys = ybuf + ylane[s];
@@ -1319,7 +1372,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         }
     }
     if (do_gram) {
-        float* go = gram_part + ((int64_t)blockIdx.x * S + sp) * KP * KP;
+        float* go = gram_part + ((int64_t)bx * S + sp) * KP * KP;
 #pragma unroll
         for (int c = 0; c < NGT; ++c)
 #pragma unroll
@@ -1335,7 +1388,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < NW; ++w) t += red[w];
-            objpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (KL ? 1.0 : 0.5) * t;
+            objpart[oidx] = (KL ? 1.0 : 0.5) * t;
         }
         if (NPROB == 2) {
 #pragma unroll
@@ -1349,6 +1402,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
             }
         }
     }
+    if constexpr (SK) __syncthreads();                  // the exchange slots and `red` are read out before the next segment's tiles land
+    }   // segments
+#ifdef NMFX_EXP_BLOCKTIME
+    if (SK && threadIdx.x == 0 && blockIdx.x < 1024) nmfx_dbg_times[WITH_OBJ][1][blockIdx.x] = wall_clock64();
+#endif
 }
 #pragma clang fp contract(off)
 
@@ -1927,7 +1985,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
                                                              : xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
             int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
             hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                               gram_part, R, ngroups, &E->state->flag, ng);
+                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide());
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
         }
@@ -1968,7 +2026,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
 #endif
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                       gram_part, R, ngroups, &E->state->flag, ng);
+                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide());
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2167,11 +2225,14 @@ int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl, int terms
 }
 
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
+// r4 (behind a stream-K product): bcnt = slabs per 128-column block of B^T (bsplit = the slab stride's count is then unused),
+// Gpart = nullptr (the side job has summed the Gram slabs itself), st != nullptr: the objective is recorded as obj[j] here
 template <int KP>
 __global__ __launch_bounds__(256) void pack_t_kernel(
     const float* __restrict__ Btpart, int bsplit, int64_t np, const float* __restrict__ Gpart, int gsplit,
     const double* __restrict__ objpart, int64_t nobj, float* __restrict__ xf32, double* __restrict__ xf64,
-    const int* __restrict__ flag)
+    const int* __restrict__ flag, const int* __restrict__ bcnt = nullptr, DevState* __restrict__ st = nullptr,
+    double* __restrict__ obj_hist = nullptr, long long j = 0, long long min_iter = 0, double tol1 = 0.0, double tol2 = 0.0)
 {
     if (*flag) return;
     __shared__ float tile[64][KP + 1];
@@ -2184,6 +2245,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
         float v[NE][4];
 #pragma unroll
         for (int u = 0; u < NE; ++u) { v[u][0] = 0.f; v[u][1] = 0.f; v[u][2] = 0.f; v[u][3] = 0.f; }
+        if (bcnt) bsplit = bcnt[c0 >> 7];
         for (int p = 0; p < bsplit; ++p) {             // (slab order per element, as before)
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
@@ -2199,6 +2261,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
         __syncthreads();
         for (int e = tid; e < KP * 64; e += 256) xf32[(int64_t)(e >> 6) * np + c0 + (e & 63)] = tile[e & 63][e >> 6];
     } else if (b < nbb + KP * KP / 256) {
+        if (!Gpart) return;
         const int64_t i = (int64_t)(b - nbb) * 256 + tid;
         float s2 = 0.f;
         int p = 0;
@@ -2218,8 +2281,129 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
         if ((tid & 63) == 0) sh[tid >> 6] = t;
         __syncthreads();
-        if (tid == 0) xf64[0] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        if (tid == 0) {
+            const double obj = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+            xf64[0] = obj;
+            if (st) {
+                const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2, true);
+                if (!rule && st->notpd_pending) { st->notpd = 1; st->flag = 3; }
+                st->notpd_pending = 0;
+            }
+        }
     }
+}
+
+// ---- stream-K plan (see xyt32_bf16_kernel<..., SK>) ----
+bool nmfx_sk_enabled(const nmfx_engine* E) {
+    static const bool on = !(getenv("NMFX_SK") && atoi(getenv("NMFX_SK")) == 0);
+    return on && E->kp == 128 && E->precision == 1 && nmfx_bf16_supported(E);
+}
+
+static int sk_plan(nmfx_engine* E, int side) {
+    nmfx_engine::SkPlan& P = E->sk[side];
+    if (P.seg) return NMFX_OK;
+    const int64_t R = side == 0 ? E->np : E->mp;       // rows of X
+    const int ngroups = (int)((side == 0 ? E->mp : E->np) / 64);
+    const int64_t rb = R / 128, units = rb * ngroups;
+    static const int forced = getenv("NMFX_SK_WORKERS") ? atoi(getenv("NMFX_SK_WORKERS")) : 0;
+    // one CU stays free for the side job; runs of at least four groups (the depth of the kernel's rings) where the problem allows
+    int64_t workers = std::min<int64_t>(E->ncu - 1, std::max<int64_t>(1, units / 4));
+    if (forced > 0) workers = std::min<int64_t>(forced, units);
+    // Runs of equal COST: a worker's cost is its groups plus `cross` group-equivalents per extra segment (the epilogue of a segment --
+    // exchange of the partial tiles, 64 KiB of slab stores -- and the refill of the rings: measured 7-10 us on config 3, where a group
+    // takes 1.5 us on the W side and 2.4 us with the objective).  The smallest bound T that `workers` greedy runs can meet, by bisection.
+    static const int cross = getenv("NMFX_SK_CROSS") ? atoi(getenv("NMFX_SK_CROSS")) : 5;
+    auto deal = [&](int64_t T, std::vector<int64_t>* ends) {        // greedy runs of cost <= T; returns the number of runs
+        int64_t u = 0, nw = 0;
+        while (u < units) {
+            int64_t cost = 0, v = u;
+            bool first_seg = true;
+            while (v < units) {
+                const int64_t b = v / ngroups, room = (b + 1) * ngroups - v;
+                const int64_t extra = first_seg ? 0 : cross;
+                if (cost + extra + 1 > T) break;
+                const int64_t take = std::min<int64_t>(room, T - cost - extra);
+                cost += extra + take; v += take; first_seg = false;
+                if (take < room) break;
+            }
+            if (v == u) v = u + 1;                     // (T < 1 cannot happen; guard against an endless loop)
+            u = v; ++nw;
+            if (ends) ends->push_back(u);
+        }
+        return nw;
+    };
+    int64_t lo = 1, hi = units + cross * rb;
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (deal(mid, nullptr) <= workers) hi = mid; else lo = mid + 1; }
+    std::vector<int64_t> ends;
+    workers = deal(lo, &ends);
+    std::vector<int4> seg;
+    std::vector<int> first(workers + 1), cnt(rb, 0);
+    static const bool cyclic = !(getenv("NMFX_SK_CYCLIC") && atoi(getenv("NMFX_SK_CYCLIC")) == 0);
+    for (int64_t w = 0; w < workers; ++w) {
+        first[w] = (int)seg.size();
+        int64_t u = w ? ends[w - 1] : 0, tau = 0;      // tau: groups this worker has done before the segment (its clock)
+        const int64_t u1 = ends[w];
+        while (u < u1) {
+            const int64_t b = u / ngroups, e = std::min<int64_t>(u1, (b + 1) * ngroups);
+            const int64_t a = u - b * ngroups, z = e - b * ngroups;
+            // start at the group congruent to the clock modulo the common run length lo (if the segment has one): see the kernel
+            int64_t st = a + (((tau - a) % lo) + lo) % lo;
+            if (st >= z || !cyclic) st = a;
+            if (cnt[b] > 255 || st > 0x7fffff) { E->err = "stream-K plan: slab / start out of range"; return NMFX_E_ARG; }
+            seg.push_back(make_int4((int)b, (int)a, (int)z, cnt[b]++ | (int)(st << 8)));
+            tau += z - a;
+            u = e;
+        }
+    }
+    first[workers] = (int)seg.size();
+    int maxslab = 1;
+    for (int64_t b = 0; b < rb; ++b) maxslab = std::max(maxslab, cnt[b]);
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.seg), seg.size() * sizeof(int4)));
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.first), first.size() * sizeof(int)));
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.cnt), cnt.size() * sizeof(int)));
+    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.slabs), (size_t)maxslab * R * E->kp * sizeof(float)));
+    NMFX_HIP(hipMemcpy(P.seg, seg.data(), seg.size() * sizeof(int4), hipMemcpyHostToDevice));
+    NMFX_HIP(hipMemcpy(P.first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+    NMFX_HIP(hipMemcpy(P.cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    P.workers = (int)workers; P.nseg = (int)seg.size(); P.maxslab = maxslab;
+    if ((int64_t)P.nseg > E->obj_part_cap) { E->err = "stream-K plan: more segments than objective partials"; return NMFX_E_ARG; }
+    return NMFX_OK;
+}
+
+int nmfx_bf16_sk_product(nmfx_engine* E, int side, bool obj, const float* gsrc, int gslabs, double fixed_rho, const char* name) {
+    int rc;
+    if ((rc = sk_plan(E, side))) return rc;
+    ProfScope ps(E, name);
+    const nmfx_engine::SkPlan& P = E->sk[side];
+    const float* X = side == 0 ? E->Vt : E->Vtile;
+    const int64_t ldx = side == 0 ? E->mp : E->np, R = side == 0 ? E->np : E->mp;
+    const int ngroups = (int)(ldx / 64);
+    const unsigned short* Yhi = side == 0 ? E->WThi : E->Hhi;
+    const unsigned short* Ylo = side == 0 ? E->WTlo : E->Hlo;
+    const unsigned short* Zhi = !obj ? nullptr : side == 0 ? E->HThi : E->Whi[0];
+    const unsigned short* Zlo = !obj ? nullptr : side == 0 ? E->HTlo : E->Wlo[0];
+    XytSide job; job.gsrc = gsrc; job.gslabs = gslabs; job.k = E->k; job.Minv = E->Minv; job.st = E->state; job.fixed_rho = fixed_rho;
+    const dim3 grid((unsigned)(P.workers + (gsrc ? 1 : 0))), block(512);
+    const size_t shm = 160 * 1024;
+    auto kern = obj ? xyt32_bf16_kernel<true, 3, 0, false, 128, 1, false, true, 8, true>
+                    : xyt32_bf16_kernel<false, 3, 0, false, 128, 1, false, true, 8, true>;
+    if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
+    if (obj) E->obj_count = P.nseg;
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, P.slabs, E->obj_part,
+                       (float*)nullptr, R, ngroups, &E->state->flag, 1, (const int4*)P.seg, (const int*)P.first, P.workers, job);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+int nmfx_bf16_pack_sk(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2) {
+    ProfScope ps(E, "pack");
+    const nmfx_engine::SkPlan& P = E->sk[0];
+    const unsigned grid = (unsigned)(E->np / 64 + E->kp * E->kp / 256 + 1);
+    hipLaunchKernelGGL((pack_t_kernel<128>), dim3(grid), dim3(256), 0, E->stream, P.slabs, P.maxslab, E->np, (const float*)nullptr, 0,
+                       E->obj_part, (int64_t)P.nseg, E->xf32, E->xf64, &E->state->flag, (const int*)P.cnt, E->state, E->obj_hist,
+                       (long long)j, (long long)min_iter, tol1, tol2);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nobj) {

@@ -33,7 +33,7 @@ struct DevState {          // lives in device memory, written by kernels
     int inner_stop;        // set when `terminate` (ao_admm.py:33-43) fires
     int inner_count;       // inner iterations executed in the current sub-problem
     int notpd;             // Cholesky hit a non-positive pivot
-    int pad1;
+    int notpd_pending;     // ... in an inversion that ran BESIDE the product whose objective may still stop the run (r4: the side job)
     double rho;            // trace(G)/k of the current sub-problem
     // added to the iteration index a launch carries: lets a captured hipGraph of two outer
     // iterations (indices 0 and 1 baked into its kernel arguments) be replayed for any pair
@@ -83,6 +83,7 @@ struct nmfx_engine {
     float* A_part = nullptr;       // [wsplit][mp][kp]
     float* B_part = nullptr;       // [hsplit][kp][np]
     double* obj_part = nullptr;    // [max blocks]
+    int64_t obj_part_cap = 0;
     float* xf32 = nullptr;         // exchange: [kp*np | kp*kp | kp]
     double* xf64 = nullptr;        // exchange: [8] = objective partial, 4 inner-loop norm sums, 3 spare
     bool own_x = true;
@@ -125,6 +126,7 @@ struct nmfx_engine {
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     int xyt_nw = 8;                // waves per block of the next 32-row product launch (4: 64-row blocks, two per CU; set and reset by the caller)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
+    const float* ao_a_src = nullptr; const int* ao_a_cnt = nullptr;   // ... the slab buffer (default A_part) and, behind a stream-K product, the slabs per 128-row block
     bool wimg_ok = false;          // Whi/Wlo[0] and WThi/WTlo are the images of the current W[0] (AO-ADMM: left by the fused W-side launches)
     bool ao_images = false;        // the fused round kernels being launched write the images of the factor they update
     bool himg_both = false;        // Hhi/Hlo AND HThi/HTlo are the images of the current H (AO-ADMM skips a rebuild)
@@ -145,6 +147,14 @@ struct nmfx_engine {
     int64_t nrm_rounds_cap = 0;
     float *bkX = nullptr, *bkU = nullptr;   // initial X, U of a fused sub-problem (restart point of the repair launch)
     int32_t* inner_hist = nullptr; int64_t inner_cap = 0;   // device [cap][2]
+    // r4, stream-K form of the k = 128 Euclidean products (kernels_bf16.hip, xyt32_bf16_kernel<..., SK>): [0] H side (X = V^T), [1] W side (X = V)
+    struct SkPlan {
+        int4* seg = nullptr;       // device [nseg]: row block, first group, end group, slab
+        int* first = nullptr;      // device [workers + 1]: a worker's segments
+        int* cnt = nullptr;        // device [R / 128]: slabs of a row block (what the consumers sum)
+        float* slabs = nullptr;    // device [maxslab][R][kp]
+        int workers = 0, nseg = 0, maxslab = 0;
+    } sk[2];
     // split configuration
     int wsplit = 1, hsplit = 1, gsplit = 1;
     bool have_v = false, have_f = false;
@@ -213,6 +223,13 @@ int nmfx_bf16_objective(nmfx_engine* E, int zbuf, const char* name);
 int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_kl_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_bf16_pack_t(nmfx_engine* E, const float* Gpart, int gsplit, int64_t nobj);
+// r4: the stream-K product of side 0 (B^T slabs = V^T W, objective with Z = H^T images if obj) / 1 (A slabs = V H^T) with the
+// inversion of (sum of gslabs slabs of gsrc) + rho I as its side job (gsrc = nullptr: none); consumers read E->sk[side]
+int nmfx_bf16_sk_product(nmfx_engine* E, int side, bool obj, const float* gsrc, int gslabs, double fixed_rho, const char* name);
+// the pack behind it: xf32 = [B^T sums transposed], xf64[0] = objective, recorded as obj[j] with the stop rule (and a pending "not
+// positive definite" of the side job promoted unless the rule fired)
+int nmfx_bf16_pack_sk(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, double tol2);
+bool nmfx_sk_enabled(const nmfx_engine* E);
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);

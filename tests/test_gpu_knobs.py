@@ -43,6 +43,12 @@ CASES = [
     ({"NMFX_NNLS128_OCC": "1"}, "anls", (260, 400, 100), dict(min_iter=3, max_iter=3, lambda_w=0.05, lambda_h=0.02, nndsvd_init=NNDSVD)),
     ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_FUSED": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    # r4: the inversions as side jobs of stream-K products are the default at k padded to 128; the launches of round 3, plain (not
+    # cyclic) runs, and a worker count that makes every run cross several row blocks (segments per worker > 2)
+    ({"NMFX_AO_OVERLAP": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_SK_CYCLIC": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_SK_WORKERS": "2"}, "ao_admm", (640, 512, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_SK_WORKERS": "7"}, "ao_admm", (640, 512, 100), dict(reg_w=[0, "nn"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_CINV": "0"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),      # elimination kernels only
