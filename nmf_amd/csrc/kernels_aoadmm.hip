@@ -577,7 +577,13 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     DevState* __restrict__ st, double* __restrict__ nrm_rounds, int phase, int32_t* __restrict__ slot,
     const int* __restrict__ hint_rd, int* __restrict__ hint_wr,
     unsigned short* __restrict__ ihi = nullptr, unsigned short* __restrict__ ilo = nullptr,       // r3: the bf16 images of the new H
-    unsigned short* __restrict__ ithi = nullptr, unsigned short* __restrict__ itlo = nullptr)     // ([KP][np]) and of H^T ([np][KP])
+    unsigned short* __restrict__ ithi = nullptr, unsigned short* __restrict__ itlo = nullptr,     // ([KP][np]) and of H^T ([np][KP])
+    // r4, behind a stream-K product (no pack launch): the right-hand side is the sum of the B^T slabs Bt[p][np][KP], p < bcnt[column
+    // block of 128], and the FIRST launch of the sub-problem records the objective (sum of nobj partials) as obj[j] and applies the
+    // stop rule -- every block evaluates the same sum and the same rule (block 0 publishes), so all of them leave together
+    const float* __restrict__ Bt = nullptr, const int* __restrict__ bcnt = nullptr, int64_t bstride = 0,
+    const double* __restrict__ objpart = nullptr, int nobj = 0, double* __restrict__ obj_hist = nullptr, double* __restrict__ xf64 = nullptr,
+    long long j = 0, long long min_iter = 0, double tol1 = 0.0, double tol2 = 0.0)
 {
     if (st->flag) return;
     constexpr int JT = KP / 16;
@@ -589,6 +595,21 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
     double* sh = reinterpret_cast<double*>(ms + ((KP >= 64 && CB == 32) ? (3 * KP * KP) / 2 : KP * LDM));    // (split form: three bf16 images)
     const int nblk = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    if (objpart && phase == 0) {
+        double t = 0.0;                                // (the pack kernel's order of additions)
+        for (int i = tid; i < nobj; i += 256) t += objpart[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0) sh[wave] = t;
+        __syncthreads();
+        const double obj = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        const bool writer = blockIdx.x == 0 && tid == 0;
+        const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2, writer);
+        const int bad = st->notpd_pending;             // (written by the side job of the launch before this one, never here)
+        if (writer) { xf64[0] = obj; if (!rule && bad) { st->notpd = 1; st->flag = 3; } }
+        if (rule || bad) return;
+        __syncthreads();
+    }
     FusedPlan plan;
     if (!fused_plan(phase, admm_iter, hint_rd, hint_wr, nrm_rounds, nblk, sh, st, slot, plan)) return;
     const int64_t c0 = (int64_t)blockIdx.x * CB;
@@ -634,12 +655,36 @@ __global__ __launch_bounds__(256) void ao_fused_cols_kernel(
                 const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + NE * x;
                 ldv<NE>(hx[r][g], srcX + idx);
                 ldv<NE>(ux[r][g], srcU + idx);
-                ldv<NE>(bx[r][g], Bsum + idx);
+                if (!Bt) ldv<NE>(bx[r][g], Bsum + idx);
                 if (plan.save) {
                     stv<NE>(Xb + idx, hx[r][g]);
                     stv<NE>(Ub + idx, ux[r][g]);
                 }
             }
+        }
+    }
+    if (Bt) {                                          // slabs [column][factor]: the lane's four factors of a column are one 16-byte load
+        const int np_ = bcnt[c0 >> 7];
+#pragma unroll
+        for (int r = 0; r < ITW; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) bx[r][g][e] = 0.f;
+        for (int p = 0; p < np_; ++p) {                // slab order; a slab's loads all in flight together
+            float4 v[ITW][NE];
+#pragma unroll
+            for (int r = 0; r < ITW; ++r) {
+                const int it = wave + 4 * r;
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    v[r][e] = it < JT ? *reinterpret_cast<const float4*>(Bt + (int64_t)p * bstride + (c0 + NE * x + e) * KP + 16 * it + 4 * q)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < ITW; ++r)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { bx[r][0][e] += v[r][e].x; bx[r][1][e] += v[r][e].y; bx[r][2][e] += v[r][e].z; bx[r][3][e] += v[r][e].w; }
         }
     }
     for (int rnd = plan.first; rnd < plan.first + plan.count; ++rnd) {
@@ -1262,9 +1307,12 @@ static int launch_fused_cols_cb(nmfx_engine* E, int prox, float lam, int admm_it
     auto kern = ao_fused_cols_kernel<KP, CB>;
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc_) return rc_; }
     const bool img = E->ao_images;                     // (ao_fused_subproblem: split-bf16 run, images allocated)
+    const bool sk = E->ao_b_src != nullptr;            // (the overlap iteration: no pack launch)
     hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / CB)), dim3(256), shm, E->stream, E->xf32, E->H, E->dualH, E->bkX, E->bkU,
                        E->Minv, E->np, prox, lam, admm_iter, E->state, E->nrm_rounds, phase, slot, hint_rd, hint_wr,
-                       img ? E->Hhi : nullptr, img ? E->Hlo : nullptr, img ? E->HThi : nullptr, img ? E->HTlo : nullptr);
+                       img ? E->Hhi : nullptr, img ? E->Hlo : nullptr, img ? E->HThi : nullptr, img ? E->HTlo : nullptr,
+                       E->ao_b_src, E->ao_b_cnt, (int64_t)E->np * E->kp, sk ? E->obj_part : (const double*)nullptr, E->ao_rec_nobj,
+                       E->obj_hist, E->xf64, (long long)E->ao_rec_j, (long long)E->ao_rec_min_iter, E->ao_rec_tol1, E->ao_rec_tol2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -1420,10 +1468,17 @@ static int aoadmm_eu_iteration_overlap(nmfx_engine* E, int prox_w, double lam_w,
     int gslabs = 64;
     if ((rc = nmfx_bf16_gram_tn(E, &gslabs))) return rc;
     if ((rc = nmfx_bf16_sk_product(E, 0, true, E->G_part, gslabs, -1.0, "hphase"))) return rc;
-    if ((rc = nmfx_bf16_pack_sk(E, j, min_iter, tol1, tol2))) return rc;
+    static const bool packed = getenv("NMFX_AO_PACK") && atoi(getenv("NMFX_AO_PACK")) == 1;      // (A/B: the pack launch of the first form)
+    if (packed) { if ((rc = nmfx_bf16_pack_sk(E, j, min_iter, tol1, tol2))) return rc; }
+    else {         // the rounds of H sum the B^T slabs themselves; their first launch records obj[j] and applies the stop rule
+        E->ao_b_src = E->sk[0].slabs; E->ao_b_cnt = E->sk[0].cnt; E->ao_rec_nobj = E->sk[0].nseg;
+        E->ao_rec_j = j; E->ao_rec_min_iter = min_iter; E->ao_rec_tol1 = tol1; E->ao_rec_tol2 = tol2;
+    }
     E->himg_both = false;                              // H changes below
     { ProfScope ps(E, "inner_h");
-      if ((rc = ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2, (int)(j & 1)))) return rc; }
+      rc = ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2, (int)(j & 1)); }
+    E->ao_b_src = nullptr; E->ao_b_cnt = nullptr;
+    if (rc) return rc;
     if (!E->himg_both && (rc = nmfx_bf16_images_h(E, true))) return rc;
     int hslabs = 32;                                   // (HHt_part holds at least 40 slabs)
     if ((rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;

@@ -2286,8 +2286,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
             xf64[0] = obj;
             if (st) {
                 const int rule = nmfx_record_objective(st, obj_hist, obj, j, min_iter, tol1, tol2, true);
-                if (!rule && st->notpd_pending) { st->notpd = 1; st->flag = 3; }
-                st->notpd_pending = 0;
+                if (!rule && st->notpd_pending) { st->notpd = 1; st->flag = 3; }      // (notpd_pending: written by every side job, never here)
             }
         }
     }

@@ -126,6 +126,8 @@ struct nmfx_engine {
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     int xyt_nw = 8;                // waves per block of the next 32-row product launch (4: 64-row blocks, two per CU; set and reset by the caller)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
+    const float* ao_b_src = nullptr; const int* ao_b_cnt = nullptr;   // AO-ADMM H side, behind a stream-K product: B^T slabs the fused rounds sum themselves (+ what their first launch records)
+    int ao_rec_nobj = 0; int64_t ao_rec_j = 0, ao_rec_min_iter = 0; double ao_rec_tol1 = 0.0, ao_rec_tol2 = 0.0;
     const float* ao_a_src = nullptr; const int* ao_a_cnt = nullptr;   // ... the slab buffer (default A_part) and, behind a stream-K product, the slabs per 128-row block
     bool wimg_ok = false;          // Whi/Wlo[0] and WThi/WTlo are the images of the current W[0] (AO-ADMM: left by the fused W-side launches)
     bool ao_images = false;        // the fused round kernels being launched write the images of the factor they update

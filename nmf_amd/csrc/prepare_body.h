@@ -321,6 +321,7 @@ __device__ __forceinline__ void ao_prepare_body(
             for (int r = 0; r < 4; ++r) out64[(int64_t)(16 * w + q + 4 * r) * KP + 16 * jb + c] = t[jb][r];
         return;
     }
+    if (defer_notpd && tid == 0) st->notpd_pending = 0;
     if (helper || idle) return;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb)
