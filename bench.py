@@ -234,44 +234,16 @@ def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192, rows=None):
 
 
 def make_sharded(torch, dist, nd, rank, world, local_rank, build):
-    """This rank's shard and its exchange.  On RCCL ("nccl") the exchange runs BEHIND the C ABI (nd.NativeShard / nd.NativeComm:
-    nmfx_comm_init_rank + nmfx_mur_run_sharded, no torch on the data path); torch.distributed's collectives between the phase calls
-    remain as the rehearsal rig (NMFX_BENCH_BACKEND=gloo: several ranks on ONE GPU) and as the fall-back when RCCL cannot be bound
-    on every rank (NMFX_DIST_NATIVE=0 forces it).  `build(cls)` makes the shard.  Every rank takes the same branch: the choice is
-    all-reduced before any data-path collective.  Returns (shard, comm, name of the loop)."""
+    """This rank's shard and its exchange: nmf_amd.dist.make_sharded.  The default is torch.distributed's collectives between the
+    phase calls; NMFX_DIST_NATIVE=1 runs the exchange BEHIND the C ABI (nd.NativeShard / nd.NativeComm: nmfx_comm_init_rank +
+    nmfx_mur_run_sharded, no torch on the data path) -- opt-in until it has run with more than one rank on RCCL; with a
+    world of one (NMFX_BENCH_FORCE_SHARDED=1: the one-GPU rehearsal) the native loop is the default, as before.  Every rank takes the
+    same branch (the choice is all-reduced before any data-path collective).  Returns (shard, comm, name of the loop)."""
     on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device(f"cuda:{local_rank}")
-    want = on_gpu and os.environ.get("NMFX_DIST_NATIVE", "1") != "0"
-    if want:
-        ok = 1
-        try:
-            from nmf_amd.engine import Engine
-            Engine.comm_unique_id()                     # binds RCCL (dlopen) or raises
-        except Exception as e:  # noqa: BLE001
-            sys.stderr.write(f"rank {rank}: RCCL behind the C ABI is not available ({e}); torch.distributed's collectives instead\n")
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        want = int(flag.item()) == 1
-    if want:
-        shard = build(nd.NativeShard)
-        comm, ok = None, 1
-        try:
-            if os.environ.get("NMFX_BENCH_BREAK_NATIVE") == "1":     # (rehearsal of this fall-back)
-                raise RuntimeError("NMFX_BENCH_BREAK_NATIVE=1")
-            comm = nd.NativeComm.create(shard)          # ncclCommInitRank on every rank
-        except Exception as e:  # noqa: BLE001
-            sys.stderr.write(f"rank {rank}: the communicator behind the C ABI did not come up ({e}); torch.distributed's collectives instead\n")
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return shard, comm, "native (nmfx_mur_run_sharded: RCCL behind the C ABI)"
-        if comm is not None:                            # some other rank failed: everybody takes the torch path
-            comm.close()
-        shard.eng.close()
-    shard = build(nd.DeviceShard)
-    return shard, nd.TorchComm(stage_through_host=not on_gpu), "torch.distributed collectives between the phase calls"
+    env = os.environ.get("NMFX_DIST_NATIVE")
+    want = (env == "1") if env is not None else world == 1
+    return nd.make_sharded(build, rank, torch.device(f"cuda:{local_rank}"), on_gpu, want_native=want,
+                           break_native=os.environ.get("NMFX_BENCH_BREAK_NATIVE") == "1")
 
 
 def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):

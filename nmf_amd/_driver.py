@@ -31,8 +31,22 @@ class Referee:
         self.eng, self.run_one, self.min_iter, self.tol1, self.tol2 = engine, run_one, min_iter, tol1, tol2
         self.mode = os.environ.get("NMFX_VERIFY_STOP", "auto")
         self.guard = 0.0
+        self.jitter6 = 0.0                           # the 6 sigma part of the guard (without the head start for the curvature)
         self.walked = 0
+        self.confirmed = 0                           # candidates accepted from the recorded history alone (see confirms)
         self.final_rule = 0
+
+    @staticmethod
+    def would_arm(history, tol2):
+        """True when update_guard, shown this history, puts a guard in force (mode 'auto').  nmf_amd.grid uses it on the histories
+        of a PAIR run (nmf_amd.mur.mur_pair keeps the plain device rule): such a combination is run again singly, refereed."""
+        import os
+        if os.environ.get("NMFX_VERIFY_STOP", "auto") == "0" or len(history) < 24:
+            return False
+        tail = np.asarray(history[-68:], dtype=np.float64)
+        d4 = np.diff(tail, n=4)
+        g = 6.0 * 1.4826 * np.median(np.abs(d4 - np.median(d4))) * np.sqrt(2.0 / 70.0)
+        return bool(np.isfinite(g) and g >= 1e-6 * tol2) or os.environ.get("NMFX_VERIFY_STOP", "auto") == "1"
 
     def update_guard(self, history):
         if self.mode == "0" or len(history) < 24:
@@ -44,6 +58,7 @@ class Referee:
         d4 = np.diff(tail, n=4)
         sigma_d = 1.4826 * np.median(np.abs(d4 - np.median(d4))) * np.sqrt(2.0 / 70.0)
         g = 6.0 * sigma_d
+        self.jitter6 = g if np.isfinite(g) else 0.0
         if g >= 1e-6 * self.tol2:
             # The walk can only test loop indices BEHIND the candidate (the pair in front of it is gone), so the candidate has to
             # come at least one iteration early even without any jitter: twice the change of the decrease per iteration on top.
@@ -61,6 +76,21 @@ class Referee:
         if g != self.guard:
             self.guard = g
             self.eng.set_stop_guard(g)
+
+    def confirms(self, history, candidate_i):
+        """The walk below can only test loop indices BEHIND the candidate (the pair that entered iteration `candidate_i` is gone),
+        so a candidate at which the reference's rule already holds -- the first tested index min_iter + 1 of a run that converged
+        before min_iter, or a decrease that falls faster than the head start assumed -- would come back one iteration late
+        (ADVICE r3).  If the RECORDED pair of objectives satisfies the plain rule with the whole jitter estimate to spare,
+        `new >= old - tol2 + 6 sigma`, the float64 values satisfy it too: the candidate is the stop.  (The index before it did
+        not fire with the guard, i.e. its recorded decrease exceeded tol2 by more than the jitter, so the rule did not hold there.)"""
+        if candidate_i + 1 >= len(history) or candidate_i <= self.min_iter:
+            return False
+        new, old = history[candidate_i + 1], history[candidate_i]
+        if new >= old - self.tol2 + self.jitter6:
+            self.confirmed += 1
+            return True
+        return False
 
     def walk(self, candidate_i, max_iter, pull):
         """From the candidate stop (device rule 2 with the guard at loop index `candidate_i`) on: the current pair is the one that
@@ -113,7 +143,9 @@ def drive(engine, run_batch, finish, max_iter, tol1, tol2, before_line=None, ref
         rule, stop_i, n_obj = engine.state()
         pull()
         if referee is not None:
-            if rule == 2 and referee.guard > 0:      # a candidate: the float64 objective decides from here on
+            if rule == 2 and referee.guard > 0 and referee.confirms(history, stop_i):
+                pass                                 # the plain rule holds at the candidate beyond the jitter: it IS the stop
+            elif rule == 2 and referee.guard > 0:    # a candidate: the float64 objective decides from here on
                 rule, stop_i, done = referee.walk(stop_i, max_iter, pull)
                 finish(done)                         # the objective of the last pair, evaluated as every other history entry
                 pull()

@@ -9,14 +9,12 @@ is evaluated on the device too.
 
 Regularisers: 'nn' and 'l1n' are built (any number of components, both losses).  'l2n' raises
 ValueError exactly like the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it is also the reference's
-DEFAULT reg_h, so callers must pass reg_h explicitly).  'l1inf' / 'l1inf_transpose' raise numpy.linalg.LinAlgError up front:
-the reference's ao_admm copy of the operator (nmf/ao_admm.py:143-195) makes the iteration blow up until a Cholesky
-factorisation fails ("leading minor not positive definite").  DEVIATION: as `reg_h` that happens in the first outer
-iteration of the reference too; as `reg_w` (with a well-behaved `reg_h`) the reference first completes some outer iterations --
-printing their `[i]: objective` lines, and with a small `max_iter` even returning a Results -- before the same exception at an
-iteration between 3 and 60 that depends on rounding.  This port does not reproduce those diverging iterates (their values are
-an amplification of rounding differences, DESIGN.md 4c'); it raises the reference's exception type before the first one.  The
-working copy of the operator is ADMM's (nmf_amd.admm)."""
+DEFAULT reg_h, so callers must pass reg_h explicitly).  'l1inf' / 'l1inf_transpose' (nmf/ao_admm.py:143-195, word for word the
+operator of nmf/admm.py:158-210) run on the device with the least-squares loss and at most 128 components (r4): in the reference
+they wipe a factor out within a few outer iterations -- W = 0 after the first one as `reg_w`, H = 0 inside the first one as
+`reg_h` -- and the next Cholesky factorisation raises numpy.linalg.LinAlgError; here the same pivot test (NMFX_E_NOTPD) raises the
+same exception in the same outer iteration, and a run whose `max_iter` ends before it returns the reference's Results
+(tests/golden/ao_admm_l1inf_*.npz).  With the KL loss or beyond 128 components they still raise that exception up front."""
 from collections import namedtuple
 
 import numpy as np
@@ -29,8 +27,11 @@ from .engine import Engine
 Experiment = namedtuple('Experiment', 'method components distance_type nndsvd_init min_iter max_iter admm_iter tol1 tol2 lambda_w prox_w lambda_h prox_h')
 
 
-def _prox_code(kind):
+def _prox_code(kind, on_device=False):
+    """on_device: 'l1inf*' is available (single GPU, least-squares loss, k <= 128); otherwise it raises what the reference ends in."""
     if kind in ('nn', 'l1n'):
+        return L.PROX[kind]
+    if kind in ('l1inf', 'l1inf_transpose') and on_device:
         return L.PROX[kind]
     if kind == 'l2n':
         raise ValueError('setting an array element with a sequence. The requested array has an '
@@ -52,8 +53,9 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
     dist = L.EU if distance_type == 'eu' else L.KL
     init = utils.initial_factors(v, k, nndsvd_init, defer_device=True)
     # the reference meets the H regulariser first (ao_admm.py:261), then W's
-    prox_h = _prox_code(reg_h[1])
-    prox_w = _prox_code(reg_w[1])
+    on_device = distance_type == 'eu' and k <= 128
+    prox_h = _prox_code(reg_h[1], on_device)
+    prox_w = _prox_code(reg_w[1], on_device)
 
     with Engine.for_data(v, k, device=device, engine=engine) as eng:
         w0, h0 = utils.device_initial_factors(eng, v, k, nndsvd_init, init)

@@ -74,7 +74,7 @@ struct nmfx_comm {
     bool want_graph = false, graph_failed = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    double g_lw = 0, g_lh = 0, g_t1 = 0, g_t2 = 0; int64_t g_min = 0; int g_dist = -1; int g_chunks = 0;
+    double g_lw = 0, g_lh = 0, g_t1 = 0, g_t2 = 0; int64_t g_min = 0; int g_dist = -1; int g_chunks = 0; int g_precision = -1;
     const void* g_hist = nullptr; hipStream_t g_stream = nullptr;     // what the captured nodes point at
     bool g_klfresh = false;               // captured with "the previous iteration's KL epilogue left its images and sums" (kl_h_iter)
     int64_t replays = 0;
@@ -92,6 +92,17 @@ static int need_rccl(nmfx_engine* E) {
 static void drop_graph(nmfx_comm* c) {
     if (c->exec) { hipGraphExecDestroy(c->exec); c->exec = nullptr; }
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+// nmfx_set_precision: what nmfx_comm_negotiate settled -- the merged objective, the chunk unit -- and a captured graph
+// belong to the arithmetic mode they were settled in.  The exact-f32 epilogues put the objective partial into xf64, which a merged
+// iteration does not reduce; a replayed graph would run the old mode's kernels.
+void nmfx_comm_invalidate(nmfx_engine* E) {
+    nmfx_comm* c = E->comm;
+    if (!c) return;
+    c->negotiated = false; c->merged = false;
+    drop_graph(c);
+    nmfx_set_exchange_rank(E, 0, 0);
 }
 
 void nmfx_comm_free(nmfx_engine* E) {      // nmfx_destroy
@@ -311,7 +322,7 @@ static int capture_pair(nmfx_engine* E, int distance, double lw, double lh, int6
     if (hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); c->exec = nullptr; (void)hipGetLastError(); return NMFX_E_HIP; }
     c->graph = g;
     c->g_hist = E->obj_hist; c->g_stream = E->stream;
-    c->g_dist = distance; c->g_lw = lw; c->g_lh = lh; c->g_min = min_iter; c->g_t1 = tol1; c->g_t2 = tol2; c->g_chunks = chunks;
+    c->g_dist = distance; c->g_lw = lw; c->g_lh = lh; c->g_min = min_iter; c->g_t1 = tol1; c->g_t2 = tol2; c->g_chunks = chunks; c->g_precision = E->precision;
     return NMFX_OK;
 }
 
@@ -348,7 +359,7 @@ extern "C" int nmfx_mur_run_sharded(nmfx_handle_t E, int distance, double lambda
             if ((rc = nmfx_ensure_obj_capacity(E, end + 4))) return rc;           // (may move the history: checked below)
             const bool same = c->exec && c->g_dist == distance && c->g_lw == lambda_w && c->g_lh == lambda_h && c->g_min == min_iter &&
                               c->g_t1 == tol1 && c->g_t2 == tol2 && c->g_chunks == chunks && c->g_hist == E->obj_hist &&
-                              c->g_stream == E->stream;
+                              c->g_stream == E->stream && c->g_precision == E->precision;
             if (!same) {
                 const bool fresh_now = distance == NMFX_KL && E->kl_h_iter == j - 1;
                 if (fresh_now) E->kl_h_iter = -1;

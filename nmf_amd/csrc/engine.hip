@@ -255,6 +255,7 @@ int nmfx_reset_stream(nmfx_handle_t E) {
 int nmfx_set_precision(nmfx_handle_t E, int mode) {
     if (E) { E->himg_both = false; E->wimg_ok = false; E->gxb_img_ready = false; }
     if (!E || (mode != 0 && mode != 1)) { if (E) E->err = "precision must be 0 (f32) or 1 (split bf16)"; return NMFX_E_ARG; }
+    if (E->precision != mode) nmfx_comm_invalidate(E);
     E->precision = mode;
     return NMFX_OK;
 }

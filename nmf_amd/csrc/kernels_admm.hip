@@ -198,8 +198,8 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
 // argument checks, allocations and (for the first iteration) the start state w_aux = w, h_aux = h (admm.py:27-28)
 // with the objective partials of the initial pair (admm.py:289)
 static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count, bool any_k = false) {
-    if (E) E->anls_a_ready = false; E->kl_h_iter = -2;
     if (!E) return NMFX_E_ARG;
+    E->anls_a_ready = false; E->kl_h_iter = -2;
     E->himg_both = false;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }

@@ -1417,12 +1417,57 @@ static int ao_fused_subproblem(nmfx_engine* E, bool cols, float* W, int prox, fl
     return NMFX_OK;
 }
 
+// ---- prox 'l1inf' / 'l1inf_transpose' inside AO-ADMM (nmf/ao_admm.py:143-195 = nmf/admm.py:158-210 word for word; r4) ----
+// The operator couples whole rows / columns of the factor, so a round is: aux = M^-1 (B + rho (X + U)) (the round kernel's
+// "solve only" mode), X_prev = X, X = prox(aux, U) and U += X - aux (kernels_prox.hip, with the sub-problem's rho read on the
+// device), then the four sums of `terminate` (ao_admm.py:33-43) from (X, X_prev, aux, U) in the slots the next round's kernel sums.
+// In the reference these runs end within a few outer iterations in scipy's LinAlgError (the operator wipes a factor out, its Gram
+// matrix is zero): here the same pivot test stops the run with NMFX_E_NOTPD at the same place.
+__global__ __launch_bounds__(256) void ao_l1inf_norms_kernel(
+    const float* __restrict__ X, const float* __restrict__ Xprev, const float* __restrict__ AUX, const float* __restrict__ U,
+    int64_t count, int round, const DevState* __restrict__ st, double* __restrict__ nrm)     // nrm: [2][gridDim.x][4]
+{
+    if (st->flag || st->inner_stop) return;
+    __shared__ double sh[16];
+    const int64_t per = (count + gridDim.x - 1) / gridDim.x, i0 = per * blockIdx.x, i1 = i0 + per < count ? i0 + per : count;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float x = X[i], d0 = x - AUX[i], d2 = x - Xprev[i], u = U[i];
+        n0 += d0 * d0; n1 += x * x; n2 += d2 * d2; n3 += u * u;
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * gridDim.x + blockIdx.x) * 4, sh);
+}
+
+static int ao_l1inf_subproblem(nmfx_engine* E, bool cols, int prox, double lam, int admm_iter, int32_t* slot) {
+    int rc;
+    if ((rc = nmfx_admm_state_alloc(E))) return rc;     // auxH / Asum: the aux matrices of the "solve only" rounds
+    if ((rc = ao_fused_alloc(E, admm_iter))) return rc; // bkX: X_prev
+    const int nblk = (int)((cols ? E->np : E->mp) / 64);
+    const int64_t count = cols ? (int64_t)E->kp * E->np : E->mp * (int64_t)E->kp;
+    float* X = cols ? E->H : E->W[0];
+    float* U = cols ? E->dualH : E->dualW;
+    float* aux = cols ? E->auxH : E->auxW;
+    for (int r = 0; r < admm_iter; ++r) {
+        if (cols) rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox, (float)lam, r);
+        else rc = nmfx_inner_rows(E, E->Asum, E->W[0], E->Minv, E->auxW, 1, prox, (float)lam, r);
+        if (rc) return rc;
+        NMFX_HIP(hipMemcpyAsync(E->bkX, X, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, E->stream));
+        if ((rc = nmfx_launch_prox_l1inf(E, cols, prox == NMFX_PROX_L1INF_T, -1.0, lam, 1.0, true, true))) return rc;
+        hipLaunchKernelGGL(ao_l1inf_norms_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, X, E->bkX, aux, U, count, r,
+                           E->state, E->nrm_part);
+        NMFX_HIP(hipGetLastError());
+    }
+    return nmfx_inner_finish(E, nblk, admm_iter, slot);
+}
+static bool ao_is_l1inf(int prox) { return prox == NMFX_PROX_L1INF || prox == NMFX_PROX_L1INF_T; }
+
 static int ao_h_solve(nmfx_engine* E, int prox_h, double lam_h, int admm_iter, int64_t min_iter, double tol1,
                       double tol2, int64_t j) {
     int rc;
     if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
     E->himg_both = false;                              // H changes below
     ProfScope ps(E, "inner_h");
+    if (ao_is_l1inf(prox_h)) return ao_l1inf_subproblem(E, true, prox_h, lam_h, admm_iter, E->inner_hist + j * 2);
     if (ao_fused_enabled(E, admm_iter))
         return ao_fused_subproblem(E, true, nullptr, prox_h, (float)lam_h, admm_iter, E->inner_hist + j * 2, (int)(j & 1));
     for (int r = 0; r < admm_iter; ++r) if ((rc = inner_cols(E, prox_h, (float)lam_h, r))) return rc;
@@ -1496,14 +1541,22 @@ static int aoadmm_eu_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
                                int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
     int rc;
     float* W = E->W[0];
-    if (ao_overlap(E, admm_iter) && ao_fused_enabled(E, admm_iter))
+    const bool any_l1inf = ao_is_l1inf(prox_w) || ao_is_l1inf(prox_h);
+    if (!any_l1inf && ao_overlap(E, admm_iter) && ao_fused_enabled(E, admm_iter))
         return aoadmm_eu_iteration_overlap(E, prox_w, lam_w, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j);
     // ---- H sub-problem: admm_ls_update(v, w, h, dual_h) ----
     if ((rc = ao_h_products(E))) return rc;
     if ((rc = ao_h_solve(E, prox_h, lam_h, admm_iter, min_iter, tol1, tol2, j))) return rc;
     // ---- W sub-problem: admm_ls_update(v.T, h.T, w.T, dual_w.T) ----
-    if ((rc = ao_w_products(E, j, min_iter, tol1, tol2, !ao_fused_enabled(E, admm_iter)))) return rc;
+    if ((rc = ao_w_products(E, j, min_iter, tol1, tol2, ao_is_l1inf(prox_w) || !ao_fused_enabled(E, admm_iter)))) return rc;
     E->wimg_ok = false;                                // W changes below
+    if (ao_is_l1inf(prox_w)) {                         // (the summed right-hand side moves to Asum: auxW receives the aux matrix)
+        ProfScope ps(E, "inner_w");
+        if ((rc = nmfx_admm_state_alloc(E))) return rc;
+        NMFX_HIP(hipMemcpyAsync(E->Asum, E->auxW, (size_t)E->mp * E->kp * sizeof(float), hipMemcpyDeviceToDevice, E->stream));
+        if ((rc = ao_l1inf_subproblem(E, false, prox_w, lam_w, admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+        return ao_new_pair_objective(E);
+    }
     { ProfScope ps(E, "inner_w");
       if (ao_fused_enabled(E, admm_iter)) {
           if ((rc = ao_fused_subproblem(E, false, W, prox_w, (float)lam_w, admm_iter, E->inner_hist + j * 2 + 1, (int)(j & 1)))) return rc;
@@ -1556,8 +1609,10 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss function type."; return NMFX_E_ARG; }
-    if ((prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) || (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N)) {
-        E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    auto known = [](int p) { return p == NMFX_PROX_NN || p == NMFX_PROX_L1N || p == NMFX_PROX_L1INF || p == NMFX_PROX_L1INF_T; };
+    if (!known(prox_w) || !known(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if ((ao_is_l1inf(prox_w) || ao_is_l1inf(prox_h)) && (distance != NMFX_EU || E->kp > 128)) {
+        E->err = "ao_admm with prox 'l1inf' / 'l1inf_transpose': least-squares loss and at most 128 components in this build"; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;

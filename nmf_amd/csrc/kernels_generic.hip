@@ -816,6 +816,7 @@ int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
         if (need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (pretend || free_b < need + ((size_t)256 << 20))) {
             E->gxb_disabled = true;
             E->gxb_img_ready = false;
+            nmfx_comm_invalidate(E);               // (a captured graph of a sharded run would replay the split-bf16 launches)
             char buf[256];
             snprintf(buf, sizeof buf, "%sk > 128: %.1f GiB free, the bf16 operand planes need %.1f GiB more: exact-f32 product kernel on this handle",
                      E->note.empty() ? "" : "; ", (double)free_b / (1 << 30), (double)need / (1 << 30));

@@ -45,9 +45,11 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red /* [16] *
 template <bool GLOBALK>
 __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
     const float* __restrict__ AUX, float* __restrict__ X, float* __restrict__ U, int64_t vec_stride, int64_t es,
-    int L, int Lpad, double rho, double lam, double ub, int update_dual, const int* __restrict__ flag, float* __restrict__ gkeys)
+    int L, int Lpad, double rho, double lam, double ub, int update_dual, const int* __restrict__ flag, float* __restrict__ gkeys,
+    const DevState* __restrict__ st)      // st != nullptr (AO-ADMM, r4): rho = trace(G) / k of the sub-problem, no-op once its inner stop fired
 {
     if (*flag) return;
+    if (st) { if (st->inner_stop) return; rho = st->rho; }
     extern __shared__ __attribute__((aligned(16))) float lkeys[];      // [Lpad] (LDS form)
     float* keys = GLOBALK ? gkeys + (int64_t)blockIdx.x * Lpad : lkeys;
     __shared__ double red[ROWS_NT / 64];
@@ -131,9 +133,10 @@ __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
 // one wavefront per vector i: element t at i * vs + t * es; the sorted vector takes the dual of vector 1 (admm.py:196)
 __global__ __launch_bounds__(64) void prox_l1inf_cols_kernel(
     const float* __restrict__ AUX, float* __restrict__ X, float* __restrict__ U, int64_t vs, int64_t es, int k,
-    double rho, double lam, double ub, int update_dual, const int* __restrict__ flag)
+    double rho, double lam, double ub, int update_dual, const int* __restrict__ flag, const DevState* __restrict__ st)
 {
     if (*flag) return;
+    if (st) { if (st->inner_stop) return; rho = st->rho; }
     __shared__ float keys[128];
     __shared__ double res[2];
     const int lane = threadIdx.x;
@@ -200,9 +203,11 @@ __global__ __launch_bounds__(64) void prox_l1inf_cols_kernel(
 
 // U += X - AUX (admm.py:321-322), all entries (the padding is zero in all three)
 __global__ __launch_bounds__(256) void dual_update_kernel(const float* __restrict__ AUX, const float* __restrict__ X,
-                                                          float* __restrict__ U, int64_t count, const int* __restrict__ flag)
+                                                          float* __restrict__ U, int64_t count, const int* __restrict__ flag,
+                                                          const DevState* __restrict__ st)
 {
     if (*flag) return;
+    if (st && st->inner_stop) return;
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= count) return;
     const float4 a = *reinterpret_cast<const float4*>(AUX + i), x = *reinterpret_cast<const float4*>(X + i);
@@ -214,8 +219,9 @@ __global__ __launch_bounds__(256) void dual_update_kernel(const float* __restric
 }  // namespace
 
 // X = prox(AUX, U) for the W side (mat_aux = w_aux^T, k x m) or the H side (mat_aux = h_aux, k x n)
-int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual) {
+int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual, bool ao) {
     ProfScope ps(E, "prox_l1inf");
+    const DevState* st = ao ? E->state : nullptr;       // (AO-ADMM: rho lives on the device, the rounds stop on their own)
     const float* aux = h_side ? E->auxH : E->auxW;
     float* x = h_side ? E->H : E->W[0];
     float* u = h_side ? E->dualH : E->dualW;
@@ -230,7 +236,7 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
             int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(prox_l1inf_rows_kernel<false>), (int)shm + 1024); if (rc) return rc;
             hipLaunchKernelGGL(prox_l1inf_rows_kernel<false>, dim3((unsigned)E->k), dim3(ROWS_NT), shm, E->stream, aux, x, u,
                                h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
-                               update_dual ? 1 : 0, &E->state->flag, (float*)nullptr);
+                               update_dual ? 1 : 0, &E->state->flag, (float*)nullptr, st);
         } else {            // longer vectors: the same kernel with its keys in a global work area
             if (E->prox_keys_cap < (int64_t)E->k * Lpad) {
                 if (E->prox_keys) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->prox_keys); E->prox_keys = nullptr; }
@@ -239,18 +245,18 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
             }
             hipLaunchKernelGGL(prox_l1inf_rows_kernel<true>, dim3((unsigned)E->k), dim3(ROWS_NT), 16, E->stream, aux, x, u,
                                h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
-                               update_dual ? 1 : 0, &E->state->flag, E->prox_keys);
+                               update_dual ? 1 : 0, &E->state->flag, E->prox_keys, st);
         }
     } else {                // a vector = the k factors of one column of mat_aux
         if (cols < 2) { E->err = "prox 'l1inf_transpose' reads column 1 of the dual: needs at least 2 columns"; return NMFX_E_ARG; }
         // (every vector reads the dual of vector 1: the dual update is a launch of its own behind this one)
         hipLaunchKernelGGL(prox_l1inf_cols_kernel, dim3((unsigned)cols), dim3(64), 0, E->stream, aux, x, u,
                            h_side ? (int64_t)1 : (int64_t)E->kp, h_side ? E->np : (int64_t)1, E->k, rho, lam, ub,
-                           0, &E->state->flag);
+                           0, &E->state->flag, st);
         if (update_dual) {
             const int64_t count = h_side ? (int64_t)E->kp * E->np : E->mp * (int64_t)E->kp;
             hipLaunchKernelGGL(dual_update_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, E->stream, aux, x, u,
-                               count, &E->state->flag);
+                               count, &E->state->flag, st);
         }
     }
     NMFX_HIP(hipGetLastError());

@@ -249,6 +249,7 @@ inline int nmfx_enter_family(nmfx_engine* E, int fam) {
 }
 int nmfx_ensure_obj_capacity(nmfx_engine* E, int64_t need);
 void nmfx_comm_free(nmfx_engine* E);      // comm.hip
+void nmfx_comm_invalidate(nmfx_engine* E);   // nmfx_set_precision: renegotiate, drop the captured graph, objective back to the f64 buffer
 // kernels_generic.hip: MUR for k > 128 (kp a multiple of 128), same phase protocol
 int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j);
 int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_t min_iter, double tol1, double tol2, int64_t j);
@@ -290,7 +291,7 @@ int nmfx_need_v(nmfx_engine* E);
 int nmfx_allow_lds(nmfx_engine* E, const void* kernel, int bytes);
 
 // prox 'l1inf' / 'l1inf_transpose' of ADMM (kernels_prox.hip): X = prox(X_aux, dual) on the W or the H side
-int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual);
+int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double rho, double lam, double ub, bool update_dual, bool ao = false);
 
 int nmfx_preload_bf16();
 int nmfx_preload_products();

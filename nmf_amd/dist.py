@@ -135,7 +135,7 @@ class DeviceShard:
         is short of memory for the tile-major copies (nmfx_get_note): such a rank would otherwise send one collective more
         than its peers, or chunks of another size -- a hang or mis-paired reductions.  Every rank offers what IT can do, the
         minimum over the group wins, and ranks whose arithmetic modes differ fail loudly.  Once per (shard, group)."""
-        key = id(comm)
+        key = (id(comm), self.eng.precision_epoch)     # (Engine.set_precision voids what was settled: ADVICE r3)
         if self._negotiated == key:
             return
         import os
@@ -317,12 +317,13 @@ class NativeShard(DeviceShard):
         self.eng.set_factors(w0_local, h0)
 
     def negotiate(self, comm):
-        if self._negotiated == id(comm):
+        key = (id(comm), self.eng.precision_epoch)     # (nmfx_set_precision voids the library's side as well)
+        if self._negotiated == key:
             return
         self.eng.comm_negotiate()            # NmfxError (NMFX_E_STATE) when the ranks' arithmetic modes differ
         self._merged = self.eng.comm_info()[2]
         self._chunk_unit = int(self.eng.mur_chunk_info(0)[0] or 0)       # (the library keeps the negotiated unit itself)
-        self._negotiated = id(comm)
+        self._negotiated = key
 
 
 class NativeComm:
@@ -892,16 +893,14 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
             a[...] = t.cpu().numpy()
     else:
         w0, h0 = utils.initial_factors(_Shape(m, n), k, nndsvd_init, uniform=(method == 'anls'))
-    # on RCCL the exchange runs behind the C ABI (NativeShard / NativeComm: the engine's own communicator and stream, the MUR loop as
-    # one C call); NMFX_DIST_NATIVE=0 keeps torch.distributed's collectives on torch's stream between the phase calls
-    import os
-    native = shard_factory is None and on_gpu and os.environ.get("NMFX_DIST_NATIVE", "1") != "0"
-    if native:
-        shard = NativeShard(v_local, k, w0[r0:r1], h0, dev.index or 0)
-        comm = NativeComm.create(shard)
+    # The exchange: torch.distributed's collectives on torch's stream between the phase calls (the default), or -- NMFX_DIST_NATIVE=1 --
+    # behind the C ABI (NativeShard / NativeComm: the engine's own RCCL communicator and stream, the MUR loop as one C call).  The
+    # native path stays OPT-IN until a run with more than one rank on RCCL has been recorded (it has only ever run with a
+    # world of one), and every rank takes the same branch: the choice is all-reduced before and after the communicator comes up.
+    if shard_factory is not None:
+        shard = shard_factory(v_local, k, w0[r0:r1], h0)
     else:
-        make = shard_factory or (lambda v, kk, w, h: DeviceShard(v, kk, w, h, dev.index or 0))
-        shard = make(v_local, k, w0[r0:r1], h0)
+        shard, comm, _ = make_sharded(lambda cls: cls(v_local, k, w0[r0:r1], h0, dev.index or 0), rank, dev, on_gpu)
     run_kw = {key: val for key, val in kw.items()
               if key not in ('nndsvd_init', 'use_fcnnls')}
     try:
@@ -920,6 +919,53 @@ def factorize(data, k, method='mur', *, gather=True, device=None, backend=None, 
         if hasattr(shard, "close"):
             shard.close()
     return Results(w, res.h, res.i, res.obj_history, experiment)
+
+
+def make_sharded(build, rank, dev, on_gpu, want_native=None, break_native=False):
+    """This rank's shard and its exchange: (shard, comm, name of the loop).  `build(cls)` makes the shard (DeviceShard or
+    NativeShard).  Native = RCCL behind the C ABI (nmfx_comm_init_rank + nmfx_mur_run_sharded, no torch on the data path): taken when
+    `want_native` (default: NMFX_DIST_NATIVE=1) and EVERY rank can bind RCCL and bring its communicator up -- a rank that raised
+    before a broadcast or inside ncclCommInitRank would leave its peers blocked, so the outcome of each step is MIN-all-reduced and
+    all ranks fall back to torch.distributed's collectives together."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as tdist
+    if want_native is None:
+        want_native = os.environ.get("NMFX_DIST_NATIVE", "0") == "1"
+    want = bool(on_gpu and want_native)
+
+    def all_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    if want:
+        ok = True
+        try:
+            from .engine import Engine
+            Engine.comm_unique_id()                     # binds RCCL (dlopen) or raises
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"rank {rank}: RCCL behind the C ABI is not available ({e}); torch.distributed's collectives instead\n")
+            ok = False
+        want = all_ok(ok)
+    if want:
+        shard = build(NativeShard)
+        comm, ok = None, True
+        try:
+            if break_native:                            # (rehearsal of this fall-back)
+                raise RuntimeError("native communicator disabled for a rehearsal")
+            comm = NativeComm.create(shard)             # ncclCommInitRank on every rank
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"rank {rank}: the communicator behind the C ABI did not come up ({e}); torch.distributed's collectives instead\n")
+            ok = False
+        if all_ok(ok):
+            return shard, comm, "native (nmfx_mur_run_sharded: RCCL behind the C ABI)"
+        if comm is not None:                            # some other rank failed: everybody takes the torch path
+            comm.close()
+        shard.eng.close()
+    shard = build(DeviceShard)
+    return shard, TorchComm(stage_through_host=not on_gpu), "torch.distributed collectives between the phase calls"
 
 
 class _Shape:

@@ -21,6 +21,7 @@ class Engine:
         h = C.c_void_p()
         L.check(self.lib.nmfx_create(C.byref(h), int(device), self.m, self.n, self.k))
         self.h = h
+        self.precision_epoch = 0
         note = self.lib.nmfx_get_note(h)
         if note:                                  # e.g. the fall back to the exact-f32 kernels for lack of memory
             logging.warning('nmf_amd: %s', note.decode())
@@ -56,6 +57,7 @@ class Engine:
         """'f32' (exact f32 MFMA) or 'bf16' (split-bf16 products: every solver's Euclidean products and MUR-KL's
         quotient products when k pads to 64 or 128)."""
         self._ck(self.lib.nmfx_set_precision(self.h, {"f32": 0, "bf16": 1}[mode]))
+        self.precision_epoch += 1           # row-sharded drivers negotiate the collective sequence again (dist.*Shard.negotiate)
 
     def precision(self):
         return "bf16" if self.lib.nmfx_get_precision(self.h) == 1 else "f32"

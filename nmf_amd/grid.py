@@ -22,6 +22,7 @@ import numpy as np
 
 from .engine import Engine
 from . import utils
+from ._driver import Referee
 
 _METHODS = ('mur', 'anls', 'admm', 'ao_admm')
 
@@ -112,21 +113,30 @@ def _mur_eu_grid_in_pairs(data, solver, features, lambda_w, lambda_h, save_dir, 
             nxt = i + 1
             if big is not None and combos[i][0] <= 64 and nxt < len(combos) and combos[nxt][0] <= 64:
                 a, b = combos[i], combos[nxt]
+                rng_state = np.random.get_state()
                 res = mur_pair(data, a[0], [dict(k=a[0], lambda_w=a[1], lambda_h=a[2]), dict(k=b[0], lambda_w=b[1], lambda_h=b[2])],
                                engine=big, device=device, **pair_kw)
+                # A pair runs on the plain device rule; single runs referee the rule in float64 once the recorded objective's jitter
+                # is no longer negligible against tol2 (nmf_amd._driver.Referee).  Where that referee would have armed, the pair's
+                # stop index may differ from the sequential grid's: run the two combinations again singly, from the same RNG state
+                # (tight tolerances on large matrices only).
+                tol2 = common.get('tol2', 1e-5)
+                if any(r.i < common.get('max_iter', 100000) - 1 and Referee.would_arm(r.obj_history, tol2) for r in res):
+                    np.random.set_state(rng_state)
+                    res = [run_single(i), run_single(nxt)]
                 out[i], out[nxt] = res
+                done_now = (i, nxt)
                 i += 2
             else:
                 out[i] = run_single(i)
+                done_now = (i,)
                 i += 1
+            if save_dir is not None:                           # after every run, like the sequential loop: a late failure keeps the earlier files
+                for q in done_now:
+                    _save(data, combos[q][0], out[q], save_dir)
     finally:
         if big is not None:
             big.close()
         for eng in singles.values():
             eng.close()
-    runs = []
-    for (k, lw, lh), res in zip(combos, out):
-        runs.append((dict(features=k, lambda_w=lw, lambda_h=lh), res))
-        if save_dir is not None:
-            _save(data, k, res, save_dir)
-    return runs
+    return [(dict(features=k, lambda_w=lw, lambda_h=lh), res) for (k, lw, lh), res in zip(combos, out)]

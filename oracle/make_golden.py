@@ -100,7 +100,7 @@ def run_solver(method, v, k, seed, kwargs):
     return res, text, inner
 
 
-def solver_case(name, method, vspec, k, seed, kwargs, snaps=(1, 2, 10)):
+def solver_case(name, method, vspec, k, seed, kwargs, snaps=(1, 2, 10), extra=None):
     if ONLY and name not in ONLY:
         return
     v = make_v(vspec)
@@ -135,6 +135,8 @@ def solver_case(name, method, vspec, k, seed, kwargs, snaps=(1, 2, 10)):
         r2, _, _ = run_solver(method, make_v(vspec), k, seed, kw)
         data[f"snap{s}_w"] = r2.w
         data[f"snap{s}_h"] = r2.h
+    if extra:
+        data.update(extra)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
     print(f"{name:34s} i={res.i:4d} obj0={res.obj_history[0]:.6g} objN={res.obj_history[-1]:.6g} "
           f"rule={rule} inner={len(inner)//2}")
@@ -283,6 +285,35 @@ def main():
     solver_case("aoadmm_eu_converge", "ao_admm", dict(kind="planted", rank=6, seed=14, m=90, n=70), 6, 14,
                 dict(distance_type="eu", reg_w=(0, "nn"), reg_h=(0, "nn"),
                      min_iter=3, max_iter=200, admm_iter=10, tol1=1e-9, tol2=1e-4), snaps=(1,))
+    # prox 'l1inf' / 'l1inf_transpose' in ao_admm (ao_admm.py:143-195): the operator wipes a factor out and the next Cholesky
+    # factorisation raises LinAlgError -- after 0, 1 or 2 completed outer iterations, depending on the placement.  Per placement:
+    # the LARGEST max_iter (<= 6) the reference completes (fixture = that run; none when the first iteration already raises)
+    # and `raises_at` = the max_iter at which it raises (-1: it does not within 6).
+    L = dict(kind="planted", rank=6, seed=21, m=96, n=80)
+    raises = {}
+    for tag, reg_w, reg_h in (("w_l1inf", (0.1, "l1inf"), (0, "nn")), ("w_l1inf_t", (0.1, "l1inf_transpose"), (0, "nn")),
+                              ("h_l1inf", (0, "nn"), (0.1, "l1inf")), ("h_l1inf_t", (0, "nn"), (0.1, "l1inf_transpose"))):
+        name = "aoadmm_eu_" + tag
+        if ONLY and name not in ONLY:
+            continue
+        last_ok, raises_at = 0, -1
+        for mx in range(1, 7):
+            kw = dict(distance_type="eu", reg_w=reg_w, reg_h=reg_h, min_iter=mx, max_iter=mx, admm_iter=10)
+            try:
+                run_solver("ao_admm", make_v(L), 6, 22, kw)
+                last_ok = mx
+            except np.linalg.LinAlgError:
+                raises_at = mx
+                break
+        raises[tag] = raises_at
+        if last_ok:
+            solver_case(name, "ao_admm", L, 6, 22,
+                        dict(distance_type="eu", reg_w=reg_w, reg_h=reg_h, min_iter=last_ok, max_iter=last_ok, admm_iter=10),
+                        snaps=(), extra=dict(raises_at=np.int64(raises_at)))
+        else:
+            print(f"{name:34s} raises LinAlgError in its first outer iteration (no fixture)")
+    if raises and not ONLY:
+        assert raises["h_l1inf"] == 1, raises        # (tests/test_gpu_aoadmm.py relies on it: no fixture for this placement)
     # ---- ADMM ----
     D = dict(kind="planted", rank=8, seed=15, m=128, n=96)
     solver_case("admm_eu_nn", "admm", D, 8, 16,

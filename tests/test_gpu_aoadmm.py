@@ -54,6 +54,42 @@ def test_aoadmm_error_behaviour():
             U.initial_factors = orig
 
 
+@pytest.mark.parametrize("name", ["aoadmm_eu_w_l1inf", "aoadmm_eu_w_l1inf_t", "aoadmm_eu_h_l1inf_t"])
+def test_aoadmm_l1inf_runs_like_the_reference_until_its_cholesky_fails(name):
+    """SURVEY a12 (nmf/ao_admm.py:143-195): with 'l1inf' / 'l1inf_transpose' the reference completes 0-2 outer iterations -- the
+    operator wipes a factor out -- and then raises scipy's LinAlgError in the next Cholesky factorisation.  The fixtures are the
+    reference's last completed run and the max_iter at which it raises; the device must return the former and raise at the latter."""
+    from nmf_amd.ao_admm import ao_admm
+    z, meta, v, res = run_fixture(name, ao_admm)
+    assert res.i == int(z["i"]) and len(res.obj_history) == res.i + 2
+    assert wh_error(res.w, res.h, z["w"], z["h"], v) < WH_TOL
+    np.testing.assert_allclose(res.obj_history, z["obj_history"], rtol=OBJ_RTOL)
+    assert np.array_equal(ao_admm.last_inner_counts, z["inner"]), (ao_admm.last_inner_counts, z["inner"])
+    # a factor the reference left at exactly zero is exactly zero here too
+    for got, ref in ((res.w, z["w"]), (res.h, z["h"])):
+        if not np.any(ref):
+            assert not np.any(got)
+    bad = int(z["raises_at"])
+    assert bad == int(z["i"]) + 2
+    with pytest.raises(np.linalg.LinAlgError):
+        run_fixture(name, ao_admm, min_iter=bad, max_iter=bad)
+
+
+def test_aoadmm_l1inf_on_h_fails_in_the_first_outer_iteration_like_the_reference():
+    """reg_h = 'l1inf' (oracle/make_golden.py asserts it for the reference): H = 0 after the first H sub-problem, H H^T + rho I = 0."""
+    from nmf_amd.ao_admm import ao_admm
+    from oracle import nmf_ref as R
+    v = R.fixture_matrix(dict(kind="planted", rank=6, seed=21, m=96, n=80))
+    kw = dict(distance_type="eu", reg_w=(0, "nn"), reg_h=(0.1, "l1inf"), min_iter=1, max_iter=1, admm_iter=10)
+    np.random.seed(22)
+    with pytest.raises(np.linalg.LinAlgError):
+        with np.errstate(all="ignore"):
+            R.ao_admm(v.astype(np.float64), 6, **kw)
+    np.random.seed(22)
+    with pytest.raises(np.linalg.LinAlgError):
+        ao_admm(v.copy(), 6, **kw)
+
+
 def test_aoadmm_kl_matches_reference():
     from nmf_amd.ao_admm import ao_admm
     z, meta, v, res = run_fixture("aoadmm_kl_nn", ao_admm)

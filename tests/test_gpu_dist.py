@@ -366,6 +366,58 @@ def test_factorize_api_two_ranks_on_one_gpu(tmp_path):
     np.testing.assert_allclose(z["ao_obj"], ref.obj_history, rtol=2e-5)      # (measured: 1.2e-6)
 
 
+def _api_native_worker(rank, world, rdzv, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from nmf_amd import dist as nd
+    from oracle import nmf_ref as R
+    v = R.planted_matrix(600, 260, 12, seed=41, dtype=np.float32)
+    out = {}
+    taken = []
+    real = nd.make_sharded
+    nd.make_sharded = lambda *a, **kw: (lambda r: (taken.append(r[2]), r)[1])(real(*a, **kw))
+    for tag, env, brk in (("torch", None, False), ("native", "1", False), ("broken", "1", True)):
+        if env is None:
+            os.environ.pop("NMFX_DIST_NATIVE", None)
+        else:
+            os.environ["NMFX_DIST_NATIVE"] = env
+        create = nd.NativeComm.create
+        if brk:                                          # the communicator does not come up on this rank: everybody falls back
+            nd.NativeComm.create = staticmethod(lambda shard: (_ for _ in ()).throw(RuntimeError("no communicator (test)")))
+        try:
+            np.random.seed(7)
+            res = nd.factorize(v, 12, method="mur", backend="nccl", distance_type="eu", min_iter=10, max_iter=10)
+        finally:
+            nd.NativeComm.create = create
+        out[tag + "_w"], out[tag + "_h"], out[tag + "_obj"] = res.w, res.h, np.asarray(res.obj_history)
+    out["taken"] = np.array(taken)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_factorize_takes_the_native_exchange_only_on_request_and_falls_back_together(tmp_path):
+    """nmf_amd.dist.factorize on RCCL runs torch.distributed's collectives by default; NMFX_DIST_NATIVE=1 asks for the
+    communicator behind the C ABI, and a rank on which it does not come up takes every rank to the torch path (the outcome of each
+    step is all-reduced: nmf_amd.dist.make_sharded) instead of leaving its peers in a collective.  World of one on RCCL."""
+    from oracle import nmf_ref as R
+    spawn_ranks(_api_native_worker, (1, None, str(tmp_path)), 1)
+    z = np.load(tmp_path / "rank0.npz")
+    taken = [str(t) for t in z["taken"]]
+    assert taken[0].startswith("torch.distributed") and taken[1].startswith("native") and taken[2].startswith("torch.distributed"), taken
+    v = R.planted_matrix(600, 260, 12, seed=41, dtype=np.float32)
+    np.random.seed(7)
+    ref = R.mur(v.astype(np.float64), 12, distance_type="eu", min_iter=10, max_iter=10)
+    for tag in ("torch", "native", "broken"):
+        assert np.linalg.norm(z[tag + "_w"] @ z[tag + "_h"] - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+        np.testing.assert_allclose(z[tag + "_obj"], ref.obj_history, rtol=1e-6)
+    np.testing.assert_array_equal(z["torch_obj"], z["broken_obj"])
+
+
 @pytest.mark.parametrize("launch", ["torchrun", "self"])
 def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) and as a plain

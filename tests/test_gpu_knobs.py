@@ -215,3 +215,27 @@ def test_refereed_stop_equals_the_oracles_stop_index(solver, monkeypatch):
     assert res.i == ref.i and len(res.obj_history) == res.i + 2, (res.i, ref.i)
     assert np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)
+
+
+def test_refereed_stop_at_the_first_tested_index(monkeypatch):
+    """a run that has converged before min_iter stops at loop index min_iter + 1 in the reference (nmf/mur.py:131).  With the
+    referee armed (guard > 0) the device's candidate IS that index; the walk can only test indices behind a candidate, so it used to
+    return min_iter + 2 with one history entry too many.  The recorded pair now confirms the candidate (Referee.confirms)."""
+    from oracle import nmf_ref as R
+    from nmf_amd.mur import mur
+    monkeypatch.setenv("NMFX_VERIFY_STOP", "1")
+    m, n, k = 300, 260, 36
+    v = R.planted_matrix(m, n, k, seed=77, dtype=np.float32)
+    kw = dict(distance_type="eu", max_iter=3000, tol1=1e-9, tol2=5e-3)
+    np.random.seed(3)
+    i0 = R.mur(v.astype(np.float64), k, min_iter=5, **kw).i
+    min_iter = max(i0 + 40, 80)                      # (beyond the first batch of 64: the guard is armed when the first test comes)
+    np.random.seed(3)
+    ref = R.mur(v.astype(np.float64), k, min_iter=min_iter, **kw)
+    np.random.seed(3)
+    res = mur(v.copy(), k, min_iter=min_iter, **kw)
+    assert ref.i == min_iter + 1
+    rf = mur.last_referee
+    assert rf.guard > 0 and rf.confirmed == 1 and rf.walked == 0, (rf.guard, rf.confirmed, rf.walked)
+    assert res.i == ref.i and len(res.obj_history) == ref.i + 2, (res.i, ref.i, len(res.obj_history))
+    assert np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
