@@ -291,18 +291,34 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
 
         run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 2 * (warmup + steps) + 8)
 
-        run(0, warmup + steps)                          # untimed rehearsal (lazy allocations, pools), then from the start again
-        fence()
-        shard.eng.set_factors(w0, h0)
-        run(0, warmup)
-        fence()
-        t0 = time.perf_counter()
-        run(warmup, steps)
-        fence()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item()) / steps
+        def timed():
+            run(0, warmup + steps)                      # untimed rehearsal (lazy allocations, pools), then from the start again
+            fence()
+            shard.eng.set_factors(w0, h0)
+            run(0, warmup)
+            fence()
+            t0 = time.perf_counter()
+            run(warmup, steps)
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / steps
+
+        # The chunked exchange (NMFX_DIST_CHUNKS, DESIGN 5: the all-reduce of a column chunk of [W^T V] behind the product of the
+        # next one) can only be settled on a multi-GPU node: both forms are timed in the same run.  The
+        # slot's iter_per_s is the form the environment asked for (default: one piece); the other one rides along.
+        asked = max(1, int(os.environ.get("NMFX_DIST_CHUNKS", "1") or 1))
+        by_chunks = {}
+        for nch in sorted({1, 2, asked}):
+            os.environ["NMFX_DIST_CHUNKS"] = str(nch)
+            try:
+                by_chunks[nch] = timed()
+            except Exception as e:  # noqa: BLE001  (every rank runs the same sequence: a failure here is the same on all of them)
+                by_chunks[nch] = f"{type(e).__name__}: {e}"
+        os.environ["NMFX_DIST_CHUNKS"] = str(asked)
+        if not isinstance(by_chunks[asked], float):
+            raise RuntimeError(by_chunks[asked])
+        dt = by_chunks[asked]
         _, _, n_obj = shard.eng.state()
         obj = shard.eng.objectives(0, n_obj)
         ok = bool(np.all(np.isfinite(obj)) and obj[-1] < obj[0])
@@ -313,6 +329,8 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
                 "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
                 "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
                 "precision": shard.eng.precision(), "loop": loop + " / " + run.mode, "objective_first_last": [float(obj[0]), float(obj[-1])],
+                "exchange_chunks": asked,
+                "ms_per_step_by_exchange_chunks": {str(c): (v * 1e3 if isinstance(v, float) else v) for c, v in by_chunks.items()},
                 "objective_decreasing": ok, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
                 "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
@@ -323,6 +341,69 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
         shard.eng.close()
         del shard
         torch.cuda.empty_cache()
+
+
+def scaling_model(torch, dev, base_ms):
+    """What CAN be measured about N = 2 / 4 / 8 on one GPU: one rank's step of the row-sharded loop -- phase A,
+    pack, exchange, phase B through nmfx_mur_run_sharded, RCCL behind the C ABI with a world of ONE (the collective is a local copy)
+    -- at the per-rank shapes of configs 2 and 5, and a stated model of the all-reduce that is missing from it, so that the first
+    SCALE record has something to be checked against.  base_ms: measured single-GPU ms per iteration of the two configs."""
+    from nmf_amd import dist as nd
+    NEVER = 10 ** 12
+    # All-reduce model (an ASSUMPTION until a multi-GPU node has run it; MI355X_MICROARCH: 7 xGMI links x ~153 GB/s per GPU, a ring
+    # is bound by one link): t = alpha(N) + 2 (N - 1) / N * bytes / beta, alpha = launch + 2 (N - 1) hops of ~2.5 us, beta = 0.8 x 153 GB/s
+    beta = 0.8 * 153e9
+    alpha = {2: 12e-6, 4: 22e-6, 8: 42e-6}
+    out = {"all_reduce_model": {"formula": "t = alpha(N) + 2 (N - 1) / N * bytes / beta", "alpha_us": {str(q): a * 1e6 for q, a in alpha.items()},
+                                "beta_gbs": beta / 1e9, "status": "assumed (ring over one xGMI link per direction); not hidden behind compute in the prediction"},
+           "per_rank_step": "measured: nmfx_mur_run_sharded with a world of one on RCCL (the N > 1 code path; its collective moves nothing)",
+           "configs": {}}
+    for cfg, (m, n, k, steps) in (("cfg2", (16384, 8192, 64, 40)), ("cfg5", (131072, 16384, 128, 6))):
+        rows_out = []
+        for world in (2, 4, 8):
+            rows = m // world
+            rs = np.random.RandomState(0)
+            w0, h0 = np.abs(rs.randn(rows, k)), np.abs(rs.randn(k, n))
+            try:
+                shard = nd.NativeShard(None, k, w0, h0, dev.index or 0, shape=(rows, n),
+                                       fill=lambda e: device_planted(e, torch, m, n, k, 0, dev, rows=(0, rows)))
+            except Exception as e:  # noqa: BLE001
+                rows_out.append({"n_gpus": world, "error": f"{type(e).__name__}: {e}"})
+                continue
+            try:
+                comm = nd.NativeComm(shard, 0, 1, shard.eng.comm_unique_id())
+                shard.negotiate(comm)
+                eng = shard.eng
+                eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 0, 2 * steps)       # clocks, pools, lazy allocations
+                eng.synchronize()
+                eng.set_factors(w0, h0)
+                eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 0, 3)
+                eng.synchronize()
+                t0 = time.perf_counter()
+                eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 3, steps)
+                eng.synchronize()
+                step = (time.perf_counter() - t0) / steps
+                _, _, n_obj = eng.state()
+                obj = eng.objectives(0, n_obj)
+                assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], f"scaling_model {cfg} N={world}: bad objective history"
+                n32 = shard.xf32.count
+                nbytes = 4.0 * n32 if shard.merge_objective() else 4.0 * n32 + 64
+                t_ar = alpha[world] + 2.0 * (world - 1) / world * nbytes / beta
+                pred = step + t_ar
+                rows_out.append({"n_gpus": world, "rows_per_rank": rows, "measured_step_us_world_of_one": step * 1e6,
+                                 "all_reduce_bytes": nbytes, "collectives_per_iteration": 1 if shard.merge_objective() else 2,
+                                 "model_all_reduce_us": t_ar * 1e6, "predicted_iter_per_s": 1.0 / pred,
+                                 "predicted_speedup_vs_1_gpu": (base_ms[cfg] * 1e-3 / pred) if base_ms.get(cfg) else None,
+                                 "upper_bound_speedup_without_exchange": (base_ms[cfg] * 1e-3 / step) if base_ms.get(cfg) else None})
+                comm.close()
+            except Exception as e:  # noqa: BLE001
+                rows_out.append({"n_gpus": world, "rows_per_rank": rows, "error": f"{type(e).__name__}: {e}"})
+            finally:
+                shard.eng.close()
+                del shard
+                torch.cuda.empty_cache()
+        out["configs"][cfg] = {"shape": [m, n, k], "ms_per_iteration_on_1_gpu": base_ms.get(cfg), "ranks": rows_out}
+    return out
 
 
 def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None,
@@ -478,6 +559,14 @@ def other_configs(torch, dev, only=None):
              flops=lambda t: 4.0 * 16384 * 8192 * 256 + 2.0 * 256 * 256 * (16384 + 8192) + 2.0 * 256 * 256 * (t[0] * 8192 + t[1] * 16384)
              + 2.0 * 256 ** 3 / 3,
              nbytes=lambda t: 2.0 * 16384 * 8192 * 4 + 8.0 * 256 * 4 * (t[0] * 8192 + t[1] * 16384)),
+        # ADMM (nmf/admm.py:292-334) beyond 128 components: V-sized products with FOUR split-bf16 terms (they are fed back through the
+        # unshifted-rho Gram systems), the objective of (w, h) by one more product; algorithmic work: three V-sized products
+        dict(name="admm_k256_on_cfg2_shape", workload="ADMM Euclidean, rho = 1, reg_w = (0, 'nn'), reg_h = (0.1, 'l1n'), V=16384x8192 f32, k=256, "
+                                                      "0.05 |randn| start (composed path, split-bf16 products with four terms)",
+             m=16384, n=8192, k=256, steps=8, warmup=3, init="randn_small", bound="mfma_bf16x3",
+             queue=lambda e, f, c: e.admm_run(0, 1.0, 0, 0.0, 1, 0.1, NEVER, 1e-5, 1e-5, f, c),
+             flops=6.0 * 16384 * 8192 * 256 + 4.0 * 256 * 256 * (16384 + 8192) + 4.0 * 256 ** 3 / 3,
+             nbytes=3.0 * 16384 * 8192 * 4 + 10.0 * (16384 + 8192) * 256 * 4),
     ]
     for sp in specs:
         if only and sp["name"] not in only:
@@ -804,9 +893,16 @@ def main():
             others = [cfg5_sharded(torch, dist, nd, rank, world, local_rank)]
         except Exception as e:  # noqa: BLE001  (reported in its slot, never hidden; a rank that failed alone would hang the others'
             others = [{"config": "cfg5", "error": f"{type(e).__name__}: {e}"}]          # collectives -- the driver's timeout ends that)
+    smodel = None
     if rank == 0 and world == 1 and not sharded and not args.no_others and (m, n, k) == (M, N, K):
         eng.close()               # free the HBM: config 5 on one GPU holds three 8 GiB copies of V
         others = other_configs(torch, torch.device(f"cuda:{local_rank}"))
+        try:
+            c5 = next((o for o in others if o.get("config") == "cfg5_on_1_gpu" and "ms_per_step" in o), None)
+            smodel = scaling_model(torch, torch.device(f"cuda:{local_rank}"),
+                                   {"cfg2": dt / args.steps * 1e3, "cfg5": c5["ms_per_step"] if c5 else None})
+        except Exception as e:  # noqa: BLE001
+            smodel = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and roof is not None and not args.no_traffic:
         eng.close()               # free the HBM before the child passes allocate their own
@@ -856,6 +952,7 @@ def main():
                           "frac_of_hbm_peak": iter_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS / world},
             "kernels": prof,
             "other_configs": others,
+            "scaling_model": smodel,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

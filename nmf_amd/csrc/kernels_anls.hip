@@ -192,7 +192,9 @@ __global__ __launch_bounds__(KP <= 64 ? 256 : 128) void nnls_bpp_kernel(
         if (idx[t] < KP) X[(int64_t)idx[t] * sj + c * sc] = (valid[t] && x[t] > 0.f) ? x[t] : 0.f;
 }
 
+#ifdef NMFX_NNLS_STATS          // experiment builds only (tools/anls_perf.py --stats), like the other nmfx_debug_* exports: not part of include/nmfx.h
 __device__ unsigned long long nnls_dbg[8];     // [sum of iterations, max, problems, exchanges in back-up mode, pivots, final support]
+#endif
 
 // Register-resident variant for k <= 64 (one variable per lane, one right-hand side per wave):
 // lane i keeps row i of G in registers, the elimination works on a register copy with the pivot
@@ -299,9 +301,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #endif
 }
 
-extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {     // build with -DNMFX_NNLS_STATS
+#ifdef NMFX_NNLS_STATS
+extern "C" int nmfx_debug_nnls_stats(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnls_dbg), sizeof(nnls_dbg)) == hipSuccess ? 0 : -1;
 }
+#endif
 
 // k = 128: two waves per right-hand side (thread = variable), rows in registers, the pivot row
 // handed over through a double-buffered LDS row (one barrier per pivot), the masks of the two

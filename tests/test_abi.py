@@ -24,6 +24,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in nmfx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     assert lib.nmfx_version() >= 100
+    # ... and nothing beyond the header (a debug export had slipped out of an experiment build's #ifdef)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True) if nm else None
+    if out is not None and out.returncode == 0:
+        exported = sorted(set(re.findall(r"\bT (nmfx_[a-z0-9_]+)$", out.stdout, flags=re.M)))
+        assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_error_codes_without_device():

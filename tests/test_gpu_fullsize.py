@@ -152,6 +152,74 @@ def test_config5_shard_mur_eu_16384x16384_k128_vs_oracle():
     assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
 
 
+def _cfg5_sharded_worker(rank, world, rdzv, outdir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)     # (carries the 128-byte RCCL id only)
+    from nmf_amd import dist as nd
+    from oracle import nmf_ref as R
+    m, n, k, iters = 16384, 16384, 128, 3
+    v = R.planted_matrix(m, n, k, seed=5, dtype=np.float32)
+    rs = np.random.RandomState(0)                       # nmf/mur.py:108-109
+    w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+    out = {}
+    for tag, env in (("one_piece", {}), ("two_chunks", {"NMFX_DIST_CHUNKS": "2"}), ("graph", {"NMFX_DIST_GRAPH": "1"})):
+        for key in ("NMFX_DIST_CHUNKS", "NMFX_DIST_GRAPH"):
+            os.environ.pop(key, None)
+        os.environ.update(env)
+        shard = nd.NativeShard(v, k, w0, h0, 0)
+        comm = nd.NativeComm.create(shard)
+        shard.negotiate(comm)
+        res = nd.mur_sharded(shard, comm, distance_type="eu", min_iter=iters + (1 if tag == "graph" else 0),
+                             max_iter=iters + (1 if tag == "graph" else 0), graph=(tag == "graph") or None)
+        out[tag + "_w"], out[tag + "_h"], out[tag + "_obj"] = res.w, res.h, np.asarray(res.obj_history)
+        out[tag + "_merged"] = int(shard.merge_objective())
+        out[tag + "_replays"] = shard.eng.comm_graph_replays()
+        shard.close()
+    np.savez(os.path.join(outdir, "rank0.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_config5_shard_through_the_sharded_entry_points_vs_oracle(tmp_path):
+    """config 5's per-rank shard (131072 / 8 rows x 16384, k = 128) through the ROW-SHARDED loop -- pack, exchange
+    (world of one on RCCL, behind the C ABI: nmfx_mur_run_sharded), phase B -- instead of the single-GPU mur(): one piece, two column
+    chunks with the all-reduce of chunk 0 on the side stream behind the product of chunk 1, and the hipGraph replay of iteration pairs.
+    Every form against the float64 oracle; the chunked and replayed runs bit-identical to the eager one-piece run where the
+    arithmetic is the same (the graph run does one iteration more: compared on the common prefix)."""
+    from conftest import spawn_ranks
+    spawn_ranks(_cfg5_sharded_worker, (1, None, str(tmp_path)), 1)
+    z = np.load(tmp_path / "rank0.npz")
+    m, n, k, iters = 16384, 16384, 128, 3
+    v = R.planted_matrix(m, n, k, seed=5, dtype=np.float32)
+    rs = np.random.RandomState(0)
+    w0, h0 = np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n))
+    ref = R.mur(v, k, w0=w0, h0=h0, distance_type="eu", min_iter=iters + 1, max_iter=iters + 1, snapshots=(iters,))
+    ref3_w, ref3_h = ref.trace["snap"][iters]
+    for tag in ("one_piece", "two_chunks"):
+        err = wh_error_blocked(z[tag + "_w"], z[tag + "_h"], ref3_w, ref3_h, v)
+        print(f"\nPARITY sharded {tag}: WH {err:.2e}, merged objective {int(z[tag + '_merged'])}")
+        assert err < WH_TOL, (tag, err)
+        np.testing.assert_allclose(z[tag + "_obj"], ref.obj_history[:iters + 1], rtol=1e-6)
+    err = wh_error_blocked(z["graph_w"], z["graph_h"], ref.w, ref.h, v)
+    assert err < WH_TOL, err
+    np.testing.assert_allclose(z["graph_obj"], ref.obj_history, rtol=1e-6)
+    assert int(z["graph_replays"]) >= 1 and int(z["one_piece_replays"]) == 0
+    # replayed launches = the eager ones, bit for bit (the LAST objective of a run comes from the closing objective-only pass, another
+    # order of additions than the one fused into the next iteration's W phase: compared up to the one before it)
+    np.testing.assert_array_equal(z["graph_obj"][:iters], z["one_piece_obj"][:iters])
+    # (the chunked form sums its slabs in another order -- more reduction splits per column chunk: 3e-9 relative, not bit-identical)
+    assert int(z["one_piece_merged"]) == 1              # one collective per iteration (objective inside the f32 buffer)
+
+
 def test_admm_fixed_rho_8192x4096_k64_vs_oracle():
     """ADMM with the caller's fixed rho = 1 (nmf/admm.py:216-230): cond(G + rho I) grows with m, and the
     device applies an explicit inverse -- the shape where that would show."""

@@ -84,6 +84,8 @@ for k in (256,):
         e.admm_run(L.EU, 1.0, L.PROX['nn'], 0.0, L.PROX['l1n'], 0.1, NEVER, 1e-5, 1e-5, 3, steps)
         e.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        e.state()
+        _, _, n_obj = e.state()
+        obj = e.objectives(0, n_obj)                     # (r3 read slot 3 + steps, which only a finish call writes: "objective": [0.0])
+        assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], obj
         print(json.dumps({"k": k, "solver": "admm eu nn/l1n rho=1", "ms_per_iter": dt * 1e3, "iter_per_s": 1 / dt,
-                          "objective": e.objectives(3 + steps, 1).tolist()}), flush=True)
+                          "objective_first_last": [float(obj[0]), float(obj[-1])]}), flush=True)
