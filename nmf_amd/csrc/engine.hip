@@ -229,7 +229,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
                     E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work,
                     E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1],
-                    E->sk[0].seg, E->sk[0].first, E->sk[0].cnt, E->sk[0].slabs, E->sk[1].seg, E->sk[1].first, E->sk[1].cnt, E->sk[1].slabs};
+                    E->kl_S[0], E->kl_S[1], E->kl_DV[0], E->kl_DV[1], E->sk[0].seg, E->sk[0].first, E->sk[0].cnt, E->sk[0].slabs, E->sk[1].seg, E->sk[1].first, E->sk[1].cnt, E->sk[1].slabs};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;
@@ -371,9 +371,11 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     }
     if (hmat) { if ((rc = put_padded(E, E->H, hmat, E->k, E->n, E->kp, E->np))) return rc; }
     // (S, DV: the m x n auxiliaries of the KL-loss ADMM variants start from zero, ao_admm.py:17-30)
-    float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH, E->S, E->DV};
-    const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np, E->mp * E->np, E->mp * E->np};
-    for (int i = 0; i < 6; ++i)
+    float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH, E->S, E->DV, E->kl_S[0], E->kl_DV[0], E->kl_S[1], E->kl_DV[1]};
+    const int64_t mn = E->mp * E->np;
+    const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np, mn, mn, mn, mn, mn, mn};
+    E->kl_side = 0;                                    // (split-bf16 form of the same state: zero in both orientations)
+    for (int i = 0; i < 10; ++i)
         if (zero[i]) NMFX_HIP(hipMemsetAsync(zero[i], 0, (size_t)zc[i] * 4, E->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);
     E->wsel = 0;

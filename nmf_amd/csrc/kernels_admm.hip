@@ -167,6 +167,71 @@ static int admm_kl_iteration(nmfx_engine* E, double rho, int prox_w, double lam_
     return admm_kl_update(E, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j);
 }
 
+// The KL-loss iteration on the split-bf16 kernels (r4; one GPU, k padded to 64 or 128; NMFX_KL_BF16=0 keeps the exact-f32 launches):
+// both right-hand sides from the SAME S = v_aux + dual_v (admm.py:303-305) -- w_aux^T S on the copy of S in the orientation of V^T
+// (kl_S[0]), S h_aux^T on the one the auxiliaries write (kl_S[1], rows m) --, the two halves as in the exact path, then the m x n
+// auxiliaries where the product w_aux h_aux stands in the accumulators (admm.py:311-314) and the transposed copy of the new S.
+static bool admm_kl_bf16(const nmfx_engine* E) {
+    static const bool on = !(getenv("NMFX_KL_BF16") && atoi(getenv("NMFX_KL_BF16")) == 0);
+    return on && admm_bf16(E);
+}
+
+static int admm_kl_objective_bf16(nmfx_engine* E) {     // KL(V, w h) partials from the images of (w, h): one pass over the tile-major V
+    int rc;
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+    return nmfx_bf16_kl_objective(E);
+}
+
+static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                                  int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const int64_t nobj32 = E->obj_count;                               // partials of the KL objective pass that closed the iteration before
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_kl_state(E, false))) return rc;
+    // ---- h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T S + rho (h + dual_h)) ----
+    if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // (w_aux)^T images: Y
+    if ((rc = nmfx_bf16_kl_product(E, 0, 4))) return rc;
+    if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);
+    else {
+        if ((rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
+        rc = nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj32);
+    }
+    if (rc) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, rho))) return rc;
+    if (prox_h == NMFX_PROX_L2N) {
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+        if ((rc = nmfx_inner_cols(E, E->Ph, E->auxH, 2, prox_h, (float)lam_h, 0))) return rc;
+    } else if (prox_h == NMFX_PROX_L1INF || prox_h == NMFX_PROX_L1INF_T) {
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox_h, (float)lam_h, 0))) return rc;
+        if ((rc = nmfx_launch_prox_l1inf(E, true, prox_h == NMFX_PROX_L1INF_T, rho, lam_h, 1.0, true))) return rc;
+    } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc;
+    // ---- w_aux from the NEW h_aux ----
+    if ((rc = nmfx_bf16_images_h(E, false, E->auxH))) return rc;       // h_aux images: Y of the product and of the auxiliaries
+    if ((rc = nmfx_bf16_kl_product(E, 1, 4))) return rc;
+    if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, rho))) return rc;
+    if (prox_w == NMFX_PROX_L2N) {
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Pw, E->auxW, 2, prox_w, (float)lam_w, 0))) return rc;
+    } else if (prox_w == NMFX_PROX_L1INF || prox_w == NMFX_PROX_L1INF_T) {
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
+        if ((rc = nmfx_launch_prox_l1inf(E, false, prox_w == NMFX_PROX_L1INF_T, rho, lam_w, 1.0, true))) return rc;
+    } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc;
+    // ---- v_aux, dual_v from w_aux h_aux; the new S in both orientations ----
+    if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // the new w_aux: Z
+    if ((rc = nmfx_bf16_vaux(E, 1))) return rc;
+    E->kl_side = 1;
+    if ((rc = nmfx_bf16_kl_orient(E, 0, false))) return rc;            // (kl_S[1] stays valid: the W-side product of the next iteration reads it)
+    E->wimg_ok = false; E->himg_both = false;
+    return admm_kl_objective_bf16(E);                                  // KL objective of (w, h) (admm.py:324)
+}
+
 extern "C" int nmfx_set_l2n_operator(nmfx_handle_t E, int which, const double* p) {
     if (!E || !p || (which != 0 && which != 1)) { if (E) E->err = "set_l2n_operator: bad argument"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
@@ -224,6 +289,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
         if (E->kp > 128) return NMFX_OK;               // (nmfx_generic_admm_run evaluates the initial objective itself)
         if (distance == NMFX_EU) rc = admm_objective(E);
+        else if (admm_kl_bf16(E) && any_k) rc = admm_kl_objective_bf16(E);      // (any_k: nmfx_admm_run; the row-sharded phases keep the exact-f32 pass their pack counts on)
         else rc = nmfx_launch_wphase(E, E->W[0], false, true, true);
         if (rc) return rc;
     }
@@ -257,7 +323,8 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? admm_eu_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)
-            : admm_kl_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
+            : admm_kl_bf16(E) ? admm_kl_iteration_bf16(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)
+                              : admm_kl_iteration(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
         if (rc) return rc;
     }
     return NMFX_OK;

@@ -1603,6 +1603,77 @@ static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     return nmfx_launch_wphase(E, W, false, true, true);            // KL objective (utils.py:21-26)
 }
 
+// The KL-loss iteration on the split-bf16 kernels (r4; k padded to 64 or 128, one GPU; NMFX_KL_BF16=0 keeps the exact-f32 launches
+// above).  Per round of a sub-problem: the right-hand side product with S in the place of V (the Euclidean product kernel on the
+// tile-major S), the round kernel, the images of the aux matrix, and the m x n auxiliaries where the product W h_aux stands in the
+// accumulators (xyt32_bf16_kernel<..., VAUX>).  S and dual_v live tile-major in the orientation of the sub-problem (rows n for H,
+// rows m for W) and are transposed at the two switches of an outer iteration.  16384 x 8192, k = 128, ten rounds each: 26.0 -> see
+// DESIGN 4b (the exact-f32 auxiliaries alone took 933 us per round).
+static bool ao_kl_bf16(const nmfx_engine* E) {
+    static const bool on = !(getenv("NMFX_KL_BF16") && atoi(getenv("NMFX_KL_BF16")) == 0);
+    return on && ao_bf16(E);
+}
+
+// KL(V, W H) partials of the current pair from the images of W and H (split-bf16 product, one pass over the tile-major V)
+static int ao_kl_objective(nmfx_engine* E) {
+    int rc;
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_images_w(E, E->W[0], 0))) return rc;
+    E->wimg_ok = true;
+    if ((rc = nmfx_bf16_images_h(E, false))) return rc;
+    return nmfx_bf16_kl_objective(E);
+}
+
+static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, int prox_h, double lam_h,
+                                    int admm_iter, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    int rc;
+    float* W = E->W[0];
+    const int64_t kk = (int64_t)E->kp * E->kp;
+    const int* stop = &E->state->inner_stop;
+    const int64_t nobj32 = E->obj_count;                               // partials of the KL objective pass that closed the iteration before (ao_kl_objective)
+    if ((rc = nmfx_bf16_prepare(E))) return rc;
+    if ((rc = nmfx_bf16_kl_state(E, false))) return rc;
+    // ---- H sub-problem (state in the orientation of V^T) ----
+    if ((rc = nmfx_bf16_kl_orient(E, 0, true))) return rc;
+    if (!E->wimg_ok && (rc = nmfx_bf16_images_w(E, W, 0))) return rc;  // W^T images: Y of the products and of the auxiliaries (left by the objective pass)
+    for (int r = 0; r < admm_iter; ++r) {
+        E->xyt_flag2 = r > 0 ? stop : nullptr;
+        rc = nmfx_bf16_kl_product(E, 0, 4);                            // B^T slabs = S^T W (four terms: fed back through the Gram system)
+        E->xyt_flag2 = nullptr;
+        if (rc) return rc;
+        if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);
+        else {
+            if (r == 0 && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
+            rc = nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj32);
+        }
+        if (rc) return rc;
+        if (r == 0 && (rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
+        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, r))) return rc;
+        if ((rc = nmfx_bf16_images_h(E, true, E->auxH))) return rc;    // (h_aux)^T images: Z of the auxiliaries
+        if ((rc = nmfx_bf16_vaux(E, 0, stop))) return rc;
+    }
+    if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
+    // ---- W sub-problem (transposed data: the orientation of V) ----
+    if ((rc = nmfx_bf16_kl_orient(E, 1, true))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, false))) return rc;                // H images: Y
+    if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
+    if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
+    if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
+    for (int r = 0; r < admm_iter; ++r) {
+        E->xyt_flag2 = r > 0 ? stop : nullptr;
+        rc = nmfx_bf16_kl_product(E, 1, 4);                            // A slabs = S H^T
+        E->xyt_flag2 = nullptr;
+        if (rc) return rc;
+        if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
+        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, r))) return rc;
+        if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;       // w_aux images: Z
+        if ((rc = nmfx_bf16_vaux(E, 1, stop))) return rc;
+    }
+    if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
+    E->himg_both = false;
+    return ao_kl_objective(E);                                         // KL objective of the new pair (utils.py:21-26)
+}
+
 extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double lambda_w, int prox_h,
                                double lambda_h, int admm_iter, int64_t min_iter, double tol1, double tol2,
                                int64_t first, int64_t count) {
@@ -1629,13 +1700,17 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
             ? nmfx_generic_aoadmm_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count)
             : nmfx_generic_aoadmm_kl_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count);
     if (distance != NMFX_EU) { E->lazy_objective = false; E->himg_both = false; }
+    if (distance == NMFX_KL && ao_kl_bf16(E) && (first == 0 || E->obj_count <= 0)) E->wimg_ok = false;
     if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
-        if ((rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL))) return rc;
+        if (distance == NMFX_KL && ao_kl_bf16(E)) rc = ao_kl_objective(E);
+        else rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL);
+        if (rc) return rc;
     }
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? aoadmm_eu_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
-            : aoadmm_kl_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
+            : ao_kl_bf16(E) ? aoadmm_kl_iteration_bf16(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
+                            : aoadmm_kl_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
         if (rc) return rc;
     }
     return NMFX_OK;

@@ -627,17 +627,33 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 struct XytSide {                 // the side job: Minv = (sum of gslabs slabs of gsrc + rho I)^-1, rho = trace / k (fixed_rho < 0) -- nmf/ao_admm.py:53-55
     const float* gsrc; int gslabs; int k; float* Minv; DevState* st; double fixed_rho;
 };
-template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true, int NW = 8, bool SK = false>
+// VAUX = true (r4; with WITH_OBJ, without the A-product): the m x n auxiliaries of the KL-loss ADMM variants instead of the residual --
+// nmf/ao_admm.py:87-93, nmf/admm.py:306-314: with P = Z Y (= w h_aux, or its transpose) where the accumulator stands,
+//   v_bar = P - dual_v;  v_aux = ((v_bar - 1) + sqrt((v_bar - 1)^2 + 4 v)) / 2;  dual_v += v_aux - P;  S = v_aux + dual_v
+// dual_v (vaux_dv) and S (vaux_s: the only form in which v_aux enters the next right-hand side) are TILE-MAJOR like X, in the
+// orientation of X.  They are streamed straight to / from registers: the loads of group g + 1 go out behind the barrier of group g,
+// the stores of group g behind the barrier of group g + 1 (stores count in vmcnt as well: issued at the END of a group they would
+// sit in front of the next group's counted waits).  The counted waits of the V loaders hold for the steady state only (groups
+// with three predecessors and three successors: 24 / 20 younger loads); the first and last groups of a block drain the queue.
+template <bool WITH_OBJ, int TERMS, int ABL = 0, bool KL = false, int KP = 64, int NPROB = 1, bool TEMPORAL = false, bool WITH_A = true, int NW = 8, bool SK = false,
+          int VMODE = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const float* __restrict__ X, int64_t ldx,
     const unsigned short* __restrict__ Yhi, const unsigned short* __restrict__ Ylo, int64_t ldy,
     const unsigned short* __restrict__ Zhi, const unsigned short* __restrict__ Zlo,
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
     int ngroups, const int* __restrict__ flag, int ng,
-    const int4* __restrict__ sk_seg = nullptr, const int* __restrict__ sk_first = nullptr, int sk_workers = 0, XytSide side = XytSide())
+    const int4* __restrict__ sk_seg = nullptr, const int* __restrict__ sk_first = nullptr, int sk_workers = 0, XytSide side = XytSide(),
+    float* __restrict__ vaux_dv = nullptr, float* __restrict__ vaux_s = nullptr, const int* __restrict__ flag2 = nullptr)
 {
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
+    if (flag2 && *flag2) return;                       // (the inner stop of a KL-ADMM sub-problem has fired: a no-op like every later round)
+    // VMODE 1 = VAUX (above); VMODE 2 = the KL objective of (Z, Y) alone -- sum x log(x / zy) [inf, nan -> 0] - x + zy, nmf/utils.py:21-26 --
+    // where the objective-only form evaluates the residual: the closing objective of the KL-loss ADMM variants (r4; the exact-f32 pass
+    // took 400 us at 16384 x 8192, k = 128)
+    constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2;
+    static_assert(VMODE == 0 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
     static_assert(!SK || (KP == 128 && !KL && NPROB == 1 && NW == 8 && WITH_A && ABL == 0), "stream-K: the Euclidean k = 128 products");
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
@@ -850,6 +866,52 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 2; ++e) va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
     };
+    // VAUX: the lane's 16 elements of a group -- row n31 of its row group, 16-byte chunks 8 hh + 4 s + 2 b + e -- of dual_v (in) and
+    // of the new S / dual_v (out), at the positions of the tile-major X.  The loads are inline asm: hipcc does not count the LDS-DMA
+    // requests in its own vmcnt bookkeeping and would put its waits where it believes the loads are the only ones in flight.
+    f32x4 vx_cur[2][2], vx_next[2][2];
+    float4 vx_s[2][2], vx_d[2][2];
+    const unsigned vx_lane = (unsigned)(((rg * 32 + n31) * 64 + 4 * (8 * hh + 2 * b)) * 4);      // bytes; + 64 s + 16 e, + the tile
+    auto vaux_tile = [&](int grp) { return ((int64_t)bx * (ldx / 64) + grp) * 8192; };           // floats (NW = 8: one tile per block and group)
+    auto vaux_load = [&](int grp, f32x4 (&dst)[2][2]) {
+        const unsigned long long src = (unsigned long long)(vaux_dv + vaux_tile(grp));
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:64\n\tglobal_load_dwordx4 %3, %4, %5 offset:80"
+                     : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[1][0]), "=&v"(dst[1][1]) : "v"(vx_lane), "s"(src) : "memory");
+    };
+    auto vaux_store = [&](int grp) {
+        const int64_t off = vaux_tile(grp) + vx_lane / 4;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                *reinterpret_cast<float4*>(vaux_s + off + 16 * s2 + 4 * e) = vx_s[s2][e];
+                *reinterpret_cast<float4*>(vaux_dv + off + 16 * s2 + 4 * e) = vx_d[s2][e];
+            }
+    };
+    auto vaux_update = [&](const VRegs& v) {           // d[4 a + c] <-> va[a >> 1][a & 1], component c
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(vx_cur[s2][e]));      // (behind the counted wait: the uses stay below it)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 x4 = v.va[a >> 1][a & 1];
+            const f32x4 u4 = vx_cur[a >> 1][a & 1];
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            float so[4], uo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float p = v.d[4 * a + c];
+                const float t = (p - u4[c]) - 1.f;
+                const float va_ = 0.5f * (t + __builtin_sqrtf(t * t + 4.f * xs[c]));
+                uo[c] = u4[c] + (va_ - p);
+                so[c] = va_ + uo[c];
+            }
+            vx_s[a >> 1][a & 1] = make_float4(so[0], so[1], so[2], so[3]);
+            vx_d[a >> 1][a & 1] = make_float4(uo[0], uo[1], uo[2], uo[3]);
+        }
+    };
     Frag8 fh[2][2], fl[2][2];                          // Y fragments: [register set][fragment]
     // PIPE: the LAST stage of a group (residual k-steps 2, 3; its fragments are in register set 1 by then) is carried
     // over the next group's barrier and runs while that group's first fragment reads are in flight -- with nothing but
@@ -868,6 +930,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         NMFX_STAMP(ts0);
         if (ABL & 1) { }
         else if (yrole) dma_wait_le<0>();
+        else if (VAUX) {                               // steady state: 12 (VRING - 1) loads are younger than V(grp) (see the kernel's VAUX note)
+            if (grp >= g0 + VRING && grp + VRING - 1 < g1) dma_wait_le<12 * (VRING - 1)>(); else dma_wait_le<0>();
+        }
         else if (PIPE) {                               // V(grp + 1) must have landed; V(grp + 2) (, V(grp + 3): VRING = 4) may stay in flight
             const int ahead = g1 - 2 - grp;
             if (VRING >= 4 && ahead >= 2) dma_wait_le<16>(); else if (ahead >= 1) dma_wait_le<8>(); else dma_wait_le<0>();
@@ -882,6 +947,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         // burst at the top of the group they cost 500-800 cycles per loader wave with the matrix pipe idle (stamps)
         const bool dma_on = PIPE && !(ABL & 1) && (yrole ? grp + 1 < g1 : grp + VRING < g1);
         if (!PIPE && yrole) { if (grp + 1 < g1) issue_y(); }
+        if constexpr (VAUX) {
+            vaux_load(grp + 1 < g1 ? grp + 1 : grp, vx_next);       // (behind the last group: a harmless reload, so that every group issues the same)
+            if (grp > g0) vaux_store(grp - 1);
+        }
         const unsigned char* ybuf = smem + ycur * YBUF;
         const unsigned char* vt = vring + vcur * VSLOT;
         const unsigned char* vtn = vring + (vcur == VRING - 1 ? 0 : vcur + 1) * VSLOT;
@@ -1007,7 +1076,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 }
             }
         }
-        if (WITH_OBJ && !PIPE) residual(cur, NPROB == 2 ? osum2 : osum);          // (PIPE: one group late, see above)
+        if constexpr (VAUX) {
+            // dual_v of this group: requested a group ago.  V loaders: 20 younger loads in the steady state (V(grp + VRING - 1), dual_v and V of
+            // this group); Y loaders: their wait at the top of the group has drained it
+            if (!yrole) { if (grp >= g0 + 1 && grp + VRING < g1) dma_wait_le<20>(); else dma_wait_le<0>(); }
+            vaux_update(cur);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) vx_cur[s2][e] = vx_next[s2][e];
+        }
+        else if constexpr (KLOBJ) {
+            float k0 = 0.f, k1 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 x4 = cur.va[a >> 1][a & 1];
+                const float vv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // x log(x / p) - x + p = p ((1 + u) log(1 + u) - u), u = (x - p) / p.  Near the optimum the objective is 1e-5 of
+                    // sum x, so the three-term form cancels five digits and the hardware log / rcp (1 ulp, slightly biased)
+                    // showed as 8e-5 of the objective at 16384 x 8192; for |u| <= 1/8 the series sum_{k >= 2} (-u)^k / (k (k - 1))
+                    // has no cancellation at all (next term 1e-8 relative).  Elsewhere the reference's expression, with its
+                    // inf / nan -> 0 (x = 0 or p = 0: u is -1, inf or nan, never small)
+                    const float pv = cur.d[4 * a + c], rp = __builtin_amdgcn_rcpf(pv);
+                    const float u = (vv[c] - pv) * rp;
+                    const float poly = 0.5f + u * (-1.f / 6.f + u * (1.f / 12.f + u * (-1.f / 20.f + u * (1.f / 30.f + u * (-1.f / 42.f + u * (1.f / 56.f))))));
+                    float t = vv[c] * (__builtin_amdgcn_logf(vv[c] * rp) * 0.69314718055994531f);
+                    t = (t != t || t == __builtin_inff()) ? 0.f : t;
+                    const float term = (__builtin_fabsf(u) <= 0.125f) ? pv * (u * u) * poly : (t - vv[c]) + pv;
+                    if (c & 1) k1 += term; else k0 += term;
+                }
+            }
+            osum += (double)(k0 + k1);
+        }
+        else if (WITH_OBJ && !PIPE) residual(cur, NPROB == 2 ? osum2 : osum);          // (PIPE: one group late, see above)
         NMFX_STAMP(ts4);
 #ifdef NMFX_EXP_STAMPS
         acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_early += ts3 - ts2; acc_mfma += ts4 - ts3;
@@ -1315,6 +1418,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
+    if constexpr (VAUX) { if (g0 < g1) vaux_load(g0, vx_cur); }       // (behind the V requests above; the first group's waits drain it)
     if (KL && KP == 128) {
         for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
         osum += 0.69314718055994531 * olog;
@@ -1334,6 +1438,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
             if (grp + 1 < g1) group(grp + 1, Q, P);
         }
     }
+    if constexpr (VAUX) { if (g0 < g1) vaux_store(g1 - 1); }
     if (PIPE && g0 < g1) {                             // the last group's carried stage and residual
         if ((g1 - g0) & 1) { carried_stage(P.d, false); residual(P, osum); } else { carried_stage(Q.d, false); residual(Q, osum); }
     }
@@ -1379,7 +1484,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
             for (int r = 0; r < 4; ++r)
                 go[(int64_t)(16 * git + 4 * g + r) * KP + 16 * (gj0 + c) + x] = gacc[c][r];
     }
-    if (WITH_OBJ) {
+    if (WITH_OBJ && !VAUX) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) osum += __shfl_down(osum, off, 64);
         double* red = reinterpret_cast<double*>(smem + 4 * NT * 4096);      // behind the exchange slots
@@ -1388,7 +1493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < NW; ++w) t += red[w];
-            objpart[oidx] = (KL ? 1.0 : 0.5) * t;
+            objpart[oidx] = ((KL || KLOBJ) ? 1.0 : 0.5) * t;
         }
         if (NPROB == 2) {
 #pragma unroll
@@ -1423,6 +1528,22 @@ __global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __res
     for (int r = ty; r < 64; r += 4) tile[r][tx] = in[(r0 + r) * ldi + c0 + tx];
     __syncthreads();
     float* dst = out + ((c0 >> 7) * (rows_in >> 6) + blockIdx.y) * 8192 + (c0 & 64) * 64;
+    for (int c = ty; c < 64; c += 4) dst[c * 64 + tx] = tile[tx][c];
+}
+
+// out = in^T, both TILE-MAJOR (in: R x C as tiles [128][64], out: C x R as tiles [128][64]): the m x n state of the KL-loss ADMM
+// variants changes orientation between the two sub-problems (r4)
+__global__ __launch_bounds__(256) void tile_transpose_kernel(const float* __restrict__ in, int64_t R, int64_t C, float* __restrict__ out,
+                                                              const int* __restrict__ flag)
+{
+    if (*flag) return;
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const float* src = in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192 + (r0 & 64) * 64;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[r * 64 + tx];
+    __syncthreads();
+    float* dst = out + ((c0 >> 7) * (R >> 6) + blockIdx.y) * 8192 + (c0 & 64) * 64;
     for (int c = ty; c < 64; c += 4) dst[c * 64 + tx] = tile[tx][c];
 }
 
@@ -1985,7 +2106,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
                                                              : xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
             int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
             hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide());
+                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2);
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
         }
@@ -2026,7 +2147,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
 #endif
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide());
+                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2224,6 +2345,93 @@ int nmfx_bf16_vtw(nmfx_engine* E, bool obj, const char* name, bool kl, int terms
                       E->kp == 64 ? E->G_part : nullptr, name, kl, E->gram_ng_h, terms);
 }
 
+// ---- KL-loss ADMM variants on the split-bf16 kernels (r4) ----
+// State: S = v_aux + dual_v and dual_v, tile-major, in the orientation of the sub-problem at hand -- side 0 (H sub-problem): rows n
+// like Vt (E->kl_S[0], kl_DV[0]); side 1 (W sub-problem): rows m like Vtile (kl_S[1], kl_DV[1]).
+int nmfx_bf16_kl_state(nmfx_engine* E, bool reset) {
+    int rc;
+    const int64_t cnt = E->mp * E->np;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = lazy_alloc(E, &E->kl_S[i], cnt))) return rc;
+        if ((rc = lazy_alloc(E, &E->kl_DV[i], cnt))) return rc;
+    }
+    if (reset) {           // v_aux = dual_v = 0 (ao_admm.py:28-30, admm.py:31-35: both names are bound to ONE array of zeros)
+        for (int i = 0; i < 2; ++i) {
+            NMFX_HIP(hipMemsetAsync(E->kl_S[i], 0, (size_t)cnt * sizeof(float), E->stream));
+            NMFX_HIP(hipMemsetAsync(E->kl_DV[i], 0, (size_t)cnt * sizeof(float), E->stream));
+        }
+        E->kl_side = 0;
+    }
+    return NMFX_OK;
+}
+
+// bring the state into the orientation of `side` (a no-op when it is there)
+int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv) {
+    if (E->kl_side == side) return NMFX_OK;
+    ProfScope ps(E, "transpose");
+    const int from = E->kl_side;
+    const int64_t R = from == 0 ? E->np : E->mp, C = from == 0 ? E->mp : E->np;
+    const dim3 grid((unsigned)(C / 64), (unsigned)(R / 64));
+    hipLaunchKernelGGL(tile_transpose_kernel, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
+    if (with_dv)
+        hipLaunchKernelGGL(tile_transpose_kernel, grid, dim3(256), 0, E->stream, (const float*)E->kl_DV[from], R, C, E->kl_DV[side], &E->state->flag);
+    NMFX_HIP(hipGetLastError());
+    E->kl_side = side;
+    return NMFX_OK;
+}
+
+// the m x n auxiliaries (see xyt32_bf16_kernel<..., VAUX>): side 0: X = V^T, Y = W^T images, Z = (h_aux)^T images (HThi / HTlo);
+// side 1: X = V, Y = H-like images (Hhi / Hlo), Z = W-like images (Whi / Wlo[0]); flag2: optional second skip flag (the inner stop)
+int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2) {
+    ProfScope ps(E, "kl_vaux");
+    const float* X = side == 0 ? E->Vt : E->Vtile;
+    const int64_t ldx = side == 0 ? E->mp : E->np, R = side == 0 ? E->np : E->mp;
+    const int splits = side == 0 ? E->bt_split : E->bf_wsplit;
+    const unsigned short* Yhi = side == 0 ? E->WThi : E->Hhi;
+    const unsigned short* Ylo = side == 0 ? E->WTlo : E->Hlo;
+    const unsigned short* Zhi = side == 0 ? E->HThi : E->Whi[0];
+    const unsigned short* Zlo = side == 0 ? E->HTlo : E->Wlo[0];
+    if (!E->kl_S[side] || !Zhi) { E->err = "vaux: state or images missing"; return NMFX_E_STATE; }
+    const dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+    const size_t shm = 160 * 1024;
+    auto k64 = xyt32_bf16_kernel<true, 3, 0, false, 64, 1, false, false, 8, false, 1>;
+    auto k128 = xyt32_bf16_kernel<true, 3, 0, false, 128, 1, false, false, 8, false, 1>;
+    auto kern = E->kp == 64 ? k64 : k128;
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, (float*)nullptr, E->obj_part, (float*)nullptr, R,
+                       (int)(ldx / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), E->kl_DV[side], E->kl_S[side], flag2);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// obj_part[(mp / 128) * bf_wsplit] = KL(V, W H) partials from the images Whi / Wlo[0] and Hhi / Hlo (one pass over the tile-major V)
+int nmfx_bf16_kl_objective(nmfx_engine* E) {
+    ProfScope ps(E, "objective");
+    const dim3 grid((unsigned)(E->mp / 128), (unsigned)E->bf_wsplit), block(512);
+    const size_t shm = 160 * 1024;
+    auto k64 = xyt32_bf16_kernel<true, 3, 0, false, 64, 1, false, false, 8, false, 2>;
+    auto k128 = xyt32_bf16_kernel<true, 3, 0, false, 128, 1, false, false, 8, false, 2>;
+    auto kern = E->kp == 64 ? k64 : k128;
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
+    E->obj_count = (E->mp / 128) * E->bf_wsplit;
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, (const float*)E->Vtile, E->np, (const unsigned short*)E->Hhi, (const unsigned short*)E->Hlo, E->np,
+                       (const unsigned short*)E->Whi[0], (const unsigned short*)E->Wlo[0], (float*)nullptr, E->obj_part, (float*)nullptr, E->mp,
+                       (int)(E->np / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr,
+                       (const int*)nullptr);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// the two right-hand-side products with S in the place of V (slabs as nmfx_bf16_vtw / nmfx_bf16_vht leave them; no objective)
+int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2) {
+    (void)flag2;       // (a product behind the inner stop is wasted work, not a wrong result: its consumers are no-ops)
+    if (side == 0)
+        return launch_xyt(E, false, E->kl_S[0], true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
+                          E->Bt_part, E->kp == 64 ? E->G_part : nullptr, "hphase", false, E->gram_ng_h, terms);
+    return launch_xyt(E, false, E->kl_S[1], true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
+                      E->A_part, E->kp == 64 ? E->HHt_part : nullptr, "wphase_noobj", false, E->gram_ng_w, terms);
+}
+
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
 // r4 (behind a stream-K product): bcnt = slabs per 128-column block of B^T (bsplit = the slab stride's count is then unused),
 // Gpart = nullptr (the side job has summed the Gram slabs itself), st != nullptr: the objective is recorded as obj[j] here
@@ -2275,6 +2483,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(
         for (; p < gsplit; ++p) s2 += Gpart[(int64_t)p * KP * KP + i];
         xf32[bcount + i] = s2;
     } else {
+        if (nobj < 0) return;                          // (no objective behind this product: xf64[0] stays what it is)
         double t = 0.0;
         for (int64_t i = tid; i < nobj; i += 256) t += objpart[i];
 #pragma unroll
@@ -2389,7 +2598,7 @@ int nmfx_bf16_sk_product(nmfx_engine* E, int side, bool obj, const float* gsrc, 
     if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
     if (obj) E->obj_count = P.nseg;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, P.slabs, E->obj_part,
-                       (float*)nullptr, R, ngroups, &E->state->flag, 1, (const int4*)P.seg, (const int*)P.first, P.workers, job);
+                       (float*)nullptr, R, ngroups, &E->state->flag, 1, (const int4*)P.seg, (const int*)P.first, P.workers, job, (float*)nullptr, (float*)nullptr, (const int*)nullptr);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
