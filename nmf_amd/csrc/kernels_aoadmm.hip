@@ -393,6 +393,152 @@ __global__ __launch_bounds__(256) void ao_inner_rows_kernel(
     block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
 }
 
+// ---- the same two rounds for ANY padded rank (r4: k > 128, kernels_generic.hip) -------------------------------------------------
+// One launch per round beyond 128 components as well (r3: right-hand side, product, prox / dual / norms and `terminate` were four
+// launches per round, 100 us where the arithmetic is 20).  Same protocol as the kernels above -- round r first re-derives the
+// decision of round r - 1 from the norm partials, the norm partials of round r go to nrm[r & 1] --, same MFMA product on
+// v_mfma_f32_16x16x4_f32 with a runtime contraction length: the right-hand side tile lives in LDS (kp x 64 floats on the H side,
+// 64 x (kp + 4) on the W side: kp <= 512), the rows of M^-1 (symmetric) are the other operand straight from L2.
+__global__ __launch_bounds__(256) void ao_round_cols_any_kernel(
+    const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, const float* __restrict__ Minv, int kp, int64_t np,
+    int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm)
+{
+    if (st->flag || st->inner_stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [kp][64] RHS + 16 doubles
+    double* sh = reinterpret_cast<double*>(lds + (int64_t)kp * 64);
+    const int nblk = gridDim.x, JT = kp / 16;
+    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_count = round + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    {   // RHS = B + rho (X + U)
+        const int srow = tid >> 4, sc = tid & 15;
+        for (int p = 0; p < JT; ++p) {
+            const int64_t g = (int64_t)(p * 16 + srow) * np + c0 + 4 * sc;
+            const float4 u = *reinterpret_cast<const float4*>(U + g), b = *reinterpret_cast<const float4*>(Bsum + g);
+            const float4 h = *reinterpret_cast<const float4*>(X + g);
+            *reinterpret_cast<float4*>(lds + (p * 16 + srow) * 64 + 4 * sc) =
+                make_float4(b.x + rho * (h.x + u.x), b.y + rho * (h.y + u.y), b.z + rho * (h.z + u.z), b.w + rho * (h.w + u.w));
+        }
+    }
+    __syncthreads();
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+    for (int it = wave; it < JT; it += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* mrow = Minv + (int64_t)(16 * it + x) * kp + 4 * q;
+        for (int u0 = 0; u0 < JT; u0 += 4) {           // (kp is a multiple of 128: JT of 8) four k-steps' operand loads in flight together
+            float4 mf[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) mf[uu] = *reinterpret_cast<const float4*>(mrow + 16 * (u0 + uu));
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const float ma[4] = {mf[uu].x, mf[uu].y, mf[uu].z, mf[uu].w};
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const float4 rb = *reinterpret_cast<const float4*>(lds + (16 * (u0 + uu) + 4 * q + s2) * 64 + 4 * x);
+                    acc[0] = MFMA(ma[s2], rb.x, acc[0]);
+                    acc[1] = MFMA(ma[s2], rb.y, acc[1]);
+                    acc[2] = MFMA(ma[s2], rb.z, acc[2]);
+                    acc[3] = MFMA(ma[s2], rb.w, acc[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t idx = (int64_t)(16 * it + 4 * q + g) * np + c0 + 4 * x;
+            const float ax[4] = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+            const float4 h = *reinterpret_cast<const float4*>(X + idx), u = *reinterpret_cast<const float4*>(U + idx);
+            const float hx[4] = {h.x, h.y, h.z, h.w}, ux[4] = {u.x, u.y, u.z, u.w};
+            float hn[4], un[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hn[e] = prox_apply(ax[e], ux[e], shift);
+                un[e] = ux[e] + hn[e] - ax[e];
+                const float d0 = hn[e] - ax[e], d2 = hn[e] - hx[e];
+                n0 += d0 * d0; n1 += hn[e] * hn[e]; n2 += d2 * d2; n3 += un[e] * un[e];
+            }
+            *reinterpret_cast<float4*>(X + idx) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+            *reinterpret_cast<float4*>(U + idx) = make_float4(un[0], un[1], un[2], un[3]);
+        }
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+}
+
+__global__ __launch_bounds__(256) void ao_round_rows_any_kernel(
+    const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U, const float* __restrict__ Minv, int kp,
+    int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm)
+{
+    if (st->flag || st->inner_stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [64][kp + 4] + 16 doubles
+    const int LD = kp + 4, JT = kp / 16;
+    double* sh = reinterpret_cast<double*>(lds + (int64_t)64 * LD);
+    const int nblk = gridDim.x;
+    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_count = round + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    const int64_t rb0 = (int64_t)blockIdx.x * 64;
+    for (int i = tid; i < 64 * (kp / 4); i += 256) {   // RHS = A + rho (X + U)
+        const int r = i / (kp / 4), c4 = i % (kp / 4);
+        const int64_t g = (rb0 + r) * kp + 4 * c4;
+        const float4 a = *reinterpret_cast<const float4*>(Asum + g), w = *reinterpret_cast<const float4*>(X + g);
+        const float4 d = *reinterpret_cast<const float4*>(U + g);
+        *reinterpret_cast<float4*>(lds + r * LD + 4 * c4) =
+            make_float4(a.x + rho * (w.x + d.x), a.y + rho * (w.y + d.y), a.z + rho * (w.z + d.z), a.w + rho * (w.w + d.w));
+    }
+    __syncthreads();
+    // wave w takes the column tiles w, w + 4, ... of all 64 rows: the rows of M^-1 it multiplies with come from L2 ONCE per block
+    // (with a wave per 16 rows every wave read all of M^-1: 52 us per round at k = 256 against 42 for the four launches it replaced)
+    const float* xrow = lds + x * LD + 4 * q;           // + 16 rt rows, + 16 u
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+    for (int it = wave; it < JT; it += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* mrow = Minv + (int64_t)(16 * it + x) * kp + 4 * q;
+        for (int u0 = 0; u0 < JT; u0 += 4) {
+            float4 mb[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) mb[uu] = *reinterpret_cast<const float4*>(mrow + 16 * (u0 + uu));
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const float4 xf = *reinterpret_cast<const float4*>(xrow + (16 * rt) * LD + 16 * (u0 + uu));
+                    acc[rt] = MFMA(xf.x, mb[uu].x, acc[rt]);
+                    acc[rt] = MFMA(xf.y, mb[uu].y, acc[rt]);
+                    acc[rt] = MFMA(xf.z, mb[uu].z, acc[rt]);
+                    acc[rt] = MFMA(xf.w, mb[uu].w, acc[rt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t idx = (rb0 + 16 * rt + 4 * q + g) * kp + 16 * it + x;
+                const float w = X[idx], d = U[idx], ax = acc[rt][g];
+                const float wn = prox_apply(ax, d, shift);
+                const float dn = d + wn - ax;
+                const float d0 = wn - ax, d2 = wn - w;
+                n0 += d0 * d0; n1 += wn * wn; n2 += d2 * d2; n3 += dn * dn;
+                X[idx] = wn; U[idx] = dn;
+            }
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+}
+
 // After the last round: record (rounds run | fired << 16) for this sub-problem.
 __global__ __launch_bounds__(256) void ao_inner_finish_kernel(
     DevState* __restrict__ st, const double* __restrict__ nrm, int nblk, int admm_iter,
@@ -1202,6 +1348,26 @@ static int inner_cols(nmfx_engine* E, int prox, float lam, int round) {
 
 static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round, const double* nrm_global = nullptr) {
     return nmfx_inner_rows(E, E->auxW, W, E->Minv, nullptr, 0, prox, lam, round, nrm_global);
+}
+
+// one round of a sub-problem at any padded rank up to 512 (see ao_round_*_any_kernel): X = H (cols) or W[0] (rows), its dual, B = the
+// summed right-hand side product ([kp][np] / [mp][kp]); nmfx_inner_finish(E, np / 64 | mp / 64, ...) closes the sub-problem
+int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round) {
+    if (E->kp > 512 || E->kp % 64) { E->err = "round_any: k padded to at most 512"; return NMFX_E_ARG; }
+    int rc;
+    if (cols) {
+        const size_t shm = (size_t)E->kp * 64 * sizeof(float) + 16 * sizeof(double);
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_cols_any_kernel), (int)shm))) return rc;
+        hipLaunchKernelGGL(ao_round_cols_any_kernel, dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, B, X, U, (const float*)E->Minv, E->kp,
+                           E->np, prox, lam, round, E->state, E->nrm_part);
+    } else {
+        const size_t shm = (size_t)64 * (E->kp + 4) * sizeof(float) + 16 * sizeof(double);
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_rows_any_kernel), (int)shm))) return rc;
+        hipLaunchKernelGGL(ao_round_rows_any_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, B, X, U, (const float*)E->Minv, E->kp,
+                           prox, lam, round, E->state, E->nrm_part);
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global) {

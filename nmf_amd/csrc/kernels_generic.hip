@@ -1291,6 +1291,12 @@ int gx_ao_subproblem(nmfx_engine* E, bool hside, const float* G, const float* B,
     const int64_t kp = E->kp, rows = hside ? kp : E->mp, cols = hside ? E->np : kp, cnt4 = rows * cols / 4;
     if ((rc = gx_prepare(E, G, -1.0))) return rc;
     ProfScope ps(E, hside ? "inner_h" : "inner_w");
+    static const bool one_launch = !(getenv("NMFX_GX_ROUNDS") && atoi(getenv("NMFX_GX_ROUNDS")) == 4);
+    if (one_launch && kp <= 512) {                     // r4: one launch per round (kernels_aoadmm.hip, ao_round_*_any_kernel)
+        for (int r = 0; r < admm_iter; ++r)
+            if ((rc = nmfx_round_any(E, hside, B, X, U, prox, lam, r))) return rc;
+        return nmfx_inner_finish(E, (int)((hside ? E->np : E->mp) / 64), admm_iter, slot);
+    }
     const int nblk = (int)((cnt4 + 255) / 256);
     const int* stop = &E->state->inner_stop;
     for (int r = 0; r < admm_iter; ++r) {

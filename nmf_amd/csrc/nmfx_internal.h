@@ -289,6 +289,7 @@ int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int pr
 int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
                     float lam, int round, const double* nrm_global = nullptr);
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
+int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round);   // k padded to <= 512: one launch per round
 
 // Row-major V for the kernels that read it (exact-f32 products, KL auxiliaries, the SVD): in split-bf16 mode it may
 // have been freed after the tile-major copies were built (drop_v) and is then rebuilt from Vtile.

@@ -49,6 +49,9 @@ CASES = [
     ({"NMFX_SK_CYCLIC": "0"}, "ao_admm", (384, 320, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_SK_WORKERS": "2"}, "ao_admm", (640, 512, 100), dict(reg_w=[0.05, "l1n"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_SK_WORKERS": "7"}, "ao_admm", (640, 512, 100), dict(reg_w=[0, "nn"], reg_h=[0.05, "l1n"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
+    # r4: the KL-loss variants run their V-sized products, auxiliaries and objective on the split-bf16 kernels; the exact-f32 launches
+    ({"NMFX_KL_BF16": "0"}, "ao_admm", (384, 320, 40), dict(distance_type="kl", reg_w=[0, "nn"], reg_h=[0.02, "l1n"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_KL_BF16": "0"}, "admm", (384, 320, 100), dict(rho=1.0, distance_type="kl", reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_CINV": "0"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),      # elimination kernels only
