@@ -122,6 +122,7 @@ __global__ __launch_bounds__((KP / 4) * (KP / 4) < 64 ? 64 : (KP / 4) * (KP / 4)
     }
 }
 
+#define NMFX_PREP_STAMPS_HERE
 #include "prepare_body.h"
 
 // the stand-alone launch: one workgroup of KP / 16 row waves + the helper wave

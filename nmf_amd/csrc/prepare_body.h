@@ -65,7 +65,7 @@ template <int P> __device__ __forceinline__ void gj16_pivot(f64x4& a, int c, int
     }
 }
 
-#ifdef NMFX_EXP_STAMPS         // experiment (tools/lab/prep_stamps.py): the timeline of the last blocked Gauss-Jordan launch, 10 ns ticks
+#if defined(NMFX_EXP_STAMPS) && defined(NMFX_PREP_STAMPS_HERE)   // experiment (tools/lab/prep_stamps.py): the timeline of the last blocked Gauss-Jordan launch, 10 ns ticks (kernels_aoadmm.hip only)
 __device__ unsigned long long nmfx_dbg_prep[9][40];            // [wave (8 = helper)][0 start, 1 loaded, 2 first tile inverted, 3 + 3 kb: step barrier | mid-step barrier | step done, 30 end]
 extern "C" int nmfx_debug_prep_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmfx_dbg_prep), sizeof(nmfx_dbg_prep)) == hipSuccess ? 0 : -1;

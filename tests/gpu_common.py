@@ -67,3 +67,15 @@ def direct_objective(v, w, h, kind="eu", block=2048):
         b = min(v.shape[0], a + block)
         tot += float(R.objective(np.asarray(v[a:b], dtype=np.float64), w[a:b] @ h, kind))
     return tot
+
+
+def oracle_after(ref_fn, v, k, seed, iterations, **kw):
+    """(w, h, obj_history) of the oracle after exactly `iterations` outer iterations (its stop rule off): what a device run that
+    stopped one iteration off the oracle's index is compared with -- the stop tests accept |i - i_ref| <= 1 where the firing
+    decrease sits at the resolution of an f32-grade objective, and must still pin the iterate."""
+    kw = dict(kw)
+    kw.update(min_iter=iterations, max_iter=iterations)
+    np.random.seed(seed)
+    with np.errstate(all="ignore"):
+        out = ref_fn(np.asarray(v, dtype=np.float64), k, **kw)
+    return out.w, out.h, np.asarray(out.obj_history)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from gpu_common import WH_TOL, wh_error
+from gpu_common import WH_TOL, oracle_after, wh_error
 from oracle import nmf_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -53,13 +53,23 @@ def test_mur_pair_problems_stop_independently():
     np.random.seed(3)
     sep = [mur(v.copy(), p["k"], distance_type="eu", lambda_w=p["lambda_w"], lambda_h=p["lambda_h"], **kw) for p in par]
     assert ref[0].i != ref[1].i and max(ref[0].i, ref[1].i) < 599, (ref[0].i, ref[1].i)
-    for g, s, r in zip(got, sep, ref):
+    for g, s, r, p in zip(got, sep, ref, par):
         assert abs(g.i - r.i) <= 1 and len(g.obj_history) == g.i + 2, (g.i, s.i, r.i)
         if g.i == s.i:
             assert _rel(g.w @ g.h, s.w @ s.h) < 2e-6
         if g.i == r.i:
             assert wh_error(g.w, g.h, r.w, r.h, v) < WH_TOL
             np.testing.assert_allclose(g.obj_history, r.obj_history, rtol=4e-5)
+    # whatever the index, the iterate is pinned: the oracle after exactly g.i + 1 iterations, both problems from the RNG stream
+    # the pair consumed (the |i - i_ref| <= 1 branch used to skip the comparison)
+    np.random.seed(3)
+    kw_n = {key: val for key, val in kw.items() if key not in ("min_iter", "max_iter")}
+    for g, p in zip(got, par):
+        with np.errstate(all="ignore"):
+            at = R.mur(v.astype(np.float64), p["k"], distance_type="eu", lambda_w=p["lambda_w"], lambda_h=p["lambda_h"],
+                       min_iter=g.i + 1, max_iter=g.i + 1, **kw_n)
+        assert wh_error(g.w, g.h, at.w, at.h, v) < WH_TOL
+        np.testing.assert_allclose(g.obj_history, at.obj_history, rtol=4e-5)
 
 
 def test_grid_runs_mur_eu_in_pairs_and_equals_the_oracle(capsys, monkeypatch):

@@ -3,7 +3,7 @@ Runs only on a real MI355X (`-m gpu`); everything goes through the C ABI."""
 import numpy as np
 import pytest
 
-from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
+from gpu_common import WH_TOL, oracle_after, run_fixture, snapshot_errors, wh_error
 from oracle import nmf_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +173,10 @@ def test_mur_eu_bf16_stop_index_matches_f32_and_oracle(monkeypatch):
     # this tol2 sits 2e-6 from the firing decrease (0.004998 against 5e-3): at the edge of what an f32-grade objective
     # resolves, so the split-bf16 mode may fire one iteration off here ...
     assert abs(out["bf16"].i - ref.i) <= 1, (out["bf16"].i, ref.i)
+    # ... with the iterate it returns pinned either way: the oracle's after that many iterations
+    w_o, h_o, obj_o = oracle_after(R.mur, v, 36, 3, out["bf16"].i + 1, **kw)
+    assert wh_error(out["bf16"].w, out["bf16"].h, w_o, h_o, v) < WH_TOL
+    np.testing.assert_allclose(out["bf16"].obj_history, obj_o, rtol=4e-5)
     # ... and must hit the reference's iteration exactly where the rule has a margin (tol2 between two consecutive
     # decreases, 1e-5 from either)
     dec = -np.diff(ref.obj_history)
