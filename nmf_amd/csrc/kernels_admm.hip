@@ -262,7 +262,7 @@ extern "C" int nmfx_prox_apply(nmfx_handle_t E, int side, int prox, double rho, 
 
 // argument checks, allocations and (for the first iteration) the start state w_aux = w, h_aux = h (admm.py:27-28)
 // with the objective partials of the initial pair (admm.py:289)
-static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count, bool any_k = false) {
+static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int prox_h, int64_t first, int64_t count, bool whole_run = false) {
     if (!E) return NMFX_E_ARG;
     E->anls_a_ready = false; E->kl_h_iter = -2;
     E->himg_both = false;
@@ -275,7 +275,6 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
     if (first < 0 || count < 0 || !(rho >= 0.0)) { E->err = "negative iteration range or rho"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
-    if (!any_k && (rc = nmfx_small_k_only(E, "row-sharded ADMM"))) return rc;
     if ((rc = nmfx_enter_family(E, 3))) return rc;
     if ((rc = admm_alloc(E))) return rc;
     if (distance == NMFX_KL && (rc = nmfx_kl_state_alloc(E))) return rc;
@@ -289,7 +288,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
         NMFX_HIP(hipMemcpyAsync(E->auxH, E->H, (size_t)E->kp * E->np * 4, hipMemcpyDeviceToDevice, E->stream));
         if (E->kp > 128) return NMFX_OK;               // (nmfx_generic_admm_run evaluates the initial objective itself)
         if (distance == NMFX_EU) rc = admm_objective(E);
-        else if (admm_kl_bf16(E) && any_k) rc = admm_kl_objective_bf16(E);      // (any_k: nmfx_admm_run; the row-sharded phases keep the exact-f32 pass their pack counts on)
+        else if (admm_kl_bf16(E) && whole_run) rc = admm_kl_objective_bf16(E);      // (nmfx_admm_run; the row-sharded phases keep the exact-f32 pass their pack counts on)
         else rc = nmfx_launch_wphase(E, E->W[0], false, true, true);
         if (rc) return rc;
     }
@@ -301,6 +300,7 @@ static int admm_begin(nmfx_engine* E, int distance, double rho, int prox_w, int 
 // all-reduced sums, the W half is local to the rank's rows; ADMM has no inner loop, so this is the only exchange) ----
 extern "C" int nmfx_admm_phase_products(nmfx_handle_t E, int distance, double rho, int prox_w, int prox_h, int64_t j) {
     int rc = admm_begin(E, distance, rho, prox_w, prox_h, j, 1); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_admm_phase(E, 0, distance, rho, prox_w, 0.0, prox_h, 0.0, 0, 0.0, 0.0, j);      // (r4)
     return distance == NMFX_EU ? admm_eu_products(E) : admm_kl_products(E);
 }
 
@@ -310,6 +310,7 @@ extern "C" int nmfx_admm_phase_update(nmfx_handle_t E, int distance, double rho,
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss type."; return NMFX_E_ARG; }
     if (!E->auxH || j < 0) { E->err = "admm_phase_update: call nmfx_admm_phase_products first"; return NMFX_E_STATE; }
     NMFX_HIP(hipSetDevice(E->device));
+    if (E->kp > 128) return nmfx_generic_admm_phase(E, 1, distance, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
     return distance == NMFX_EU ? admm_eu_update(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j)
                                : admm_kl_update(E, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, j);
 }

@@ -870,7 +870,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0 || lam < 0) { E->err = "bad range or lambda"; return NMFX_E_ARG; }
-    { int rc_ = nmfx_small_k_only(E, "row-sharded ANLS"); if (rc_) return rc_; rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }
+    { int rc_ = nmfx_enter_family(E, 4); if (rc_) return rc_; }      // (beyond 128 components the phases are composed from the generic kernels: r4)
     NMFX_HIP(hipSetDevice(E->device));
     if (!E->Asum) {
         NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->Asum), (size_t)E->mp * E->kp * sizeof(float)));
@@ -886,6 +886,7 @@ static int anls_ready(nmfx_engine* E, int64_t j, double lam) {
 extern "C" int nmfx_anls_phase_objective(nmfx_handle_t E, int64_t j) {
     if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, 0.0); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_anls_phase(E, 0, 0.0, 0, 0.0, 0.0, j);
     if (j == 0 && (rc = anls_objective(E))) return rc;   // obj[0] partials
     return nmfx_launch_obj_reduce(E);
 }
@@ -894,12 +895,14 @@ extern "C" int nmfx_anls_phase_w(nmfx_handle_t E, double lambda_w, int64_t min_i
                                  int64_t j) {
     if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, lambda_w); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_anls_phase(E, 1, lambda_w, min_iter, tol1, tol2, j);
     return anls_w_and_products(E, lambda_w, min_iter, tol1, tol2, j);
 }
 
 extern "C" int nmfx_anls_phase_h(nmfx_handle_t E, double lambda_h, int64_t j) {
     if (E) { E->himg_both = false; E->kl_h_iter = -2; }
     int rc = anls_ready(E, j, lambda_h); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_anls_phase(E, 2, lambda_h, 0, 0.0, 0.0, j);
     return anls_h(E, lambda_h);
 }
 

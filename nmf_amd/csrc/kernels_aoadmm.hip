@@ -474,14 +474,16 @@ __global__ __launch_bounds__(256) void ao_round_cols_any_kernel(
 
 __global__ __launch_bounds__(256) void ao_round_rows_any_kernel(
     const float* __restrict__ Asum, float* __restrict__ X, float* __restrict__ U, const float* __restrict__ Minv, int kp,
-    int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm)
+    int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm, const double* __restrict__ nrm_global)
 {
+    // (nrm_global: row-sharded runs -- the previous round's norm sums over ALL ranks' rows, as in ao_inner_rows_kernel)
     if (st->flag || st->inner_stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];    // RHS [64][kp + 4] + 16 doubles
     const int LD = kp + 4, JT = kp / 16;
     double* sh = reinterpret_cast<double*>(lds + (int64_t)64 * LD);
     const int nblk = gridDim.x;
-    if (round > 0 && inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh)) {
+    if (round > 0 && (nrm_global ? inner_round_fired(nrm_global, 1, sh)
+                                 : inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh))) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
         return;
     }
@@ -1353,7 +1355,7 @@ static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round, 
 
 // one round of a sub-problem at any padded rank up to 512 (see ao_round_*_any_kernel): X = H (cols) or W[0] (rows), its dual, B = the
 // summed right-hand side product ([kp][np] / [mp][kp]); nmfx_inner_finish(E, np / 64 | mp / 64, ...) closes the sub-problem
-int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round) {
+int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round, const double* nrm_global) {
     if (E->kp > 512 || E->kp % 64) { E->err = "round_any: k padded to at most 512"; return NMFX_E_ARG; }
     int rc;
     if (cols) {
@@ -1365,8 +1367,15 @@ int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U
         const size_t shm = (size_t)64 * (E->kp + 4) * sizeof(float) + 16 * sizeof(double);
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_rows_any_kernel), (int)shm))) return rc;
         hipLaunchKernelGGL(ao_round_rows_any_kernel, dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, B, X, U, (const float*)E->Minv, E->kp,
-                           prox, lam, round, E->state, E->nrm_part);
+                           prox, lam, round, E->state, E->nrm_part, nrm_global);
     }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// this rank's four norm sums of round `round` of the W sub-problem -> xf64[1..4] (row-sharded runs all-reduce them)
+int nmfx_gather_round_norms(nmfx_engine* E, int nblk, int round) {
+    hipLaunchKernelGGL(ao_norm_gather_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part, nblk, round, E->xf64 + 1);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -1884,7 +1893,7 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
 }
 
 // ---- row-sharded form (Euclidean loss) -----------------------------------------
-static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
+static int ao_sharded_ready(nmfx_engine* E, int64_t j, bool any_k = false) {
     if (!E) return NMFX_E_ARG;
     if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
     if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
@@ -1892,7 +1901,9 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
     E->anls_a_ready = false; E->kl_h_iter = -2;
     E->wimg_ok = false; E->ao_images = false;          // (the phase entry points rebuild the W images themselves)
     int rc;
-    if ((rc = nmfx_small_k_only(E, "AO-ADMM"))) return rc;
+    // beyond 128 components (r4): the least-squares phases are composed from the generic kernels (kernels_generic.hip,
+    // nmfx_generic_aoadmm_phase_*); the KL phases and the fused W sub-problem stay at k <= 128
+    if (!(any_k && E->kp <= 512) && (rc = nmfx_small_k_only(E, "row-sharded AO-ADMM (KL loss, fused W rounds, or more than 512 components)"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;
@@ -1903,29 +1914,33 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j) {
 }
 
 extern "C" int nmfx_aoadmm_phase_h_products(nmfx_handle_t E, int64_t j) {
-    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    int rc = ao_sharded_ready(E, j, true); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_aoadmm_phase(E, 0, 0, 0.0, 0, 0, 0.0, 0.0, j, 0);
     if (j == 0 && (rc = ao_new_pair_objective(E))) return rc;                      // obj[0] partials (ao_admm.py:256)
     return ao_h_products(E);
 }
 
 extern "C" int nmfx_aoadmm_phase_h_solve(nmfx_handle_t E, int prox_h, double lambda_h, int admm_iter,
                                          int64_t min_iter, double tol1, double tol2, int64_t j) {
-    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    int rc = ao_sharded_ready(E, j, true); if (rc) return rc;
     if (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (E->kp > 128) return nmfx_generic_aoadmm_phase(E, 1, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j, 0);
     return ao_h_solve(E, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
 }
 
 extern "C" int nmfx_aoadmm_phase_w_products(nmfx_handle_t E, int64_t min_iter, double tol1, double tol2, int64_t j) {
-    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    int rc = ao_sharded_ready(E, j, true); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_aoadmm_phase(E, 2, 0, 0.0, 0, min_iter, tol1, tol2, j, 0);
     return ao_w_products(E, j, min_iter, tol1, tol2);
 }
 
 // One inner round of the W sub-problem on this rank's rows; leaves this rank's norm sums of
 // the round in the f64 exchange buffer [1..4] for the caller to all-reduce.
 extern "C" int nmfx_aoadmm_phase_w_round(nmfx_handle_t E, int prox_w, double lambda_w, int round) {
-    int rc = ao_sharded_ready(E, 0); if (rc) return rc;
+    int rc = ao_sharded_ready(E, 0, true); if (rc) return rc;
     if (prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if (E->kp > 128) return nmfx_generic_aoadmm_phase(E, 3, prox_w, lambda_w, 0, 0, 0.0, 0.0, 0, round);
     if ((rc = inner_rows(E, E->W[0], prox_w, (float)lambda_w, round, round > 0 ? E->xf64 + 1 : nullptr))) return rc;
     hipLaunchKernelGGL(ao_norm_gather_kernel, dim3(1), dim3(256), 0, E->stream, E->state, E->nrm_part,
                        (int)(E->mp / 64), round, E->xf64 + 1);
@@ -1937,7 +1952,8 @@ extern "C" int nmfx_aoadmm_phase_w_round(nmfx_handle_t E, int prox_w, double lam
 // the new pair (summed into the exchange buffer by the next nmfx_aoadmm_phase_h_products or by
 // nmfx_objective_partial).
 extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
-    int rc = ao_sharded_ready(E, j); if (rc) return rc;
+    int rc = ao_sharded_ready(E, j, true); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_aoadmm_phase(E, 4, 0, 0.0, admm_iter, 0, 0.0, 0.0, j, 0);
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
     return ao_new_pair_objective(E);
 }
@@ -2054,6 +2070,8 @@ extern "C" int nmfx_aoadmm_phase_w_repair(nmfx_handle_t E, int prox_w, double la
 extern "C" int nmfx_objective_partial(nmfx_handle_t E) {
     if (!E) return NMFX_E_ARG;
     NMFX_HIP(hipSetDevice(E->device));
+    if (E->kp > 128 && (E->family == 2 || E->family == 3)) return NMFX_OK;      // (the composed AO-ADMM / ADMM phases close every iteration with it: xf64[0] holds it)
+    if (E->kp > 128 && E->family == 4) return nmfx_generic_anls_phase(E, 0, 0.0, 0, 0.0, 0.0, 0);
     return ao_final_objective(E);
 }
 

@@ -1377,6 +1377,67 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
     return NMFX_OK;
 }
 
+// The same iteration in the pieces a ROW-SHARDED run needs (r4; nmfx_aoadmm_phase_* dispatch here beyond 128 components, k <= 512):
+//   0 h_products: [W^T V | W^T W] of this rank's rows into the f32 exchange buffer (xf64[0] holds the objective partial the
+//                 closing phase of the iteration before -- or, at j = 0, this phase -- left)      -> all-reduce f32 + f64[:8]
+//   1 h_solve:    obj[j] and the stop rule, then the H sub-problem (replicated work on the all-reduced sums)
+//   2 w_products: H H^T (replicated), V H^T of the rank's rows, (H H^T + rho I)^-1
+//   3 w_round:    one round of the W sub-problem on the rank's rows (decision of the round before from the ALL-REDUCED norm sums
+//                 xf64[1..4]), this rank's norm sums of the round -> xf64[1..4]                   -> all-reduce f64[1:5]
+//   4 w_close:    inner-round bookkeeping, the objective partial of the new pair -> xf64[0]
+int nmfx_generic_aoadmm_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                              int64_t j, int round) {
+    int rc;
+    E->gxb_img_ready = false;
+    if ((rc = gx_buffers(E, false))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    if ((rc = gx_alloc(E, &E->gx_r, std::max(mp, np) * kp))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_w64, gx_w64_count(kp)))) return rc;
+    if ((rc = gx_alloc(E, &E->gx_nrm, std::max(mp, np) * kp / 1024 * 4 + 64))) return rc;
+    float* W = E->W[0];
+    float* xB = E->xf32;
+    float* xG = E->xf32 + kp * np;
+    bool bf = gxb_on(E);
+    if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
+    E->gxb_img_ready = false;
+    switch (phase) {
+    case 0:
+        if (j == 0 && (rc = gx_objective_partial(E, bf))) return rc;              // obj[0] (ao_admm.py:256)
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");
+          if (bf) rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8);
+          else rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8);
+          return rc; }
+    case 1:
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        if ((rc = gx_ao_subproblem(E, true, xG, xB, E->H, E->dualH, prox, (float)lam, admm_iter, E->inner_hist + j * 2))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = gxb_images_h(E, E->H))) return rc; }
+        return NMFX_OK;
+    case 2:
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");
+          if (bf) rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4);
+          else rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1);
+          if (rc) return rc; }
+        return gx_prepare(E, E->HHt, -1.0);
+    case 3:
+        if ((rc = nmfx_round_any(E, false, E->A_part, W, E->dualW, prox, (float)lam, round, round > 0 ? E->xf64 + 1 : nullptr))) return rc;
+        return nmfx_gather_round_norms(E, (int)(mp / 64), round);
+    case 4:
+        if ((rc = nmfx_inner_finish(E, (int)(mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = gxb_images_w(E, W))) return rc; }
+        return gx_objective_partial(E, bf);
+    default:
+        E->err = "generic AO-ADMM phase: 0 .. 4"; return NMFX_E_ARG;
+    }
+}
+
 // ---- AO-ADMM with the KL loss (nmf/ao_admm.py:71-101, 274-289) and ADMM (nmf/admm.py:216-230, 292-334) for k > 128 --------------------
 namespace {
 
@@ -1519,76 +1580,111 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
 
 // ADMM (one level, fixed rho): aux_update twice, prox twice, dual updates, KL: v_aux / dual_v from w_aux h_aux (admm.py:292-324).
 // The caller (nmfx_admm_run) has allocated the ADMM state and, for the first iteration, set w_aux = w, h_aux = h.
-int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
-                          double tol1, double tol2, int64_t first, int64_t count) {
+// One ADMM iteration beyond 128 components in its two halves (the row-sharded form exchanges between them, r4):
+//   products: [w_aux^T data | w_aux^T w_aux] of this rank's rows into the f32 exchange buffer (xf64[0] holds the objective partial of the
+//             pair the update before left -- or, at j = 0, of the initial pair)
+//   update:   obj[j] and the stop rule, then everything else of admm.py:292-334 (h_aux and the H half replicated, w_aux, both prox
+//             operators, the duals and v_aux row-local), and the objective partial of the new (w, h) -> xf64[0]
+struct GxAdmm { bool kl, bf; const float* data; float *xB, *xG; };
+static int gx_admm_setup(nmfx_engine* E, int distance, int prox_w, int prox_h, GxAdmm* c) {
     E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
     if (prox_w == NMFX_PROX_L1INF_T || prox_h == NMFX_PROX_L1INF_T) {
         E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components"; return NMFX_E_ARG; }
     if ((rc = gx_admm_buffers(E))) return rc;
-    const bool kl = distance == NMFX_KL;
-    const int64_t mp = E->mp, np = E->np, kp = E->kp;
-    float* W = E->W[0];
-    float* xB = E->xf32;
-    float* xG = E->xf32 + kp * np;
-    const float* data = kl ? E->S : E->V;              // (KL: v_aux + dual_v, admm.py:224)
-    const int* flag = &E->state->flag;
+    c->kl = distance == NMFX_KL;
+    c->xB = E->xf32;
+    c->xG = E->xf32 + (int64_t)E->kp * E->np;
+    c->data = c->kl ? E->S : E->V;                     // (KL: v_aux + dual_v, admm.py:224)
     // Euclidean loss, split-bf16 runs: the V-sized products from the V planes and images of the auxiliaries (FOUR terms: the Gram
     // systems carry the caller's fixed rho, kernels_bf16.hip top), the objective's W H from the images of (w, h) (three terms)
-    bool bf = !kl && gxb_on(E);
-    if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
+    c->bf = !c->kl && gxb_on(E);
+    if (c->bf) { rc = gxb_prepare(E, E->W[0]); if (rc == GXB_NOFIT) c->bf = false; else if (rc) return rc; }
     E->gxb_img_ready = false;
-    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;     // (admm.py:289)
-    for (int64_t j = first; j < first + count; ++j) {
-        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
-                           E->state, E->obj_hist);
-        NMFX_HIP(hipGetLastError());
-        // h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T data + rho (h + dual_h))
-        { ProfScope ps(E, "gram_tn");
-          if ((rc = gx_split_product<false, false>(E, E->auxW, kp, E->auxW, kp, xG, kp, kp, mp, 64))) return rc; }
-        { ProfScope ps(E, "hphase");
-          if (bf) {
-              if ((rc = gxb_images_w(E, E->auxW))) return rc;
-              rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8, 4);
-          } else rc = gx_split_product<false, false>(E, E->auxW, kp, data, np, xB, kp, np, mp, 8);
-          if (rc) return rc; }
-        if ((rc = gx_prepare(E, xG, rho))) return rc;
-        { ProfScope ps(E, "inner_h");
-          const int64_t c4 = kp * np / 4;
-          hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)xB, (const float*)E->H,
-                             (const float*)E->dualH, E->gx_r, c4, (const DevState*)E->state);
-          NMFX_HIP(hipGetLastError());
-          if ((rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, np, E->auxH, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc; }
-        // w_aux^T = (h_aux h_aux^T + rho I)^-1 (h_aux data^T + rho (w^T + dual_w^T)), from the NEW h_aux
-        { ProfScope ps(E, "gram_nt");
-          if ((rc = gx_split_product<true, true>(E, E->auxH, np, E->auxH, np, E->HHt, kp, kp, np, 64))) return rc; }
-        { ProfScope ps(E, "wphase");
-          if (bf) {
-              if ((rc = gxb_images_h(E, E->auxH))) return rc;
-              rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 4);
-          } else rc = gx_split_product<true, true>(E, data, np, E->auxH, np, E->A_part, mp, kp, np, 1);
-          if (rc) return rc; }
-        if ((rc = gx_prepare(E, E->HHt, rho))) return rc;
-        { ProfScope ps(E, "inner_w");
-          const int64_t c4 = mp * kp / 4;
-          hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->A_part, (const float*)W,
-                             (const float*)E->dualW, E->gx_r, c4, (const DevState*)E->state);
-          NMFX_HIP(hipGetLastError());
-          if ((rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->auxW, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc; }
-        // h = prox(h_aux, dual_h), w = prox(w_aux, dual_w), duals += x - x_aux
-        if ((rc = gx_admm_prox(E, true, prox_h, rho, lam_h))) return rc;
-        if ((rc = gx_admm_prox(E, false, prox_w, rho, lam_w))) return rc;
-        if (kl) {                                      // v_aux, dual_v from w_aux h_aux (admm.py:312-315)
-            ProfScope ps(E, "kl_vaux");
-            if ((rc = gx_launch<true, false>(E, GX_VAUX, E->auxW, kp, E->auxH, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, nullptr, E->S))) return rc;
-        }
-        if (bf) { ProfScope ps(E, "images");          // images of the new (w, h) for the objective
-                  if ((rc = gxb_images_w(E, W))) return rc;
-                  if ((rc = gxb_images_h(E, E->H))) return rc; }
-        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;
-    }
-    (void)flag;
     return NMFX_OK;
+}
+
+static int gx_admm_products(nmfx_engine* E, const GxAdmm& c) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    // h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T data + rho (h + dual_h)): the two sums over rows
+    { ProfScope ps(E, "gram_tn");
+      if ((rc = gx_split_product<false, false>(E, E->auxW, kp, E->auxW, kp, c.xG, kp, kp, mp, 64))) return rc; }
+    { ProfScope ps(E, "hphase");
+      if (c.bf) {
+          if ((rc = gxb_images_w(E, E->auxW))) return rc;
+          rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], c.xB, kp, np, mp, 8, 4);
+      } else rc = gx_split_product<false, false>(E, E->auxW, kp, c.data, np, c.xB, kp, np, mp, 8);
+      if (rc) return rc; }
+    return NMFX_OK;
+}
+
+static int gx_admm_update(nmfx_engine* E, const GxAdmm& c, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
+                          double tol1, double tol2, int64_t j) {
+    int rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    float* W = E->W[0];
+    hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                       E->state, E->obj_hist);
+    NMFX_HIP(hipGetLastError());
+    if ((rc = gx_prepare(E, c.xG, rho))) return rc;
+    { ProfScope ps(E, "inner_h");
+      const int64_t c4 = kp * np / 4;
+      hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)c.xB, (const float*)E->H,
+                         (const float*)E->dualH, E->gx_r, c4, (const DevState*)E->state);
+      NMFX_HIP(hipGetLastError());
+      if ((rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, np, E->auxH, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc; }
+    // w_aux^T = (h_aux h_aux^T + rho I)^-1 (h_aux data^T + rho (w^T + dual_w^T)), from the NEW h_aux
+    { ProfScope ps(E, "gram_nt");
+      if ((rc = gx_split_product<true, true>(E, E->auxH, np, E->auxH, np, E->HHt, kp, kp, np, 64))) return rc; }
+    { ProfScope ps(E, "wphase");
+      if (c.bf) {
+          if ((rc = gxb_images_h(E, E->auxH))) return rc;
+          rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 4);
+      } else rc = gx_split_product<true, true>(E, c.data, np, E->auxH, np, E->A_part, mp, kp, np, 1);
+      if (rc) return rc; }
+    if ((rc = gx_prepare(E, E->HHt, rho))) return rc;
+    { ProfScope ps(E, "inner_w");
+      const int64_t c4 = mp * kp / 4;
+      hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->A_part, (const float*)W,
+                         (const float*)E->dualW, E->gx_r, c4, (const DevState*)E->state);
+      NMFX_HIP(hipGetLastError());
+      if ((rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->auxW, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc; }
+    // h = prox(h_aux, dual_h), w = prox(w_aux, dual_w), duals += x - x_aux
+    if ((rc = gx_admm_prox(E, true, prox_h, rho, lam_h))) return rc;
+    if ((rc = gx_admm_prox(E, false, prox_w, rho, lam_w))) return rc;
+    if (c.kl) {                                        // v_aux, dual_v from w_aux h_aux (admm.py:312-315)
+        ProfScope ps(E, "kl_vaux");
+        if ((rc = gx_launch<true, false>(E, GX_VAUX, E->auxW, kp, E->auxH, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, nullptr, E->S))) return rc;
+    }
+    if (c.bf) { ProfScope ps(E, "images");            // images of the new (w, h) for the objective
+                if ((rc = gxb_images_w(E, W))) return rc;
+                if ((rc = gxb_images_h(E, E->H))) return rc; }
+    return c.kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, c.bf);
+}
+
+int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
+                          double tol1, double tol2, int64_t first, int64_t count) {
+    GxAdmm c;
+    int rc = gx_admm_setup(E, distance, prox_w, prox_h, &c); if (rc) return rc;
+    if (first == 0 && count > 0 && (rc = c.kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, c.bf))) return rc;     // (admm.py:289)
+    for (int64_t j = first; j < first + count; ++j) {
+        if ((rc = gx_admm_products(E, c))) return rc;
+        if ((rc = gx_admm_update(E, c, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j))) return rc;
+    }
+    return NMFX_OK;
+}
+
+// row-sharded ADMM beyond 128 components (nmfx_admm_phase_products / _update dispatch here; the W-side prox must be row-local)
+int nmfx_generic_admm_phase(nmfx_engine* E, int phase, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                            int64_t min_iter, double tol1, double tol2, int64_t j) {
+    GxAdmm c;
+    int rc = gx_admm_setup(E, distance, prox_w, prox_h, &c); if (rc) return rc;
+    if (phase == 0) {
+        if (j == 0 && (rc = c.kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, c.bf))) return rc;
+        return gx_admm_products(E, c);
+    }
+    return gx_admm_update(E, c, rho, prox_w, lam_w, prox_h, lam_h, min_iter, tol1, tol2, j);
 }
 
 // ---- ANLS (nmf/anls.py:18-47, 111-122) for k > 128 -------------------------------------------------------------------------------------
@@ -1809,6 +1905,36 @@ int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t mi
         if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;
     }
     return NMFX_OK;
+}
+
+// row-sharded ANLS beyond 128 components (nmfx_anls_phase_* dispatch here, r4): 0 objective partial of the current pair -> xf64[0];
+// 1 obj[j] + stop rule, H H^T (replicated), V H^T and the NNLS rows of W (rank-local), then [W^T V | W^T W] of the rank's rows into
+// the f32 exchange buffer; 2 the NNLS columns of H from the all-reduced sums (replicated)
+int nmfx_generic_anls_phase(nmfx_engine* E, int phase, double lam, int64_t min_iter, double tol1, double tol2, int64_t j) {
+    E->gxb_img_ready = false;
+    int rc;
+    if ((rc = gx_buffers(E, false))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    const bool kl = E->anls_dist == NMFX_KL;
+    float* W = E->W[0];
+    float* xB = E->xf32;
+    float* xG = E->xf32 + kp * np;
+    if (phase == 0) return kl ? gx_kl_objective_partial(E) : gx_objective_partial(E);
+    if (phase == 1) {
+        hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                           E->state, E->obj_hist);
+        NMFX_HIP(hipGetLastError());
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        { ProfScope ps(E, "wphase");
+          if ((rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1))) return rc; }
+        if ((rc = gx_nnls(E, E->HHt, 2.0 * lam, E->A_part, W, 1, kp, E->m))) return rc;
+        { ProfScope ps(E, "gram_tn");
+          if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
+        { ProfScope ps(E, "hphase");
+          return gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8); }
+    }
+    return gx_nnls(E, xG, 2.0 * lam, xB, E->H, np, 1, E->n);
 }
 
 // The Euclidean objective of the CURRENT pair (W as nmfx_get_factors would return it, H) evaluated entirely in float64 on the

@@ -270,6 +270,10 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
 int nmfx_generic_admm_run(nmfx_engine* E, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h, int64_t min_iter,
                           double tol1, double tol2, int64_t first, int64_t count);
 int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t min_iter, double tol1, double tol2, int64_t first, int64_t count);
+// row-sharded forms beyond 128 components (r4): ADMM phase 0 products / 1 update; ANLS phase 0 objective / 1 W half + products / 2 H half
+int nmfx_generic_admm_phase(nmfx_engine* E, int phase, int distance, double rho, int prox_w, double lam_w, int prox_h, double lam_h,
+                            int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_generic_anls_phase(nmfx_engine* E, int phase, double lam, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_preload_generic();
 // the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
 inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {
@@ -289,7 +293,12 @@ int nmfx_inner_cols(nmfx_engine* E, const float* M, float* aux, int mode, int pr
 int nmfx_inner_rows(nmfx_engine* E, const float* Asum, float* W, const float* M, float* aux, int mode, int prox,
                     float lam, int round, const double* nrm_global = nullptr);
 int nmfx_inner_finish(nmfx_engine* E, int nblk, int admm_iter, int32_t* slot, const double* nrm_global = nullptr);
-int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round);   // k padded to <= 512: one launch per round
+int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round,
+                   const double* nrm_global = nullptr);   // k padded to <= 512: one launch per round
+int nmfx_gather_round_norms(nmfx_engine* E, int nblk, int round);
+// row-sharded AO-ADMM (least-squares loss) beyond 128 components, phase 0 .. 4 = h_products, h_solve, w_products, w_round, w_close
+int nmfx_generic_aoadmm_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                              int64_t j, int round);
 
 // Row-major V for the kernels that read it (exact-f32 products, KL auxiliaries, the SVD): in split-bf16 mode it may
 // have been freed after the tile-major copies were built (drop_v) and is then rebuilt from Vtile.

@@ -666,7 +666,10 @@ def aoadmm_sharded(shard, comm, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0
     # ONE exchange for the whole W sub-problem where the shard can run its rounds speculatively (the HIP engine, for
     # 2 <= admm_iter <= 64): the [admm_iter x 4] table of norm sums.  `fused=False` keeps one exchange per round.
     if fused is None:
-        fused = hasattr(shard, "ao_w_fused") and 2 <= admm_iter <= MAX_FUSED_ROUNDS
+        # (beyond 128 components the device composes the iteration from generic kernels -- r4 -- and exchanges the norm sums of
+        #  the W sub-problem round by round: the speculative fused rounds keep a k-wide panel on chip)
+        small_k = getattr(getattr(shard, "eng", None), "k", 0) <= 128
+        fused = hasattr(shard, "ao_w_fused") and 2 <= admm_iter <= MAX_FUSED_ROUNDS and small_k
     table = x64[8:8 + 4 * admm_iter] if fused else None
 
     def queue(first, count):

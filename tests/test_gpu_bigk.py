@@ -255,7 +255,10 @@ def test_anls_k256_kkt_at_lambda_zero_with_a_dead_component():
     assert y[h == 0].min() > -2e-4 * scale and np.abs(y[h > 0]).max() < 2e-4 * scale
 
 
-def test_row_sharded_anls_says_so_beyond_128_components():
+def test_row_sharded_phases_run_beyond_128_components():
+    """r4: the row-sharded phase entry points of AO-ADMM (least-squares loss), ADMM and ANLS are composed from the generic kernels beyond
+    128 components (tests/test_gpu_dist.py runs them against the oracle with 1 and 2 ranks); what stays at k <= 128 says so: the
+    KL-loss phases of AO-ADMM and its fused W sub-problem."""
     from nmf_amd._lib import NmfxError
     from nmf_amd.engine import Engine
     v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
@@ -263,8 +266,13 @@ def test_row_sharded_anls_says_so_beyond_128_components():
     with Engine(300, 260, 160) as eng:
         eng.upload_v(v)
         eng.set_factors(rs.rand(300, 160), rs.rand(160, 260))
+        eng.anls_phase_objective(0)
+        eng.synchronize()
+    with Engine(300, 260, 160) as eng:
+        eng.upload_v(v)
+        eng.set_factors(rs.rand(300, 160), rs.rand(160, 260))
         with pytest.raises(NmfxError, match="more than 128 components"):
-            eng.anls_phase_objective(0)
+            eng._ck(eng.lib.nmfx_aoadmm_kl_phase_h_products(eng.h, 0, 0))
 
 
 def test_mur_eu_16384x8192_k256_vs_oracle():

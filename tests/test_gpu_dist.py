@@ -261,6 +261,24 @@ def _solver_case(solver):
         v = R.planted_matrix(m, n, k, seed=35, dtype=np.float32)
         w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
         return m, n, k, v, w0, h0, kw
+    if solver == "admm_k160":
+        m, n, k = 520, 384, 160
+        kw = dict(rho=1.0, distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4)
+        v = R.planted_matrix(m, n, 24, seed=38, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
+    if solver == "anls_k160":
+        m, n, k = 400, 320, 160
+        kw = dict(lambda_w=0.1, lambda_h=0.05, min_iter=2, max_iter=3, tol1=1e-3, tol2=1e-3)
+        v = R.planted_matrix(m, n, 24, seed=39, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
+    if solver == "ao_admm_k160":                           # r4: beyond 128 components the phases are composed from the generic kernels
+        m, n, k = 520, 384, 160
+        kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=4, max_iter=4, admm_iter=10)
+        v = R.planted_matrix(m, n, 24, seed=37, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
     if solver.startswith("ao_admm"):
         m, n, k = 520, 300, (40 if solver.endswith("bf16") else 12)    # k = 40: split-bf16 products, lazy objective
         kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=8, max_iter=8, admm_iter=10)
@@ -301,8 +319,8 @@ def _solver_gpu_worker(rank, world, rdzv, backend, solver, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "admm", "admm_bf16",
-                                    "admm_kl", "anls"])
+@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "admm",
+                                    "admm_bf16", "admm_kl", "admm_k160", "anls", "anls_k160"])
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
 def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
     import torch.multiprocessing as mp
