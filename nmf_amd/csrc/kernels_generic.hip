@@ -1547,8 +1547,9 @@ int gx_admm_prox(nmfx_engine* E, bool hside, int prox, double rho, double lam) {
         NMFX_HIP(hipGetLastError());
         return NMFX_OK;
     }
-    if (prox == NMFX_PROX_L1INF) return nmfx_launch_prox_l1inf(E, hside, false, rho, lam, 1.0, true);
-    E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components";
+    if (prox == NMFX_PROX_L1INF || prox == NMFX_PROX_L1INF_T)      // (r4: 'l1inf_transpose' takes one workgroup per column beyond 128 entries)
+        return nmfx_launch_prox_l1inf(E, hside, prox == NMFX_PROX_L1INF_T, rho, lam, 1.0, true);
+    E->err = "Unknown prox_type.";
     return NMFX_E_ARG;
 }
 
@@ -1589,8 +1590,6 @@ struct GxAdmm { bool kl, bf; const float* data; float *xB, *xG; };
 static int gx_admm_setup(nmfx_engine* E, int distance, int prox_w, int prox_h, GxAdmm* c) {
     E->gxb_img_ready = false;                          // (this solver rewrites W and H without the images of the k > 128 MUR loop)
     int rc;
-    if (prox_w == NMFX_PROX_L1INF_T || prox_h == NMFX_PROX_L1INF_T) {
-        E->err = "prox 'l1inf_transpose' sorts the k entries of a column in one wavefront: at most 128 components"; return NMFX_E_ARG; }
     if ((rc = gx_admm_buffers(E))) return rc;
     c->kl = distance == NMFX_KL;
     c->xB = E->xf32;

@@ -46,8 +46,9 @@ template <bool GLOBALK>
 __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
     const float* __restrict__ AUX, float* __restrict__ X, float* __restrict__ U, int64_t vec_stride, int64_t es,
     int L, int Lpad, double rho, double lam, double ub, int update_dual, const int* __restrict__ flag, float* __restrict__ gkeys,
-    const DevState* __restrict__ st)      // st != nullptr (AO-ADMM, r4): rho = trace(G) / k of the sub-problem, no-op once its inner stop fired
-{
+    const DevState* __restrict__ st,      // st != nullptr (AO-ADMM, r4): rho = trace(G) / k of the sub-problem, no-op once its inner stop fired
+    int transpose = 0)                    // 1 (r4, 'l1inf_transpose' beyond 128 components: one workgroup per column instead of one wavefront):
+{                                         // the sorted vector takes the dual of vector 1 (admm.py:196), theta is clamped at zero (admm.py:206)
     if (*flag) return;
     if (st) { if (st->inner_stop) return; rho = st->rho; }
     extern __shared__ __attribute__((aligned(16))) float lkeys[];      // [Lpad] (LDS form)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
             const float a = AUX[base + e * es], d = U[base + e * es];
             const double p = (double)a + (double)d - shift;
             psum += p < 0.0 ? 0.0 : p;
-            keys[e] = a - d;
+            keys[e] = a - (transpose ? U[vec_stride + e * es] : d);
         } else keys[e] = -__builtin_inff();
     }
     const double total = block_sum_1024(psum, red);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(ROWS_NT) void prox_l1inf_rows_kernel(
         }
         __syncthreads();
         const double theta = rho / (double)count * (s_total + shift - ub);
-        theta_over_rho = theta / rho;
+        theta_over_rho = (transpose && !(theta > 0.0)) ? 0.0 : theta / rho;
     }
     for (int e = tid; e < L; e += ROWS_NT) {
         const float a = AUX[base + e * es], d = U[base + e * es];
@@ -236,7 +237,7 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
             int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(prox_l1inf_rows_kernel<false>), (int)shm + 1024); if (rc) return rc;
             hipLaunchKernelGGL(prox_l1inf_rows_kernel<false>, dim3((unsigned)E->k), dim3(ROWS_NT), shm, E->stream, aux, x, u,
                                h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
-                               update_dual ? 1 : 0, &E->state->flag, (float*)nullptr, st);
+                               update_dual ? 1 : 0, &E->state->flag, (float*)nullptr, st, 0);
         } else {            // longer vectors: the same kernel with its keys in a global work area
             if (E->prox_keys_cap < (int64_t)E->k * Lpad) {
                 if (E->prox_keys) { NMFX_HIP(hipStreamSynchronize(E->stream)); hipFree(E->prox_keys); E->prox_keys = nullptr; }
@@ -245,11 +246,19 @@ int nmfx_launch_prox_l1inf(nmfx_engine* E, bool h_side, bool transpose, double r
             }
             hipLaunchKernelGGL(prox_l1inf_rows_kernel<true>, dim3((unsigned)E->k), dim3(ROWS_NT), 16, E->stream, aux, x, u,
                                h_side ? E->np : (int64_t)1, h_side ? (int64_t)1 : (int64_t)E->kp, (int)cols, (int)Lpad, rho, lam, ub,
-                               update_dual ? 1 : 0, &E->state->flag, E->prox_keys, st);
+                               update_dual ? 1 : 0, &E->state->flag, E->prox_keys, st, 0);
         }
     } else {                // a vector = the k factors of one column of mat_aux
         if (cols < 2) { E->err = "prox 'l1inf_transpose' reads column 1 of the dual: needs at least 2 columns"; return NMFX_E_ARG; }
         // (every vector reads the dual of vector 1: the dual update is a launch of its own behind this one)
+        if (E->k > 128) {   // r4: a column of more than 128 entries takes the one-workgroup-per-vector kernel of 'l1inf' with the transposed strides
+            int64_t Lpad = 2; while (Lpad < E->k) Lpad <<= 1;
+            const size_t shm = (size_t)Lpad * sizeof(float);
+            int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(prox_l1inf_rows_kernel<false>), (int)shm + 1024); if (rc) return rc;
+            hipLaunchKernelGGL(prox_l1inf_rows_kernel<false>, dim3((unsigned)cols), dim3(ROWS_NT), shm, E->stream, aux, x, u,
+                               h_side ? (int64_t)1 : (int64_t)E->kp, h_side ? E->np : (int64_t)1, E->k, (int)Lpad, rho, lam, ub,
+                               0, &E->state->flag, (float*)nullptr, st, 1);
+        } else
         hipLaunchKernelGGL(prox_l1inf_cols_kernel, dim3((unsigned)cols), dim3(64), 0, E->stream, aux, x, u,
                            h_side ? (int64_t)1 : (int64_t)E->kp, h_side ? E->np : (int64_t)1, E->k, rho, lam, ub,
                            0, &E->state->flag, st);

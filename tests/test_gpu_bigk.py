@@ -173,8 +173,8 @@ def test_admm_beyond_128_components_vs_oracle(distance, regs, rho):
 
 
 def test_admm_l1inf_beyond_128_components_like_the_small_k_path():
-    """'l1inf' (one vector per factor) has no limit on k; 'l1inf_transpose' sorts a column's k entries in one wavefront and says so."""
-    from nmf_amd._lib import NmfxError
+    """'l1inf' (one vector per factor) has no limit on k; 'l1inf_transpose' (one vector per column: k entries) takes one workgroup per
+    column beyond 128 entries (r4: it used to refuse) -- both against the oracle over the first two iterations, on both sides."""
     from nmf_amd.admm import admm
     m, n, k = 300, 260, 160
     v = R.planted_matrix(m, n, 12, seed=4, dtype=np.float32)
@@ -183,8 +183,14 @@ def test_admm_l1inf_beyond_128_components_like_the_small_k_path():
     ref = R.admm(v.astype(np.float64), k, **kw)
     assert res.i == ref.i
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-3)
-    with pytest.raises(NmfxError, match="l1inf_transpose"):
-        admm(v.copy(), k, rho=1.0, reg_w=(0, "nn"), reg_h=(0.1, "l1inf_transpose"), max_iter=2, nndsvd_init=(False, "zero"))
+    for regs in (dict(reg_w=(0, "nn"), reg_h=(0.1, "l1inf_transpose")), dict(reg_w=(0.1, "l1inf_transpose"), reg_h=(0, "nn"))):
+        kw = dict(rho=1.0, distance_type="eu", min_iter=2, max_iter=2, nndsvd_init=(True, "zero"), **regs)
+        res = admm(v.copy(), k, **kw)
+        with np.errstate(all="ignore"):
+            ref = R.admm(v.astype(np.float64), k, **kw)
+        assert res.i == ref.i
+        np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-3)
+        assert wh_error(res.w, res.h, ref.w, ref.h, v) < WH_TOL
 
 
 @pytest.mark.parametrize("regs", [((0, "nn"), (0, "nn")), ((0.05, "l1n"), (0.02, "l1n"))])
