@@ -3,12 +3,13 @@
 # only, as MI355X_MICROARCH.md prescribes), one summary with the derived figures:
 #   hbm_bytes_per_launch = 2 x FETCH_SIZE KB (gfx950: wide streaming reads are counted half) + WRITE_SIZE KB
 #   mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)     (the same normalisation for every kernel)
-#   usage: tools/collect_pmc.sh r03      -> gpurun_out/pmc_r03/summary.json  (copy into profiles/)
-tag=${1:-r03}
+#   (r4: one row per (kernel, grid) -- the composed path launches one kernel name at V-sized and at Gram-sized shapes)
+#   usage: tools/collect_pmc.sh r04      -> gpurun_out/pmc_r04/summary.json  (copy into profiles/)
+tag=${1:-r04}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
-for probe in ${PROBES:-cfg2 k128 kl cfg3 pair k256}; do
+for probe in ${PROBES:-cfg2 k128 kl cfg3 pair k256 aokl}; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"; do
     name=${probe}_$(echo "$ctr" | tr ' ' '+')
     if [ "$probe" = cfg2 ]; then
@@ -32,10 +33,12 @@ for f in sorted(glob.glob(out + "/*.csv")):
         if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k and "gxb_gemm_kernel" not in k and "gxt_gemm_kernel" not in k:
             continue
         short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        acc[probe + ": " + short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+        acc[probe + ": " + short + " grid " + str(grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
     e = {c: sum(v) / len(v) for c, v in d.items()}
+    e["launches_seen"] = max(len(v) for v in d.values())
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CYCLES"):
