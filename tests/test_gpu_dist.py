@@ -268,8 +268,8 @@ def _solver_case(solver):
         w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
         return m, n, k, v, w0, h0, kw
     if solver == "anls_k160":
-        m, n, k = 400, 320, 160
-        kw = dict(lambda_w=0.1, lambda_h=0.05, min_iter=2, max_iter=3, tol1=1e-3, tol2=1e-3)
+        m, n, k = 240, 200, 160                            # (small: the oracle's per-column scipy NNLS at k = 160 is the slow part)
+        kw = dict(lambda_w=0.1, lambda_h=0.05, min_iter=1, max_iter=2, tol1=1e-3, tol2=1e-3)
         v = R.planted_matrix(m, n, 24, seed=39, dtype=np.float32)
         w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
         return m, n, k, v, w0, h0, kw
