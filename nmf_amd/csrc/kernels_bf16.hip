@@ -757,7 +757,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
             if (st < YPW / 2) dma_run2(ybase, smem0 + yq * YBUF + ydst + st * 2048, yoffs[2 * (st < YPW / 2 ? st : 0)], yoffs[2 * (st < YPW / 2 ? st : 0) + 1]);
             if (st == YPW / 2 - 1) { ybase += ystep; yq = (yq == YR - 1) ? 0 : yq + 1; }
         } else {
+#ifdef NMFX_EXP_VFRONT         // experiment (r4): the V requests of a group in its first two stages (four pieces each) instead of two per stage
+            if (st == 0) (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+            if (st == 1) (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
+#else
             (TEMPORAL ? dma_run2 : dma_run2_nt)(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
+#endif
             if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1); }
         }
     };

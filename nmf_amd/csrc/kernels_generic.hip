@@ -624,7 +624,18 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t kch = K / 32, nch = kch / gridDim.z, c0 = nch * blockIdx.z;
     const int64_t mt = M / 128;
-    const int64_t rt0 = 2 * (int64_t)blockIdx.y, rt1 = (rt0 + 1 < mt) ? rt0 + 1 : rt0;          // (an odd number of row tiles: the last block loads its tile twice)
+    // r4: the column tiles of one row block on ONE XCD, next to each other in time.  Blocks are dealt to the 8 XCDs round-robin in
+    // linear order (x fastest), so with (x, y) = blockIdx the nx column tiles of a row block -- which stream the SAME A planes (the
+    // V planes of V H^T: 512 MiB) -- sat on nx different XCDs and each fetched them from HBM: 923 MB per launch against 562 MB of
+    // operands at k = 256 (PMC, profiles/r04_pmc_summary.json), four times V at k = 512.  Within groups of 8 row blocks the linear
+    // index is re-read as (column tile, row block) = (L' / 8, L' % 8): L' and L' + 8 -- the same XCD, dispatched in the same round --
+    // are neighbouring column tiles of one row block, and the second reader finds the planes in that XCD's L2.
+    int bxi = blockIdx.x, byi = blockIdx.y;
+    if (gridDim.x > 1 && gridDim.y >= 8) {
+        const int nx = gridDim.x, L = byi * nx + bxi, grp = L / (8 * nx), Lp = L % (8 * nx);
+        if (8 * (grp + 1) <= (int)gridDim.y) { byi = 8 * grp + (Lp & 7); bxi = Lp >> 3; }      // (a last partial group keeps its order)
+    }
+    const int64_t rt0 = 2 * (int64_t)byi, rt1 = (rt0 + 1 < mt) ? rt0 + 1 : rt0;          // (an odd number of row tiles: the last block loads its tile twice)
     const bool second = rt0 + 1 < mt;
     // DMA: per chunk six units of 8 KiB (A hi t0, A hi t1, A lo t0, A lo t1, B hi, B lo); wave w copies piece w (1 KiB) of each
     unsigned long long src[6];
@@ -632,8 +643,8 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
     src[1] = (unsigned long long)(Ahi + (rt1 * kch + c0) * 4096) + wave * 1024ull;
     src[2] = (unsigned long long)(Alo + (rt0 * kch + c0) * 4096) + wave * 1024ull;
     src[3] = (unsigned long long)(Alo + (rt1 * kch + c0) * 4096) + wave * 1024ull;
-    src[4] = (unsigned long long)(Bhi + ((int64_t)blockIdx.x * kch + c0) * 4096) + wave * 1024ull;
-    src[5] = (unsigned long long)(Blo + ((int64_t)blockIdx.x * kch + c0) * 4096) + wave * 1024ull;
+    src[4] = (unsigned long long)(Bhi + ((int64_t)bxi * kch + c0) * 4096) + wave * 1024ull;
+    src[5] = (unsigned long long)(Blo + ((int64_t)bxi * kch + c0) * 4096) + wave * 1024ull;
     const unsigned smem0 = __builtin_amdgcn_readfirstlane(gxt_lds_off(gxt_smem));
     const unsigned voff = (unsigned)lane * 16u;
     auto issue = [&](int64_t c, int stage) {
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
     }
     if (wr >= 128 && !second) return;                  // (the duplicated tile of an odd last block)
     float* Cz = C + (int64_t)blockIdx.z * cstride;
-    const int64_t i0 = (int64_t)blockIdx.y * 256, j0 = (int64_t)blockIdx.x * 128;
+    const int64_t i0 = (int64_t)byi * 256, j0 = (int64_t)bxi * 128;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
