@@ -571,10 +571,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (MODE == GX_RESID ? 0.5 : 1.0) * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
+bool gxr_on();
+int gxr_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi, const unsigned short* Blo,
+               int64_t ldq, int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, double* part, const int* flag2,
+               unsigned short* Qhi, unsigned short* Qlo);
 int gxb_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, int64_t lda, const unsigned short* Bhi,
                const unsigned short* Blo, int64_t ldb, float* C, int64_t ldc, int64_t cstride, int64_t M, int64_t N, int64_t K, int S,
                const float* X, int64_t ldx, double* part, const int* flag2 = nullptr, unsigned short* Qhi = nullptr, unsigned short* Qlo = nullptr) {
     // (GX_RESID / GX_KLQ only: the long contractions -- every GX_STORE product -- run on gxt_gemm_kernel below)
+    if (gxr_on() && mode != GX_STORE && S == 1) return gxr_launch(E, mode, Ahi, Alo, Bhi, Blo, ldc, M, N, K, X, ldx, part, flag2, Qhi, Qlo);
     if (mode == GX_STORE || M % GX_T || N % GX_T || K % ((int64_t)S * GXB_KC)) { E->err = "gxb_launch: shape / mode"; return NMFX_E_ARG; }
     const dim3 grid((unsigned)(N / GX_T), (unsigned)(M / GX_T), (unsigned)S), block(256);
     const int* flag = &E->state->flag;
@@ -612,11 +617,13 @@ __device__ __forceinline__ void gxt_dma(unsigned long long base, unsigned dst, u
 }
 constexpr int GXT_STAGE = 6 * 8192, GXT_SHM = 3 * GXT_STAGE;
 
+int gx_stagger() { static const int v = getenv("NMFX_GX_STAGGER") ? atoi(getenv("NMFX_GX_STAGGER")) : 1; return v; }
+
 template <int TERMS>
 __global__ __launch_bounds__(512) void gxt_gemm_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, const unsigned short* __restrict__ Bhi,
     const unsigned short* __restrict__ Blo, float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t M, int64_t K,
-    const int* __restrict__ flag, const int* __restrict__ flag2)
+    const int* __restrict__ flag, const int* __restrict__ flag2, int stagger)
 {
     if (*flag || (flag2 && *flag2)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char gxt_smem[];
@@ -675,11 +682,13 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
     issue(0, 0);
     if (nch > 1) issue(1, 1);
     int stage = 0;
-    for (int64_t c = 0; c < nch; ++c) {
-        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // chunk c has landed everywhere; everybody is done with the stage chunk c + 2 goes to
-        if (c + 2 < nch) issue(c + 2, stage >= 1 ? stage - 1 : 2);      // (c + 2) % 3
+    // il: this wave's six DMA pieces of chunk c + 2 go out BETWEEN the MFMA groups of chunk c (one piece behind each of the first six
+    // groups of three MFMAs, pinned by scheduling barriers), so that their issue (60-180 cycles each) runs in the shadow of the
+    // wave's own matrix work instead of in front of it
+    auto multiply = [&](bool il, int64_t cn, int nstage) {
         const unsigned char* st = gxt_smem + stage * GXT_STAGE;
+        const unsigned dst = smem0 + nstage * GXT_STAGE + wave * 1024;
+        const unsigned long long adv = (unsigned long long)cn * 8192ull;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             GxbFrag ah[2], al[2], bh[2], bl[2];
@@ -698,8 +707,29 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
                     acc[ti][tj] = GXB_MFMA(al[ti], bh[tj], acc[ti][tj]);
                     acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
                     if (TERMS >= 4) acc[ti][tj] = GXB_MFMA(al[ti], bl[tj], acc[ti][tj]);
+                    const int g = 4 * ks + 2 * ti + tj;
+                    if (g < 6) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (il) gxt_dma(src[g] + adv, dst + g * 8192, voff);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
         }
+    };
+    // r4: the two waves of a SIMD (w and w + 4) run the same program between the same barriers and would issue their six DMA
+    // pieces at the same time, the SIMD's matrix pipe idle meanwhile, then queue for it together.  stagger 1: waves 0-3 request chunk
+    // c + 2 BEFORE their MFMAs of chunk c, waves 4-7 BEHIND them (the target stage held chunk c - 1, which every wave has left at this
+    // iteration's barrier; at the next wait chunk c + 2 is the only younger request either way).  stagger 16: interleaved (above).
+    const bool inl = stagger & 16;
+    const bool early = (stagger & 1) ? wave < 4 : true;
+    for (int64_t c = 0; c < nch; ++c) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // chunk c has landed everywhere; everybody is done with the stage chunk c + 2 goes to
+        const int nstage = stage >= 1 ? stage - 1 : 2; // (c + 2) % 3
+        const bool more = c + 2 < nch;
+        if (!inl && early && more) issue(c + 2, nstage);
+        multiply(inl && more, c + 2, nstage);          // (ONE instance between the two conditional requests: the accumulators stay in place)
+        if (!inl && !early && more) issue(c + 2, nstage);
         stage = (stage == 2) ? 0 : stage + 1;
     }
     if (wr >= 128 && !second) return;                  // (the duplicated tile of an odd last block)
@@ -712,6 +742,318 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
                 Cz[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + n31] = acc[ti][tj][r];
+}
+
+// ---- the SHORT contractions (objective, KL quotient: contraction over the factor index, V-sized output that never leaves the chip as
+// f32) as a PERSISTENT form of the kernel above (r4) ---------------------------------------------------------------------------------
+// gxb_gemm_kernel spent a block per 128 x 128 output tile: with eight 32-deep chunks per tile (k = 256) the head of the operand
+// pipeline, the X tile's round trip and the epilogue were paid once per tile and two blocks per CU had to cover each other's.  Here
+// one 512-thread block per CU walks a run of 256 x 128 output tiles (row-block major, the runs of one XCD next to each other, so
+// that its L2 holds the A planes of its 8 row blocks) and the three-stage LDS-DMA ring of gxt_gemm_kernel runs THROUGH the tile
+// boundaries: while a tile's epilogue executes, the first two chunks of the next tile are already in flight.  Both factors are read
+// as tiled images (W: rows m; H^T: rows n; contraction kp).  The epilogue's X tile (V in f32, row-major) arrives in the register
+// image of the accumulators, requested in four quarters behind the tile's first four chunks.  Those loads are inline asm and waited
+// for by the loop's own counted vmcnt (hipcc does not count the LDS-DMA requests; loads return in order; the quotient's stores are
+// never counted, which only makes a wait stricter).
+//   GX_RESID: part[block] = 1/2 sum (X - C)^2 over the block's tiles (utils.py:29)
+//   GX_KLQ:   Q = X / (C + 1e-9) as bf16 hi / lo planes in the TILED image of the product that consumes them (contraction along
+//             the columns), and with want_obj the KL objective (utils.py:23-26) into part[block]
+template <int MODE, bool OBJ>
+__global__ __launch_bounds__(512) void gxr_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, const unsigned short* __restrict__ Bhi,
+    const unsigned short* __restrict__ Blo, int64_t M, int64_t N, int64_t K, const float* __restrict__ X, int64_t ldx,
+    double* __restrict__ part, int64_t npart, const int* __restrict__ flag, const int* __restrict__ flag2,
+    unsigned short* __restrict__ Qhi, unsigned short* __restrict__ Qlo, int64_t ldq, int stagger)
+{
+    if (*flag || (flag2 && *flag2)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gxt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, n31 = lane & 31, b = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = (int)(K / 32);
+    const int64_t mt = M / 128, nrb = (mt + 1) / 2, nct = N / 128, T = nrb * nct;
+    const int nb = (int)gridDim.x;
+    int vb = (int)blockIdx.x;
+    if ((nb & 7) == 0) vb = (vb & 7) * (nb >> 3) + (vb >> 3);          // (blocks b, b + 8, .. share an XCD: give them neighbouring runs)
+    const int64_t t0 = T * vb / nb, t1 = T * (vb + 1) / nb;
+    const unsigned smem0 = __builtin_amdgcn_readfirstlane(gxt_lds_off(gxt_smem));
+    const unsigned voff = (unsigned)lane * 16u;
+    // the issue pointer: (tile, chunk) of the next request, two chunks ahead of the one being multiplied
+    int64_t q_rb = t0 / nct, q_ct = t0 % nct;
+    int q_c = 0, q_stage = 0;
+    int64_t q_left = (t1 - t0) * nch;
+    unsigned long long q_a0, q_a1, q_b;                // byte offsets of the next chunk in the A planes (two row tiles) and the B planes
+    auto q_tile = [&]() {
+        const int64_t rt0 = 2 * q_rb, rt1 = (rt0 + 1 < mt) ? rt0 + 1 : rt0;
+        q_a0 = (unsigned long long)(rt0 * nch * 8192 + wave * 1024); q_a1 = (unsigned long long)(rt1 * nch * 8192 + wave * 1024);
+        q_b = (unsigned long long)(q_ct * nch * 8192 + wave * 1024);
+    };
+    q_tile();
+    auto issue = [&]() {
+        const unsigned dst = smem0 + q_stage * GXT_STAGE + wave * 1024;
+        gxt_dma((unsigned long long)Ahi + q_a0, dst, voff);
+        gxt_dma((unsigned long long)Ahi + q_a1, dst + 8192, voff);
+        gxt_dma((unsigned long long)Alo + q_a0, dst + 2 * 8192, voff);
+        gxt_dma((unsigned long long)Alo + q_a1, dst + 3 * 8192, voff);
+        gxt_dma((unsigned long long)Bhi + q_b, dst + 4 * 8192, voff);
+        gxt_dma((unsigned long long)Blo + q_b, dst + 5 * 8192, voff);
+        q_stage = (q_stage == 2) ? 0 : q_stage + 1;
+        --q_left;
+        q_a0 += 8192; q_a1 += 8192; q_b += 8192;
+        if (++q_c == nch) { q_c = 0; if (++q_ct == nct) { q_ct = 0; ++q_rb; } q_tile(); }
+    };
+    const int wr = 64 * (wave >> 1), wc = 64 * (wave & 1);
+    int aoff[2][2], boff[2][2];                       // [tile][k-step]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = (wr & 127) + 32 * t + n31, rb = wc + 32 * t + n31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            aoff[t][ks] = (wr >> 7) * 8192 + ra * 64 + 16 * ((2 * ks + b) ^ ((ra >> 2) & 3));        // + 16384: lo
+            boff[t][ks] = 4 * 8192 + rb * 64 + 16 * ((2 * ks + b) ^ ((rb >> 2) & 3));                // + 8192: lo
+        }
+    }
+    gxb_f32x16 acc[2][2];
+    float xv[64];                                      // [(2 ti + tj) 16 + r], the register image of acc
+    int stage = 0;
+    auto multiply = [&]() {
+        const unsigned char* st = gxt_smem + stage * GXT_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            GxbFrag ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t].u = *reinterpret_cast<const uint4*>(st + aoff[t][ks]);
+                al[t].u = *reinterpret_cast<const uint4*>(st + aoff[t][ks] + 16384);
+                bh[t].u = *reinterpret_cast<const uint4*>(st + boff[t][ks]);
+                bl[t].u = *reinterpret_cast<const uint4*>(st + boff[t][ks] + 8192);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(al[ti], bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(ah[ti], bl[tj], acc[ti][tj]);
+                }
+        }
+        stage = (stage == 2) ? 0 : stage + 1;
+    };
+    double tot = 0.0;
+    gxb_f32x16 pacc[2][2];                             // GX_KLQ: the accumulators of the tile before, until its quotient has left
+    bool pending = false, p_live = false, act_prev = false;
+    unsigned short *p_q0 = nullptr, *p_q1 = nullptr;
+    // quarter h of the quotient epilogue: ti = h >> 1, rows r = 8 (h & 1) .. + 7, both column tiles (v_rcp_f32 / v_log_f32 as in the
+    // tuned MUR-KL kernels, kernels_bf16.hip: the inf / nan cases of utils.py:24 come out the same and are zeroed the same way)
+    auto klq_piece = [&](int pc) {                     // pc = 2 h + half: rows r = 8 (h & 1) + 4 half .. + 3 of X quarter h
+        if (!p_live) return;
+        const int h = pc >> 1, ti = h >> 1;
+        const bool odd = n31 & 1;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 8 * (h & 1) + 4 * (pc & 1) + e;
+                const float x1 = xv[(2 * ti + tj) * 16 + r], cv = pacc[ti][tj][r];
+                const float qv = x1 * __builtin_amdgcn_rcpf(cv + 1e-9f);
+                unsigned hi, lo;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(qv), "v"(0.f));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(qv - __uint_as_float(hi << 16)), "v"(0.f));
+                // two adjacent lanes hold adjacent columns: one 4-byte store per lane -- the even lane the pair of the hi plane, the odd lane
+                // the pair of the lo plane; the neighbour's half comes by DPP (quad_perm 1,0,3,2), the word by one byte permute, no branches
+                // (__shfl_xor compiles to ds_bpermute_b32 + a full lgkmcnt wait per element: that was most of the old epilogue's time)
+                const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hi : lo), 0xB1, 0xf, 0xf, false);
+                const unsigned word = __builtin_amdgcn_perm(odd ? lo : other, odd ? other : hi, 0x05040100u);
+                unsigned short* q = ((r >> 2) & 1) ? p_q1 : p_q0;
+                *reinterpret_cast<unsigned*>(q + tj * 4096 + ti * 1024 + 32 * ((r & 3) + 8 * (r >> 2))) = word;
+                if (OBJ) {
+                    float t = x1 * (__builtin_amdgcn_logf(x1 * __builtin_amdgcn_rcpf(cv)) * 0.69314718055994531f);
+                    t = (t != t || t == __builtin_inff() || t == -__builtin_inff()) ? 0.f : t;
+                    const float d2 = (t - x1) + cv;
+                    if (r & 1) s1 += d2; else s0 += d2;
+                }
+            }
+        if (OBJ) tot += (double)(s0 + s1);
+    };
+    issue();
+    issue();
+    const bool early = (stagger & 1) ? wave < 4 : true;      // (see gxt_gemm_kernel: the two waves of a SIMD request at different times)
+    const unsigned xlane = (unsigned)(((int64_t)(4 * b) * ldx + n31) * 4);
+    const unsigned long long ldx4 = (unsigned long long)ldx * 4ull;
+    int64_t rbk = t0 / nct, ctk = t0 % nct;
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const bool second = 2 * rbk + 1 < mt;
+        const bool live = second || wr < 128;          // (the duplicated tile of an odd last row block: its waves read the first tile's X and drop it)
+        const int64_t i0 = rbk * 256 + ((live ? wr : wr - 128)), j0 = ctk * 128 + wc;
+        const unsigned long long xb = (unsigned long long)(X + i0 * ldx + j0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+        // X quarter h = (ti = h >> 1, rows r = 8 (h & 1) .. + 7, both column tiles): 16 dword loads, each a full 128-byte line per
+        // half-wave (a lane's 16 entries of a 32 x 32 accumulator tile are one COLUMN: 16-byte loads along the rows touched 64 lines
+        // per instruction and the texture path, not the matrix pipe, set the pace: 240 us per launch against 170 without X)
+#define GXR_XQ(h) do { \
+            const unsigned long long r0_ = xb + (unsigned long long)(32 * ((h) >> 1) + 16 * ((h) & 1)) * ldx4; \
+            const int o_ = 32 * ((h) >> 1) + 8 * ((h) & 1); \
+            asm volatile("global_load_dword %0, %16, %17\n\tglobal_load_dword %1, %16, %17 offset:128\n\t" \
+                         "global_load_dword %2, %16, %18\n\tglobal_load_dword %3, %16, %18 offset:128\n\t" \
+                         "global_load_dword %4, %16, %19\n\tglobal_load_dword %5, %16, %19 offset:128\n\t" \
+                         "global_load_dword %6, %16, %20\n\tglobal_load_dword %7, %16, %20 offset:128\n\t" \
+                         "global_load_dword %8, %16, %21\n\tglobal_load_dword %9, %16, %21 offset:128\n\t" \
+                         "global_load_dword %10, %16, %22\n\tglobal_load_dword %11, %16, %22 offset:128\n\t" \
+                         "global_load_dword %12, %16, %23\n\tglobal_load_dword %13, %16, %23 offset:128\n\t" \
+                         "global_load_dword %14, %16, %24\n\tglobal_load_dword %15, %16, %24 offset:128" \
+                         : "=&v"(xv[o_ + 0]), "=&v"(xv[o_ + 16]), "=&v"(xv[o_ + 1]), "=&v"(xv[o_ + 17]), "=&v"(xv[o_ + 2]), "=&v"(xv[o_ + 18]), \
+                           "=&v"(xv[o_ + 3]), "=&v"(xv[o_ + 19]), "=&v"(xv[o_ + 4]), "=&v"(xv[o_ + 20]), "=&v"(xv[o_ + 5]), "=&v"(xv[o_ + 21]), \
+                           "=&v"(xv[o_ + 6]), "=&v"(xv[o_ + 22]), "=&v"(xv[o_ + 7]), "=&v"(xv[o_ + 23]) \
+                         : "v"(xlane), "s"(r0_), "s"(r0_ + ldx4), "s"(r0_ + 2 * ldx4), "s"(r0_ + 3 * ldx4), "s"(r0_ + 8 * ldx4), "s"(r0_ + 9 * ldx4), \
+                           "s"(r0_ + 10 * ldx4), "s"(r0_ + 11 * ldx4) : "memory"); } while (0)
+        // The first eight iterations are written out: each requests chunk g + 2 (waves 0-3 before their MFMAs, waves 4-7 behind them)
+        // and, last, possibly a quarter of X (16 loads) -- GX_RESID: iterations 0-3 (its epilogue closes the tile); GX_KLQ: iterations
+        // 1, 3, 5, 7.  GX_KLQ: an eighth of the quotient epilogue of the tile BEFORE (8 elements per lane: half of the X quarter that
+        // the request at the end of the next odd iteration then overwrites, 8 stores) rides in each of them -- in front of the MFMAs
+        // for waves 0-3, behind them for waves 4-7, so that one wave's VALU work runs beside its SIMD partner's MFMAs instead of both
+        // queueing for each pipe in turn.  Vector-memory operations retire in issue order, loads and stores alike
+        // (MI355X_MICROARCH.md, waitcnt), so the wait of iteration c leaves exactly those in flight that were issued behind chunk g:
+        //     waves 0-3:  S(c-2) + X(c-2) + 6 + S(c-1) + X(c-1)        waves 4-7 (stores in front of the request):  X(c-2) + S(c-1) + 6 + X(c-1)
+        // with S(j) = 8 where a piece ran in iteration j, X(j) = 16 where X was requested, j < 0 = the tail of the tile before
+        // (counter limit 63: rounded down to the next 6 + 8 i, which only makes a wait stricter).
+        const bool act = MODE == GX_KLQ && pending && p_live;          // pieces run in this tile's first eight iterations
+        auto n_s = [&](int j) { return j < 0 ? ((j + nch < 8 && act_prev) ? 8 : 0) : ((j < 8 && act) ? 8 : 0); };
+        auto n_x = [&](int j) {
+            if (j < 0) { if (tile == t0) return 0; j += nch; }
+            return MODE == GX_KLQ ? ((j < 8 && (j & 1)) ? 16 : 0) : (j < 4 ? 16 : 0);
+        };
+        auto wait_chunk = [&](int c, bool last) {
+            if (last) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+            const int n = 6 + n_x(c - 2) + n_s(c - 1) + n_x(c - 1) + (early ? n_s(c - 2) : 0);
+            if (n >= 62) asm volatile("s_waitcnt vmcnt(62)" ::: "memory");
+            else if (n >= 54) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+            else if (n >= 46) asm volatile("s_waitcnt vmcnt(46)" ::: "memory");
+            else if (n >= 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+            else if (n >= 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+            else if (n >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        };
+#define GXR_ITER(c_) do { \
+            wait_chunk(c_, false); \
+            __syncthreads(); \
+            if (early && q_left > 0) issue(); \
+            if (MODE == GX_KLQ && early && pending) klq_piece(c_); \
+            multiply();                                /* (ONE instance of the MFMA body per iteration: the accumulators stay in place) */ \
+            if (MODE == GX_KLQ && !early && pending) klq_piece(c_); \
+            if (!early && q_left > 0) issue(); } while (0)
+        if (MODE == GX_KLQ) {
+            GXR_ITER(0); GXR_ITER(1); GXR_XQ(0);
+            GXR_ITER(2); GXR_ITER(3); GXR_XQ(1);
+            GXR_ITER(4); GXR_ITER(5); GXR_XQ(2);
+            GXR_ITER(6);
+            wait_chunk(7, tile + 1 == t1 && nch == 8);
+            __syncthreads();
+            if (early && q_left > 0) issue();
+            if (early && pending) klq_piece(7);
+            multiply();
+            if (!early && pending) klq_piece(7);
+            if (!early && q_left > 0) issue();
+            GXR_XQ(3);
+        } else {
+            GXR_ITER(0); GXR_XQ(0);
+            GXR_ITER(1); GXR_XQ(1);
+            GXR_ITER(2); GXR_XQ(2);
+            GXR_ITER(3); GXR_XQ(3);
+            GXR_ITER(4); GXR_ITER(5); GXR_ITER(6);
+            wait_chunk(7, tile + 1 == t1 && nch == 8);
+            __syncthreads();
+            if (early && q_left > 0) issue();
+            multiply();
+            if (!early && q_left > 0) issue();
+        }
+#undef GXR_ITER
+#undef GXR_XQ
+        for (int c = 8; c < nch; ++c) {
+            wait_chunk(c, tile + 1 == t1 && c + 1 == nch);
+            __syncthreads();
+            if (early && q_left > 0) issue();
+            multiply();
+            if (!early && q_left > 0) issue();
+        }
+        act_prev = act;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(xv[i]));       // (the uses stay below the loop's counted waits)
+        // acc[ti][tj][r] = C(i0 + 32 ti + (r & 3) + 8 (r >> 2) + 4 b, j0 + 32 tj + n31)
+        if (MODE == GX_KLQ) {                          // handed to the next tile's first four iterations (or to the flush below)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) pacc[ti][tj] = acc[ti][tj];
+            pending = true;
+            p_live = live;
+            // this lane's 4-byte slots in the tiled image (contraction along the columns; row I = i0 + 32 ti + (r & 3) + 8 (r >> 2) + 4 b,
+            // columns J, J + 1 with J = j0 + 32 tj + (n31 & ~1)): tile ((I >> 7) (ldq / 32) + (J >> 5)) 4096 + (I & 127) 32 +
+            // 8 (((J & 31) >> 3) ^ ((I >> 2) & 3)) + (J & 7), where (I >> 2) & 3 = (2 (r >> 2) + b) & 3 = b for even r >> 2, b ^ 2 for odd
+            const int64_t tb = ((2 * rbk + (wr >> 7)) * (ldq / 32) + 4 * ctk + (wc >> 5)) * 4096 + 32 * ((wr & 127) + 4 * b) + (n31 & 6);
+            unsigned short* const pl = (n31 & 1) ? Qlo : Qhi;      // the even lane stores the pair of the hi plane, the odd lane that of the lo plane
+            p_q0 = pl + tb + 8 * ((n31 >> 3) ^ b);
+            p_q1 = pl + tb + 8 * ((n31 >> 3) ^ (b ^ 2));
+        } else if (live) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = xv[(2 * ti + tj) * 16 + r] - acc[ti][tj][r], d2 = d * d;
+                        if ((r & 3) == 0) s0 += d2; else if ((r & 3) == 1) s1 += d2; else if ((r & 3) == 2) s2 += d2; else s3 += d2;
+                    }
+                    tot += (double)((s0 + s1) + (s2 + s3));
+                }
+        }
+        if (++ctk == nct) { ctk = 0; ++rbk; }
+    }
+    if (MODE == GX_KLQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nch = 8: the last X quarter was requested behind the last wait)
+    if (MODE == GX_KLQ && pending) { klq_piece(0); klq_piece(1); klq_piece(2); klq_piece(3); klq_piece(4); klq_piece(5); klq_piece(6); klq_piece(7); }
+    if (!part) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    __syncthreads();                                   // (every wave has read its last stage)
+    double* red = reinterpret_cast<double*>(gxt_smem);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 8; ++w) s += red[w];
+        part[blockIdx.x] = (MODE == GX_RESID ? 0.5 : 1.0) * s;
+    }
+    if (blockIdx.x == 0)                               // (the callers sum one entry per 128 x 128 tile: the unused ones are zero)
+        for (int64_t i = nb + tid; i < npart; i += 512) part[i] = 0.0;
+}
+
+// the switch between the two forms of the short contractions: the factor images are written in the format the chosen kernel reads
+bool gxr_on() { static const bool on = !(getenv("NMFX_GXR") && atoi(getenv("NMFX_GXR")) == 0); return on; }
+
+int gxr_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi, const unsigned short* Blo,
+               int64_t ldq, int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, double* part, const int* flag2,
+               unsigned short* Qhi, unsigned short* Qlo) {
+    if (M % 128 || N % 128 || K % 128 || K < 256) { E->err = "gxr_launch: shape"; return NMFX_E_ARG; }
+    const int64_t T = ((M / 128 + 1) / 2) * (N / 128), npart = (M / GX_T) * (N / GX_T);
+    const int nb = (int)std::min<int64_t>(E->ncu, T);
+    const int* flag = &E->state->flag;
+    int rc;
+    const dim3 grid((unsigned)nb), block(512);
+#define GXR_GO(MODE_, OBJ_) do { \
+        if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxr_kernel<MODE_, OBJ_>), GXT_SHM))) return rc; \
+        hipLaunchKernelGGL((gxr_kernel<MODE_, OBJ_>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, M, N, K, X, ldx, part, npart, flag, flag2, \
+                           Qhi, Qlo, ldq, gx_stagger()); } while (0)
+    if (mode == GX_KLQ) { if (part) GXR_GO(GX_KLQ, true); else GXR_GO(GX_KLQ, false); }
+    else GXR_GO(GX_RESID, true);
+#undef GXR_GO
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 // bf16 hi / lo images of M [rows][cols] (f32, row-major) in the formats the product kernels read.  Natural orientation (operand rows =
@@ -768,10 +1110,10 @@ int gxt_split(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int fm
 // the factor images of the composed path: W -> Whi / Wlo [mp][kp] row-major (short contractions: objective, quotient) and W^T tiled
 // (W^T V, W^T W); H -> tiled (V H^T, H H^T) and H^T [np][kp] row-major
 int gxb_images_w(nmfx_engine* E, const float* W) {
-    return gxt_split(E, W, E->mp, E->kp, 1, E->Whi[0], E->Wlo[0], 2, E->WThi, E->WTlo, true);
+    return gxt_split(E, W, E->mp, E->kp, gxr_on() ? 2 : 1, E->Whi[0], E->Wlo[0], 2, E->WThi, E->WTlo, true);
 }
 int gxb_images_h(nmfx_engine* E, const float* H) {
-    return gxt_split(E, H, E->kp, E->np, 2, E->Hhi, E->Hlo, 1, E->HThi, E->HTlo, true);
+    return gxt_split(E, H, E->kp, E->np, 2, E->Hhi, E->Hlo, gxr_on() ? 2 : 1, E->HThi, E->HTlo, true);
 }
 
 // split-K product on the tiled planes into the slab buffer gx_s, summed into `out` (M: rows of A, N: rows of B, K: contraction)
@@ -787,10 +1129,10 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
     const int* flag = &E->state->flag;
     if (terms == 4) {
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt_gemm_kernel<4>), GXT_SHM))) return rc;
-        hipLaunchKernelGGL((gxt_gemm_kernel<4>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr);
+        hipLaunchKernelGGL((gxt_gemm_kernel<4>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr, gx_stagger());
     } else {
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt_gemm_kernel<3>), GXT_SHM))) return rc;
-        hipLaunchKernelGGL((gxt_gemm_kernel<3>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr);
+        hipLaunchKernelGGL((gxt_gemm_kernel<3>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr, gx_stagger());
     }
     NMFX_HIP(hipGetLastError());
     if (S == 1) return NMFX_OK;
