@@ -29,6 +29,17 @@ constexpr int GX_T = 128, GX_KC = 16, GX_LD = 144;
 
 enum { GX_STORE = 0, GX_RESID = 1, GX_KLQ = 2, GX_VAUX = 3 };
 
+// r4: the multiplicative update of the Euclidean MUR loop inside the image kernel of the new factor (gxt_split_kernel): the element
+// the kernel splits is  X * (sum of the numerator's slabs) / (Den + lam X + 1e-9)  (nmf/mur.py:29 / :45), written back as the new
+// factor on the way -- one launch where the composed path had three (slab sum, element-wise update, image kernel)
+struct GxUpd {
+    const float* xold = nullptr;                                          // nullptr: plain images of M
+    const float* num = nullptr; int nslab = 0; int64_t nstride = 0;      // numerator = sum of nslab slabs
+    const float* den = nullptr;
+    float lam = 0.f;
+    float* xnew = nullptr;
+};
+
 // one operand's chunk [GX_KC][128]: global -> registers (two float4 per thread), registers -> LDS plane [k][GX_LD].
 // KCONTIG: element (row, t) at base[row * ld + t]; else element (t, col) at base[t * ld + col].
 // (plain float4 values, no struct: hipcc kept a two-member staging struct in scratch)
@@ -370,6 +381,8 @@ int gx_launch(nmfx_engine* E, int mode, const float* A, int64_t lda, const float
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
+
+bool gx_fuse_update() { static const bool on = !(getenv("NMFX_GX_FUSE_UPDATE") && atoi(getenv("NMFX_GX_FUSE_UPDATE")) == 0); return on; }
 
 int gx_buffers(nmfx_engine* E, bool kl) {
     int rc;
@@ -744,6 +757,108 @@ __global__ __launch_bounds__(512) void gxt_gemm_kernel(
                 Cz[(i0 + wr + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + wc + 32 * tj + n31] = acc[ti][tj][r];
 }
 
+// ---- r4: 256 x 256 block tiles for the long contractions -------------------------------------------------------------------------
+// Measured on gxr_kernel: two more lines per lane and tile through the vector-memory path (an L2 prefetch of the next X tile) cost as
+// much as the 64 X loads themselves -- the CU's texture path, at ~36 bytes per clock for the 48 KiB of operand planes of every
+// 256 x 128 x 32 chunk, sets the pace of these kernels, not the matrix pipe (48 KiB / 36 = 1365 of the 1536 cycles a SIMD's MFMAs take).
+// A 256 x 256 tile needs 64 KiB for twice the MFMA work: 0.67 of the bytes.  Two stages of 64 KiB (A: hi / lo of two row tiles, B:
+// hi / lo of two column tiles), the request of chunk c + 1 behind the barrier of chunk c; eight waves x (4 x 2 tiles of 32 x 32),
+// 164 VGPRs.  Same box, 16384 x 8192: V H^T k = 256 165.8 -> 154.8 us, k = 512 309.6 -> 286.6; W^T V 170.3 -> 164.0, 315.2 -> 298.0
+// (the numerator's four slabs instead of two cost the update launch 8 us of that at k = 256).  A five-slot ring of half stages (one
+// and a half chunks in flight, all 160 KiB) was no faster than the two whole stages.  NMFX_GXT2=0: the 256 x 128 kernel everywhere.
+constexpr int GXT2_STAGE = 8 * 8192, GXT2_SHM = 2 * GXT2_STAGE;
+template <int TERMS>
+__global__ __launch_bounds__(512) void gxt2_gemm_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, const unsigned short* __restrict__ Bhi,
+    const unsigned short* __restrict__ Blo, float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t K,
+    const int* __restrict__ flag, const int* __restrict__ flag2)
+{
+    if (*flag || (flag2 && *flag2)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gxt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, n31 = lane & 31, b = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t kch = K / 32, nch = kch / gridDim.z, c0 = nch * blockIdx.z;
+    const int64_t at0 = 2 * (int64_t)blockIdx.y, bt0 = 2 * (int64_t)blockIdx.x;
+    unsigned long long src[8];
+    src[0] = (unsigned long long)(Ahi + (at0 * kch + c0) * 4096) + wave * 1024ull;
+    src[1] = (unsigned long long)(Ahi + ((at0 + 1) * kch + c0) * 4096) + wave * 1024ull;
+    src[2] = (unsigned long long)(Alo + (at0 * kch + c0) * 4096) + wave * 1024ull;
+    src[3] = (unsigned long long)(Alo + ((at0 + 1) * kch + c0) * 4096) + wave * 1024ull;
+    src[4] = (unsigned long long)(Bhi + (bt0 * kch + c0) * 4096) + wave * 1024ull;
+    src[5] = (unsigned long long)(Bhi + ((bt0 + 1) * kch + c0) * 4096) + wave * 1024ull;
+    src[6] = (unsigned long long)(Blo + (bt0 * kch + c0) * 4096) + wave * 1024ull;
+    src[7] = (unsigned long long)(Blo + ((bt0 + 1) * kch + c0) * 4096) + wave * 1024ull;
+    const unsigned smem0 = __builtin_amdgcn_readfirstlane(gxt_lds_off(gxt_smem));
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int64_t c, int stage) {
+        const unsigned dst = smem0 + stage * GXT2_STAGE + wave * 1024;
+        const unsigned long long adv = (unsigned long long)c * 8192ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gxt_dma(src[u] + adv, dst + u * 8192, voff);
+    };
+    const int wr = 128 * (wave >> 2), wc = 64 * (wave & 3);
+    int aoff[4][2], boff[2][2];                       // [tile][k-step]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ra = 32 * t + n31;
+            aoff[t][ks] = (wr >> 7) * 8192 + ra * 64 + 16 * ((2 * ks + b) ^ ((ra >> 2) & 3));            // + 16384: lo
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rb = wc + 32 * t + n31, rr = rb & 127;
+            boff[t][ks] = 4 * 8192 + (rb >> 7) * 8192 + rr * 64 + 16 * ((2 * ks + b) ^ ((rr >> 2) & 3));    // + 16384: lo
+        }
+    }
+    gxb_f32x16 acc[4][2];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+    issue(0, 0);
+    for (int64_t c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // chunk c has landed everywhere; everybody has left the other stage
+        if (c + 1 < nch) issue(c + 1, (int)((c + 1) & 1));
+        const unsigned char* sta = gxt_smem + (c & 1) * GXT2_STAGE;
+        const unsigned char* stb = sta;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            GxbFrag bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[t].u = *reinterpret_cast<const uint4*>(stb + boff[t][ks]);
+                bl[t].u = *reinterpret_cast<const uint4*>(stb + boff[t][ks] + 16384);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                GxbFrag ah, al;
+                ah.u = *reinterpret_cast<const uint4*>(sta + aoff[ti][ks]);
+                al.u = *reinterpret_cast<const uint4*>(sta + aoff[ti][ks] + 16384);
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    acc[ti][tj] = GXB_MFMA(ah, bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(al, bh[tj], acc[ti][tj]);
+                    acc[ti][tj] = GXB_MFMA(ah, bl[tj], acc[ti][tj]);
+                    if (TERMS >= 4) acc[ti][tj] = GXB_MFMA(al, bl[tj], acc[ti][tj]);
+                }
+            }
+        }
+    }
+    float* Cz = C + (int64_t)blockIdx.z * cstride;
+    const int64_t i0 = (int64_t)blockIdx.y * 256 + wr, j0 = (int64_t)blockIdx.x * 256 + wc;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                Cz[(i0 + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * b) * ldc + j0 + 32 * tj + n31] = acc[ti][tj][r];
+}
+
 // ---- the SHORT contractions (objective, KL quotient: contraction over the factor index, V-sized output that never leaves the chip as
 // f32) as a PERSISTENT form of the kernel above (r4) ---------------------------------------------------------------------------------
 // gxb_gemm_kernel spent a block per 128 x 128 output tile: with eight 32-deep chunks per tile (k = 256) the head of the operand
@@ -927,6 +1042,10 @@ __global__ __launch_bounds__(512) void gxr_kernel(
             if (j < 0) { if (tile == t0) return 0; j += nch; }
             return MODE == GX_KLQ ? ((j < 8 && (j & 1)) ? 16 : 0) : (j < 4 ? 16 : 0);
         };
+        // (Measured and dropped: touching the next tile's X half a tile ahead -- two dword loads per lane, one per 128-byte line of the
+        //  wave's 64 x 64 floats, values dropped -- so that the requests proper find their lines in L2: objective 203 -> 235 us, KL
+        //  quotient 330 -> 415.  Those 128 extra lines per wave and tile cost as much as the 64 X loads themselves: the launch is
+        //  paced by the lines the CU's vector-memory path takes in, ~36 bytes per clock, not by the latency of X.)
         auto wait_chunk = [&](int c, bool last) {
             if (last) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
             const int n = 6 + n_x(c - 2) + n_s(c - 1) + n_x(c - 1) + (early ? n_s(c - 2) : 0);
@@ -1062,14 +1181,23 @@ int gxr_launch(nmfx_engine* E, int mode, const unsigned short* Ahi, const unsign
 // One 64 x 64 tile per block through LDS; every global store is a 16-byte chunk of eight contraction indices.
 __global__ __launch_bounds__(256) void gxt_split_kernel(const float* __restrict__ M, int64_t rows, int64_t cols, int fmt_n,
                                                         unsigned short* __restrict__ nhi, unsigned short* __restrict__ nlo, int fmt_t,
-                                                        unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, const int* __restrict__ flag)
+                                                        unsigned short* __restrict__ thi, unsigned short* __restrict__ tlo, const int* __restrict__ flag,
+                                                        GxUpd up)
 {
     if (flag && *flag) return;                         // (a stopped run keeps the images of the iterate it stopped at)
     __shared__ __attribute__((aligned(16))) unsigned short sh[64][72], sl[64][72];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     for (int r = ty; r < 64; r += 4) {
-        const float v = M[(r0 + r) * cols + c0 + tx];
+        const int64_t idx = (r0 + r) * cols + c0 + tx;
+        float v;
+        if (up.xold) {                                 // (block-uniform)
+            const float xo = up.xold[idx];
+            float nu = up.num[idx];
+            for (int sl = 1; sl < up.nslab; ++sl) nu += up.num[sl * up.nstride + idx];
+            v = xo * nu / (up.den[idx] + up.lam * xo + 1e-9f);
+            up.xnew[idx] = v;
+        } else v = M[idx];
         unsigned hi, lo;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v), "v"(0.f));
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v - __uint_as_float(hi << 16)), "v"(0.f));
@@ -1101,25 +1229,47 @@ __global__ __launch_bounds__(256) void gxt_split_kernel(const float* __restrict_
 }
 
 int gxt_split(nmfx_engine* E, const float* M, int64_t rows, int64_t cols, int fmt_n, unsigned short* nhi, unsigned short* nlo, int fmt_t,
-              unsigned short* thi, unsigned short* tlo, bool check_flag) {
+              unsigned short* thi, unsigned short* tlo, bool check_flag, const GxUpd& up = GxUpd()) {
     hipLaunchKernelGGL(gxt_split_kernel, dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, E->stream, M, rows, cols, fmt_n, nhi, nlo,
-                       fmt_t, thi, tlo, check_flag ? (const int*)&E->state->flag : (const int*)nullptr);
+                       fmt_t, thi, tlo, check_flag ? (const int*)&E->state->flag : (const int*)nullptr, up);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 // the factor images of the composed path: W -> Whi / Wlo [mp][kp] row-major (short contractions: objective, quotient) and W^T tiled
 // (W^T V, W^T W); H -> tiled (V H^T, H H^T) and H^T [np][kp] row-major
-int gxb_images_w(nmfx_engine* E, const float* W) {
-    return gxt_split(E, W, E->mp, E->kp, gxr_on() ? 2 : 1, E->Whi[0], E->Wlo[0], 2, E->WThi, E->WTlo, true);
+int gxb_images_w(nmfx_engine* E, const float* W, const GxUpd& up = GxUpd()) {
+    return gxt_split(E, W, E->mp, E->kp, gxr_on() ? 2 : 1, E->Whi[0], E->Wlo[0], 2, E->WThi, E->WTlo, true, up);
 }
-int gxb_images_h(nmfx_engine* E, const float* H) {
-    return gxt_split(E, H, E->kp, E->np, 2, E->Hhi, E->Hlo, gxr_on() ? 2 : 1, E->HThi, E->HTlo, true);
+int gxb_images_h(nmfx_engine* E, const float* H, const GxUpd& up = GxUpd()) {
+    return gxt_split(E, H, E->kp, E->np, 2, E->Hhi, E->Hlo, gxr_on() ? 2 : 1, E->HThi, E->HTlo, true, up);
 }
 
 // split-K product on the tiled planes into the slab buffer gx_s, summed into `out` (M: rows of A, N: rows of B, K: contraction)
 int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi, const unsigned short* Blo,
-                      float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3) {
+                      float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3, const float** slabs = nullptr, int* nslab = nullptr) {
+    // (slabs != nullptr: the caller sums the slabs itself -- *slabs / *nslab say where they are -- and `out` is only written when there is one)
     int rc;
+    static const int big = getenv("NMFX_GXT2") ? atoi(getenv("NMFX_GXT2")) : 1;
+    if (big && M % 256 == 0 && N % 256 == 0 && M * N >= 256 * 256 * 16) {      // 256 x 256 tiles (V-sized products)
+        const int64_t blocks = (M / 256) * (N / 256), ch = K / 32;
+        int64_t S = std::max<int64_t>(1, std::min<int64_t>(2 * cap, ((int64_t)E->ncu + blocks - 1) / blocks));
+        const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);
+        while (S > 1 && (S * M * N > slab_cap || ch % S)) --S;
+        const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)S), block(512);
+        float* C = S == 1 ? out : E->gx_s;
+        const int* flag = &E->state->flag;
+        if (terms == 4) {
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt2_gemm_kernel<4>), GXT2_SHM))) return rc;
+            hipLaunchKernelGGL((gxt2_gemm_kernel<4>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr);
+        } else {
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt2_gemm_kernel<3>), GXT2_SHM))) return rc;
+            hipLaunchKernelGGL((gxt2_gemm_kernel<3>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr);
+        }
+        NMFX_HIP(hipGetLastError());
+        if (slabs) { *slabs = C; *nslab = (int)S; return NMFX_OK; }
+        if (S == 1) return NMFX_OK;
+        return nmfx_launch_sum_partials(E, E->gx_s, (int)S, M * N, out);
+    }
     const int64_t blocks = ((M / 128 + 1) / 2) * (N / 128), ch = K / 32;
     int64_t S = std::max<int64_t>(1, std::min<int64_t>(cap, ((int64_t)E->ncu + blocks - 1) / blocks));
     const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);
@@ -1135,6 +1285,7 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
         hipLaunchKernelGGL((gxt_gemm_kernel<3>), grid, block, GXT_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, M, K, flag, (const int*)nullptr, gx_stagger());
     }
     NMFX_HIP(hipGetLastError());
+    if (slabs) { *slabs = C; *nslab = (int)S; return NMFX_OK; }
     if (S == 1) return NMFX_OK;
     return nmfx_launch_sum_partials(E, E->gx_s, (int)S, M * N, out);
 }
@@ -1229,6 +1380,16 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
         if ((rc = nmfx_launch_obj_reduce(E, nblk, E->gx_part))) return rc;
         { ProfScope ps(E, "gram_nt");
           if ((rc = gxt_split_product(E, E->Hhi, E->Hlo, E->Hhi, E->Hlo, E->HHt, kp, kp, np, 64))) return rc; }
+        if (gx_fuse_update()) {                        // r4: slab sum, update and the images of W_new in one launch behind D = W (H H^T)
+            const float* slabs = nullptr; int nslab = 0;
+            { ProfScope ps(E, "wphase");               // A = V H^T
+              if ((rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 3, &slabs, &nslab))) return rc; }
+            ProfScope ps(E, "w_update");
+            if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
+            GxUpd up;
+            up.xold = W; up.num = slabs; up.nslab = nslab; up.nstride = mp * kp; up.den = E->gx_d; up.lam = (float)lambda; up.xnew = Wn;
+            if ((rc = gxb_images_w(E, Wn, up))) return rc;
+        } else {
         { ProfScope ps(E, "wphase");                   // A = V H^T
           if ((rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4))) return rc; }
         { ProfScope ps(E, "w_update");
@@ -1239,6 +1400,7 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
           NMFX_HIP(hipGetLastError()); }
         { ProfScope ps(E, "images");
           if ((rc = gxb_images_w(E, Wn))) return rc; }
+        }
         { ProfScope ps(E, "gram_tn");
           if ((rc = gxt_split_product(E, E->WThi, E->WTlo, E->WThi, E->WTlo, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");                   // B = W^T V
@@ -1328,7 +1490,13 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
     hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
                        E->state, E->obj_hist);
     NMFX_HIP(hipGetLastError());
-    if (!kl) {
+    if (!kl && gxb_on(E) && E->gxb_img_ready && gx_fuse_update()) {
+        // r4: the update and the images of the new H in one launch behind E = G H (element-wise, so H is updated in place)
+        if ((rc = gx_launch<true, false>(E, GX_STORE, xG, kp, E->H, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc;
+        GxUpd up;
+        up.xold = E->H; up.num = xB; up.nslab = 1; up.den = E->gx_d; up.lam = (float)lambda; up.xnew = E->H;
+        if ((rc = gxb_images_h(E, E->H, up))) return rc;
+    } else if (!kl) {
         if ((rc = gx_launch<true, false>(E, GX_STORE, xG, kp, E->H, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc;
         const int64_t c4 = kp * np / 4;
         hipLaunchKernelGGL(gx_eu_update_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->H, (const float*)xB,
