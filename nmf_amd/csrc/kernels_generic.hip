@@ -980,6 +980,7 @@ __global__ __launch_bounds__(512) void gxr_kernel(
                 const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hi : lo), 0xB1, 0xf, 0xf, false);
                 const unsigned word = __builtin_amdgcn_perm(odd ? lo : other, odd ? other : hi, 0x05040100u);
                 unsigned short* q = ((r >> 2) & 1) ? p_q1 : p_q0;
+                // (plain stores: non-temporal ones made this launch 8 % slower and the product that reads the planes 4 % faster)
                 *reinterpret_cast<unsigned*>(q + tj * 4096 + ti * 1024 + 32 * ((r & 3) + 8 * (r >> 2))) = word;
                 if (OBJ) {
                     float t = x1 * (__builtin_amdgcn_logf(x1 * __builtin_amdgcn_rcpf(cv)) * 0.69314718055994531f);
@@ -1009,18 +1010,20 @@ __global__ __launch_bounds__(512) void gxr_kernel(
                 for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
         // X quarter h = (ti = h >> 1, rows r = 8 (h & 1) .. + 7, both column tiles): 16 dword loads, each a full 128-byte line per
         // half-wave (a lane's 16 entries of a 32 x 32 accumulator tile are one COLUMN: 16-byte loads along the rows touched 64 lines
-        // per instruction and the texture path, not the matrix pipe, set the pace: 240 us per launch against 170 without X)
+        // per instruction and the texture path, not the matrix pipe, set the pace: 240 us per launch against 170 without X);
+        // non-temporal, so that the stream of V does not push the factor images out of the XCD's L2 (PMC: 849 MB fetched per
+        // launch against 562 MB of V and images; objective 206.7 -> 202 us, KL quotient 336 -> 310)
 #define GXR_XQ(h) do { \
             const unsigned long long r0_ = xb + (unsigned long long)(32 * ((h) >> 1) + 16 * ((h) & 1)) * ldx4; \
             const int o_ = 32 * ((h) >> 1) + 8 * ((h) & 1); \
-            asm volatile("global_load_dword %0, %16, %17\n\tglobal_load_dword %1, %16, %17 offset:128\n\t" \
-                         "global_load_dword %2, %16, %18\n\tglobal_load_dword %3, %16, %18 offset:128\n\t" \
-                         "global_load_dword %4, %16, %19\n\tglobal_load_dword %5, %16, %19 offset:128\n\t" \
-                         "global_load_dword %6, %16, %20\n\tglobal_load_dword %7, %16, %20 offset:128\n\t" \
-                         "global_load_dword %8, %16, %21\n\tglobal_load_dword %9, %16, %21 offset:128\n\t" \
-                         "global_load_dword %10, %16, %22\n\tglobal_load_dword %11, %16, %22 offset:128\n\t" \
-                         "global_load_dword %12, %16, %23\n\tglobal_load_dword %13, %16, %23 offset:128\n\t" \
-                         "global_load_dword %14, %16, %24\n\tglobal_load_dword %15, %16, %24 offset:128" \
+            asm volatile("global_load_dword %0, %16, %17 nt\n\tglobal_load_dword %1, %16, %17 offset:128 nt\n\t" \
+                         "global_load_dword %2, %16, %18 nt\n\tglobal_load_dword %3, %16, %18 offset:128 nt\n\t" \
+                         "global_load_dword %4, %16, %19 nt\n\tglobal_load_dword %5, %16, %19 offset:128 nt\n\t" \
+                         "global_load_dword %6, %16, %20 nt\n\tglobal_load_dword %7, %16, %20 offset:128 nt\n\t" \
+                         "global_load_dword %8, %16, %21 nt\n\tglobal_load_dword %9, %16, %21 offset:128 nt\n\t" \
+                         "global_load_dword %10, %16, %22 nt\n\tglobal_load_dword %11, %16, %22 offset:128 nt\n\t" \
+                         "global_load_dword %12, %16, %23 nt\n\tglobal_load_dword %13, %16, %23 offset:128 nt\n\t" \
+                         "global_load_dword %14, %16, %24 nt\n\tglobal_load_dword %15, %16, %24 offset:128 nt" \
                          : "=&v"(xv[o_ + 0]), "=&v"(xv[o_ + 16]), "=&v"(xv[o_ + 1]), "=&v"(xv[o_ + 17]), "=&v"(xv[o_ + 2]), "=&v"(xv[o_ + 18]), \
                            "=&v"(xv[o_ + 3]), "=&v"(xv[o_ + 19]), "=&v"(xv[o_ + 4]), "=&v"(xv[o_ + 20]), "=&v"(xv[o_ + 5]), "=&v"(xv[o_ + 21]), \
                            "=&v"(xv[o_ + 6]), "=&v"(xv[o_ + 22]), "=&v"(xv[o_ + 7]), "=&v"(xv[o_ + 23]) \

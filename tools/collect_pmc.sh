@@ -30,7 +30,7 @@ for f in sorted(glob.glob(out + "/*.csv")):
     probe = os.path.basename(f).split("_")[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "xyt32_bf16_kernel" not in k and "xyt_bf16_kernel" not in k and "gxb_gemm_kernel" not in k and "gxt_gemm_kernel" not in k:
+        if not any(t in k for t in ("xyt32_bf16_kernel", "xyt_bf16_kernel", "gxb_gemm_kernel", "gxt_gemm_kernel", "gxt2_gemm_kernel", "gxr_kernel")):
             continue
         short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
