@@ -628,6 +628,11 @@ __device__ __forceinline__ void gxt_dma(unsigned long long base, unsigned dst, u
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "s"(dst), "v"(voff) : "memory");
 }
+__device__ __forceinline__ void gxt_dma_nt(unsigned long long base, unsigned dst, unsigned voff) {      // the once-read operand: non-temporal
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(dst), "v"(voff) : "memory");
+}
 constexpr int GXT_STAGE = 6 * 8192, GXT_SHM = 3 * GXT_STAGE;
 
 int gx_stagger() { static const int v = getenv("NMFX_GX_STAGGER") ? atoi(getenv("NMFX_GX_STAGGER")) : 1; return v; }
@@ -771,8 +776,10 @@ template <int TERMS>
 __global__ __launch_bounds__(512) void gxt2_gemm_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, const unsigned short* __restrict__ Bhi,
     const unsigned short* __restrict__ Blo, float* __restrict__ C, int64_t ldc, int64_t cstride, int64_t K,
-    const int* __restrict__ flag, const int* __restrict__ flag2)
+    const int* __restrict__ flag, const int* __restrict__ flag2, int nt)
 {
+    // nt: bit 0 / 1 = the A / B planes are read once per launch (the V planes of V H^T, the V^T planes of W^T V): non-temporal
+    // requests, so that they do not push the other operand -- the factor images every block re-reads -- out of L2
     if (*flag || (flag2 && *flag2)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char gxt_smem[];
     const int tid = threadIdx.x, lane = tid & 63, n31 = lane & 31, b = lane >> 5;
@@ -793,8 +800,20 @@ __global__ __launch_bounds__(512) void gxt2_gemm_kernel(
     auto issue = [&](int64_t c, int stage) {
         const unsigned dst = smem0 + stage * GXT2_STAGE + wave * 1024;
         const unsigned long long adv = (unsigned long long)c * 8192ull;
+        if (nt & 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gxt_dma(src[u] + adv, dst + u * 8192, voff);
+            for (int u = 0; u < 4; ++u) gxt_dma_nt(src[u] + adv, dst + u * 8192, voff);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gxt_dma(src[u] + adv, dst + u * 8192, voff);
+        }
+        if (nt & 2) {
+#pragma unroll
+            for (int u = 4; u < 8; ++u) gxt_dma_nt(src[u] + adv, dst + u * 8192, voff);
+        } else {
+#pragma unroll
+            for (int u = 4; u < 8; ++u) gxt_dma(src[u] + adv, dst + u * 8192, voff);
+        }
     };
     const int wr = 128 * (wave >> 2), wc = 64 * (wave & 3);
     int aoff[4][2], boff[2][2];                       // [tile][k-step]
@@ -1259,14 +1278,18 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
         const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);
         while (S > 1 && (S * M * N > slab_cap || ch % S)) --S;
         const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)S), block(512);
+        static const int nt_on = getenv("NMFX_GXT_NT") ? atoi(getenv("NMFX_GXT_NT")) : 1;
+        // (an operand is read once where the other dimension is a single tile: with two column tiles -- k = 512 -- the second one finds
+        //  the V planes in L2 and non-temporal requests cost 4 %; k = 256: V H^T 174.6 -> 169.4 us, W^T V 180.3 -> 176.5)
+        const int nt = !nt_on ? 0 : ((N == 256 && M > 256 ? 1 : 0) | (M == 256 && N > 256 ? 2 : 0));
         float* C = S == 1 ? out : E->gx_s;
         const int* flag = &E->state->flag;
         if (terms == 4) {
             if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt2_gemm_kernel<4>), GXT2_SHM))) return rc;
-            hipLaunchKernelGGL((gxt2_gemm_kernel<4>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr);
+            hipLaunchKernelGGL((gxt2_gemm_kernel<4>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr, nt);
         } else {
             if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(gxt2_gemm_kernel<3>), GXT2_SHM))) return rc;
-            hipLaunchKernelGGL((gxt2_gemm_kernel<3>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr);
+            hipLaunchKernelGGL((gxt2_gemm_kernel<3>), grid, block, GXT2_SHM, E->stream, Ahi, Alo, Bhi, Blo, C, N, M * N, K, flag, (const int*)nullptr, nt);
         }
         NMFX_HIP(hipGetLastError());
         if (slabs) { *slabs = C; *nslab = (int)S; return NMFX_OK; }
