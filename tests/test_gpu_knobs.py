@@ -65,6 +65,17 @@ CASES = [
     ({"NMFX_PREPARE_SCALAR": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_PRECISION": "f32"}, "admm", (384, 320, 160), dict(rho=1.0, reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     # the bf16 operand planes "do not fit": the handle falls back to the exact-f32 product kernel (and says so in nmfx_get_note)
+    # r4: the composed path's alternatives -- short contractions on gxb_gemm_kernel, 256 x 128 tiles everywhere, separate update / image launches,
+    # no wave stagger / DMA pieces between the MFMA groups (512 x 512 pads to whole 256 x 256 tiles, so the default run takes gxt2_gemm_kernel)
+    ({"NMFX_GXR": "0"}, "mur", (384, 256, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
+    ({"NMFX_GXR": "0"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
+    ({"NMFX_GXT2": "0"}, "mur", (512, 512, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
+    ({"NMFX_GXT2": "0"}, "mur", (512, 512, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
+    ({"NMFX_GXT_NT": "0"}, "mur", (1024, 768, 160), dict(distance_type="eu", lambda_w=0.1, lambda_h=0.05, min_iter=8, max_iter=8)),
+    ({"NMFX_GX_FUSE_UPDATE": "0"}, "mur", (512, 512, 160), dict(distance_type="eu", lambda_w=0.1, lambda_h=0.05, min_iter=10, max_iter=10)),
+    ({"NMFX_GX_STAGGER": "0"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
+    ({"NMFX_GX_STAGGER": "16"}, "mur", (384, 256, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
+    ({"NMFX_GXR": "0"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_GXB_NOFIT": "1"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
     ({"NMFX_GXB_NOFIT": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
 ]
