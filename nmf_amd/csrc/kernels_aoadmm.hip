@@ -688,6 +688,166 @@ __device__ __forceinline__ void ao_split8x3(const float4& p, const float4& q, Ao
     ao_split2x3(q.x, q.y, hi.u.z, mid.u.z, lo.u.z); ao_split2x3(q.z, q.w, hi.u.w, mid.u.w, lo.u.w);
 }
 
+// ---- r4: the any-rank rounds with the product aux = rhs M^-1 on the bf16 matrix cores (k padded to 256 / 384) ------------------------
+// ao_round_*_any_kernel multiply in exact f32 (v_mfma_f32_16x16x4_f32): 64 x kp x kp MACs per block are 15 us of a 30-38 us round at
+// kp = 256.  Here both operands are the three bf16 images of above (hi + mid + lo = the f32 value exactly), six terms, on
+// v_mfma_f32_16x16x32_bf16: 0.375 of the matrix time.  M^-1's images are made once per sub-problem (ao_minv_images_kernel: [3][kp][kp],
+// L2-resident, the operand fragments are 16-byte global loads, the next k-step's in flight under the MFMAs of the current one); the
+// right-hand side tile of the block's 64 rows (W) / columns (H) is split once, cooperatively, into LDS ([3][64][kp + 8] bf16: rows 16
+// bytes apart from a multiple of 128, so the sixteen rows of a fragment read fall on distinct bank groups).  One kernel for both
+// sides: the accumulator tile is (entity, factor) either way, only the global addressing differs (COLS: X is [kp][np]).
+__global__ __launch_bounds__(256) void ao_minv_images_kernel(const float* __restrict__ Minv, int kp, unsigned short* __restrict__ img, const DevState* __restrict__ st)
+{
+    if (st->flag) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, kk = (int64_t)kp * kp;
+    if (8 * i >= kk) return;
+    const float4 a = *reinterpret_cast<const float4*>(Minv + 8 * i), b = *reinterpret_cast<const float4*>(Minv + 8 * i + 4);
+    AoFrag8 h, m, l;
+    ao_split8x3(a, b, h, m, l);
+    *reinterpret_cast<uint4*>(img + 8 * i) = h.u;
+    *reinterpret_cast<uint4*>(img + kk + 8 * i) = m.u;
+    *reinterpret_cast<uint4*>(img + 2 * kk + 8 * i) = l.u;
+}
+
+template <bool COLS>
+__global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
+    const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, const unsigned short* __restrict__ Mimg, int kp, int64_t ld,
+    int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm, const double* __restrict__ nrm_global)
+{
+    // ld: COLS -- np (X, U, Bsum are [kp][np], the block's entities are 64 columns); else kp (they are [mp][kp], 64 rows)
+    if (st->flag || st->inner_stop) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    const int LDR = kp + 8;                            // bf16 elements per entity row of an image
+    unsigned short* rimg = reinterpret_cast<unsigned short*>(smem_r);              // [3][64][LDR]
+    double* sh = reinterpret_cast<double*>(smem_r + (size_t)3 * 64 * LDR * 2);
+    const int nblk = gridDim.x, JT = kp / 16, KS = kp / 32;
+    if (round > 0 && (nrm_global ? inner_round_fired(nrm_global, 1, sh)
+                                 : inner_round_fired(nrm + (int64_t)((round - 1) & 1) * nblk * 4, nblk, sh))) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_stop = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->inner_count = round + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
+    const float rho = (float)st->rho;
+    const float shift = (prox == NMFX_PROX_L1N) ? (float)((double)lam / st->rho) : 0.f;
+    const int64_t e0 = (int64_t)blockIdx.x * 64;
+    const int64_t kk = (int64_t)kp * kp;
+    // RHS = B + rho (X + U), split into its three images: entity r, factors 8 c8 .. + 7
+    if (!COLS) {
+#pragma unroll 4
+        for (int i = tid; i < 64 * (kp / 8); i += 256) {   // (kp / 32 units per thread, four units' 24 loads in flight together)
+            const int r = i / (kp / 8), c8 = i % (kp / 8);
+            const int64_t g = (e0 + r) * kp + 8 * c8;
+            float4 t[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const float4 a = *reinterpret_cast<const float4*>(Bsum + g + 4 * hlf), w = *reinterpret_cast<const float4*>(X + g + 4 * hlf);
+                const float4 d = *reinterpret_cast<const float4*>(U + g + 4 * hlf);
+                t[hlf] = make_float4(a.x + rho * (w.x + d.x), a.y + rho * (w.y + d.y), a.z + rho * (w.z + d.z), a.w + rho * (w.w + d.w));
+            }
+            AoFrag8 h, m, l;
+            ao_split8x3(t[0], t[1], h, m, l);
+            *reinterpret_cast<uint4*>(rimg + r * LDR + 8 * c8) = h.u;
+            *reinterpret_cast<uint4*>(rimg + (64 + r) * LDR + 8 * c8) = m.u;
+            *reinterpret_cast<uint4*>(rimg + (128 + r) * LDR + 8 * c8) = l.u;
+        }
+    } else {
+        for (int i = tid; i < 16 * (kp / 8); i += 256) {                          // four columns x eight factors per unit
+            const int cg = i & 15, c8 = i >> 4;
+            float v[8][4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int64_t g = (int64_t)(8 * c8 + t) * ld + e0 + 4 * cg;
+                const float4 a = *reinterpret_cast<const float4*>(Bsum + g), w = *reinterpret_cast<const float4*>(X + g), d = *reinterpret_cast<const float4*>(U + g);
+                v[t][0] = a.x + rho * (w.x + d.x); v[t][1] = a.y + rho * (w.y + d.y); v[t][2] = a.z + rho * (w.z + d.z); v[t][3] = a.w + rho * (w.w + d.w);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                AoFrag8 h, m, l;
+                ao_split8x3(make_float4(v[0][c], v[1][c], v[2][c], v[3][c]), make_float4(v[4][c], v[5][c], v[6][c], v[7][c]), h, m, l);
+                const int r = 4 * cg + c;
+                *reinterpret_cast<uint4*>(rimg + r * LDR + 8 * c8) = h.u;
+                *reinterpret_cast<uint4*>(rimg + (64 + r) * LDR + 8 * c8) = m.u;
+                *reinterpret_cast<uint4*>(rimg + (128 + r) * LDR + 8 * c8) = l.u;
+            }
+        }
+    }
+    __syncthreads();
+    // wave w takes the factor tiles w, w + 4, .. of all 64 entities, ONE TILE AT A TIME: the tile's X / U values are requested first
+    // and land under its 6 x 4 x kp / 32 MFMAs; the epilogue of tile r then runs beside the other waves' matrix work (all tiles'
+    // products first and all epilogues behind them left every wave waiting for its 64 scattered loads at the same time)
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+    for (int it = wave; it < JT; it += 4) {
+        float xo[4][4], uo[4][4];                      // [rt][g]
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            if (COLS) {                                // four consecutive columns of factor row 16 it + x
+                const int64_t idx = (int64_t)(16 * it + x) * ld + e0 + 16 * rt + 4 * q;
+                const float4 h4 = *reinterpret_cast<const float4*>(X + idx), u4 = *reinterpret_cast<const float4*>(U + idx);
+                xo[rt][0] = h4.x; xo[rt][1] = h4.y; xo[rt][2] = h4.z; xo[rt][3] = h4.w;
+                uo[rt][0] = u4.x; uo[rt][1] = u4.y; uo[rt][2] = u4.z; uo[rt][3] = u4.w;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t idx = (e0 + 16 * rt + 4 * q + g) * kp + 16 * it + x;
+                    xo[rt][g] = X[idx]; uo[rt][g] = U[idx];
+                }
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // M^-1 operand: row 16 it + x, factors 32 u + 8 q .. + 7 of each image; the next k-step's in flight under this one's MFMAs
+        const unsigned short* mrow = Mimg + (int64_t)(16 * it + x) * kp + 8 * q;
+        AoFrag8 mh, mm, ml, nh, nm, nl;
+        mh.u = *reinterpret_cast<const uint4*>(mrow); mm.u = *reinterpret_cast<const uint4*>(mrow + kk); ml.u = *reinterpret_cast<const uint4*>(mrow + 2 * kk);
+        for (int u = 0; u < KS; ++u) {
+            const int un = u + 1 < KS ? u + 1 : u;
+            nh.u = *reinterpret_cast<const uint4*>(mrow + 32 * un); nm.u = *reinterpret_cast<const uint4*>(mrow + kk + 32 * un);
+            nl.u = *reinterpret_cast<const uint4*>(mrow + 2 * kk + 32 * un);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {           // acc[rt][g]: entity 16 rt + 4 q + g, factor 16 it + x
+                const int off = (16 * rt + x) * LDR + 32 * u + 8 * q;
+                AoFrag8 rh, rm, rl;
+                rh.u = *reinterpret_cast<const uint4*>(rimg + off);
+                rm.u = *reinterpret_cast<const uint4*>(rimg + 64 * LDR + off);
+                rl.u = *reinterpret_cast<const uint4*>(rimg + 128 * LDR + off);
+                acc[rt] = AO_MFMA_BF16(rh, mh, acc[rt]);
+                acc[rt] = AO_MFMA_BF16(rm, mh, acc[rt]);
+                acc[rt] = AO_MFMA_BF16(rh, mm, acc[rt]);
+                acc[rt] = AO_MFMA_BF16(rl, mh, acc[rt]);
+                acc[rt] = AO_MFMA_BF16(rh, ml, acc[rt]);
+                acc[rt] = AO_MFMA_BF16(rm, mm, acc[rt]);
+            }
+            mh = nh; mm = nm; ml = nl;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            float hn[4], un2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float ax = acc[rt][g];
+                hn[g] = prox_apply(ax, uo[rt][g], shift);
+                un2[g] = uo[rt][g] + hn[g] - ax;
+                const float d0 = hn[g] - ax, d2 = hn[g] - xo[rt][g];
+                n0 += d0 * d0; n1 += hn[g] * hn[g]; n2 += d2 * d2; n3 += un2[g] * un2[g];
+            }
+            if (COLS) {
+                const int64_t idx = (int64_t)(16 * it + x) * ld + e0 + 16 * rt + 4 * q;
+                *reinterpret_cast<float4*>(X + idx) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                *reinterpret_cast<float4*>(U + idx) = make_float4(un2[0], un2[1], un2[2], un2[3]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t idx = (e0 + 16 * rt + 4 * q + g) * kp + 16 * it + x;
+                    X[idx] = hn[g]; U[idx] = un2[g];
+                }
+            }
+        }
+    }
+    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+}
+
 // ---- all rounds of a sub-problem in ONE launch ------------------------------
 // A round only couples the blocks through `terminate` (four global norms, ao_admm.py:33-43).
 // The fused kernels therefore run ALL admm_iter rounds speculatively with X, U (and the
@@ -1358,6 +1518,28 @@ static int inner_rows(nmfx_engine* E, float* W, int prox, float lam, int round, 
 int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U, int prox, float lam, int round, const double* nrm_global) {
     if (E->kp > 512 || E->kp % 64) { E->err = "round_any: k padded to at most 512"; return NMFX_E_ARG; }
     int rc;
+    static const bool f32_rounds = getenv("NMFX_GX_ROUNDS_F32") != nullptr;
+    if (E->precision == 1 && !f32_rounds && E->kp % 32 == 0 && E->kp <= 384) {      // r4: the product on the bf16 matrix cores, three images, six terms
+        const int64_t kk = (int64_t)E->kp * E->kp;
+        if (!E->minv_img) NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&E->minv_img), (size_t)3 * kk * sizeof(unsigned short)));
+        if (round == 0) {                              // (the images of this sub-problem's M^-1: every sub-problem starts at round 0)
+            hipLaunchKernelGGL(ao_minv_images_kernel, dim3((unsigned)((kk / 8 + 255) / 256)), dim3(256), 0, E->stream, (const float*)E->Minv, (int)E->kp,
+                               E->minv_img, (const DevState*)E->state);
+            NMFX_HIP(hipGetLastError());
+        }
+        const size_t shm = (size_t)3 * 64 * (E->kp + 8) * sizeof(unsigned short) + 16 * sizeof(double);
+        if (cols) {
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<true>), (int)shm))) return rc;
+            hipLaunchKernelGGL((ao_round_any_bf16_kernel<true>), dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
+                               (int)E->kp, E->np, prox, lam, round, E->state, E->nrm_part, (const double*)nullptr);
+        } else {
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<false>), (int)shm))) return rc;
+            hipLaunchKernelGGL((ao_round_any_bf16_kernel<false>), dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
+                               (int)E->kp, E->kp, prox, lam, round, E->state, E->nrm_part, nrm_global);
+        }
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
     if (cols) {
         const size_t shm = (size_t)E->kp * 64 * sizeof(float) + 16 * sizeof(double);
         if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_cols_any_kernel), (int)shm))) return rc;

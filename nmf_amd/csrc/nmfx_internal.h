@@ -144,6 +144,7 @@ struct nmfx_engine {
     unsigned short *Whi[2] = {nullptr, nullptr}, *Wlo[2] = {nullptr, nullptr};   // [mp][kp]
     unsigned short *WThi = nullptr, *WTlo = nullptr;                              // [kp][mp]
     unsigned short *Hhi = nullptr, *Hlo = nullptr;   // [kp][np]
+    unsigned short* minv_img = nullptr;             // r4: the three bf16 images of M^-1 ([3][kp][kp]) of the any-rank rounds beyond k = 128
     unsigned short *HThi = nullptr, *HTlo = nullptr; // [np][kp], only where H^T is the Z operand (AO-ADMM's fused objective)
     double* nrm_part = nullptr;    // [blocks][4]
     double* nrm_rounds = nullptr;  // [admm_iter][blocks][4]: norm partials of the fused inner rounds
