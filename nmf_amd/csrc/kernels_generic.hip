@@ -1725,25 +1725,24 @@ __device__ __forceinline__ gx_f64x4 gx_tile64(const double* __restrict__ A, int6
     return acc;
 }
 
-__global__ __launch_bounds__(1024) void gx_bgj_init_kernel(const float* __restrict__ G, int kp, int k, double* __restrict__ T,
-                                                           DevState* __restrict__ st, double fixed_rho)
+// one block per row of T = G + rho I; every block takes the trace itself (k values), block 0 publishes rho and opens the sub-problem
+// (r4: as ONE block of 1024 threads, with a 64-bit division per element, this copy took 25 us of the 134 us chain at kp = 256)
+__global__ __launch_bounds__(256) void gx_bgj_init_kernel(const float* __restrict__ G, int kp, int k, double* __restrict__ T,
+                                                          DevState* __restrict__ st, double fixed_rho)
 {
     if (st->flag) return;
-    __shared__ double part[16];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double part[4];
+    const int tid = threadIdx.x, row = blockIdx.x;
     double tr = 0.0;
-    for (int i = tid; i < k; i += nt) tr += (double)G[(int64_t)i * kp + i];
+    for (int i = tid; i < k; i += 256) tr += (double)G[(int64_t)i * kp + i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
     if ((tid & 63) == 0) part[tid >> 6] = tr;
     __syncthreads();
-    double rho = 0.0;
-    for (int w = 0; w < nt / 64; ++w) rho += part[w];
-    rho /= (double)k;
+    double rho = (((part[0] + part[1]) + part[2]) + part[3]) / (double)k;
     if (fixed_rho >= 0.0) rho = fixed_rho;
-    const int64_t kk = (int64_t)kp * kp;
-    for (int64_t e = tid; e < kk; e += nt) T[e] = (double)G[e] + ((e / kp) == (e % kp) ? rho : 0.0);
-    if (tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
+    for (int c = tid; c < kp; c += 256) T[(int64_t)row * kp + c] = (double)G[(int64_t)row * kp + c] + (c == row ? rho : 0.0);
+    if (row == 0 && tid == 0) { st->rho = rho; st->inner_stop = 0; st->inner_count = 0; }
 }
 
 // C[kp][128] = -T[:, block p] D^-1
@@ -1807,7 +1806,7 @@ int gx_prepare(nmfx_engine* E, const float* G, double fixed_rho) {
         double* Tb[2] = {E->gx_w64, E->gx_w64 + kk};
         double* Dinv = E->gx_w64 + 2 * kk;
         double* C = Dinv + 128 * 128;
-        hipLaunchKernelGGL(gx_bgj_init_kernel, dim3(1), dim3(1024), 0, E->stream, G, kp, E->k, Tb[0], E->state, fixed_rho);
+        hipLaunchKernelGGL(gx_bgj_init_kernel, dim3((unsigned)kp), dim3(256), 0, E->stream, G, kp, E->k, Tb[0], E->state, fixed_rho);
         NMFX_HIP(hipGetLastError());
         for (int p = 0; p < nb; ++p) {
             const double* T = Tb[p & 1];
