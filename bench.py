@@ -204,8 +204,9 @@ def parity_block(v, w_g, h_g, obj_g, w_r, h_r, obj_r, block=2048):
 
 
 ALL_KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "sum_hht", "w_update", "pack",
-               "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "nnls", "small")
-V_SIZED = ("wphase", "wphase_noobj", "objective", "hphase")      # launches that stream V (or V^T) once
+               "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "kl_round_h", "kl_round_w", "transpose",
+               "nnls", "small")
+V_SIZED = ("wphase", "wphase_noobj", "objective", "hphase", "kl_vaux")      # launches that stream V (or V^T) once
 
 
 def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192, rows=None):
@@ -437,6 +438,8 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             w0, h0 = 0.05 * np.abs(rs.randn(m, k)), 0.05 * np.abs(rs.randn(k, n))      # Gram system at k = 256 is not positive definite: LinAlgError)
         elif init == "rand":                     # nmf/anls.py:104-105
             w0, h0 = rs.rand(m, k), rs.rand(k, n)
+        elif init == "rand_kl":                  # a start of the data's scale for the KL-loss ADMM variants (W H = O(1) everywhere: no 0 / 0 quotients)
+            w0, h0 = rs.rand(m, k) + 0.01, rs.rand(k, n) / k + 0.01
         else:                                    # NNDSVD 'zero' (nmf/utils.py:36-93) from the device's singular triplets
             class _Shape:
                 shape = (m, n)
@@ -491,8 +494,10 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                 "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
                 "dominant_kernel": ({"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
-                                     "algorithmic_bytes_per_launch": m * n * 4.0, "bound": "hbm",
-                                     "achieved_gbs": m * n * 4.0 / dsec / 1e9, "frac": m * n * 4.0 / dsec / 1e9 / PEAK_HBM_GBS}
+                                     # (the KL auxiliaries' update reads V and dual_v and writes dual_v and S: four V-sized streams)
+                                     "algorithmic_bytes_per_launch": m * n * 4.0 * (4 if dom == "kl_vaux" else 1), "bound": "hbm",
+                                     "achieved_gbs": m * n * 4.0 * (4 if dom == "kl_vaux" else 1) / dsec / 1e9,
+                                     "frac": m * n * 4.0 * (4 if dom == "kl_vaux" else 1) / dsec / 1e9 / PEAK_HBM_GBS}
                                     if bound == "hbm" else
                                     # split bf16: every algorithmic product is three bf16 MFMA terms (hi hi + lo hi + hi lo)
                                     {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (split bf16: 3 executed terms per product)",
@@ -570,6 +575,23 @@ def other_configs(torch, dev, only=None):
              flops=lambda t: 4.0 * 16384 * 8192 * 256 + 2.0 * 256 * 256 * (16384 + 8192) + 2.0 * 256 * 256 * (t[0] * 8192 + t[1] * 16384)
              + 2.0 * 256 ** 3 / 3,
              nbytes=lambda t: 2.0 * 16384 * 8192 * 4 + 8.0 * 256 * 4 * (t[0] * 8192 + t[1] * 16384)),
+        # the KL-loss variants (nmf/ao_admm.py:71-101, nmf/admm.py:303-315) on the config-3 shape: two V-sized auxiliaries (v_aux, dual_v)
+        # updated in EVERY inner round; split bf16 (r4: the auxiliaries as a mode of the product kernel) and the exact-f32 path beside it.
+        # Algorithmic work per inner round: the product of the right-hand side and the product inside the auxiliaries' update;
+        # V read, dual_v read + written, S written + read
+        dict(name="aoadmm_kl_on_cfg3_shape", workload="AO-ADMM KL loss, reg_w = reg_h = (0, 'nn'), V=16384x8192 f32, k=128, admm_iter=10, uniform "
+                                                      "random start of the data's scale (split bf16: auxiliaries as a mode of the product kernel)",
+             m=16384, n=8192, k=128, steps=3, warmup=1, init="rand_kl", admm_iter=T,
+             queue=lambda e, f, c: e.aoadmm_run(1, 0, 0.0, 0, 0.0, T, NEVER, 1e-3, 1e-3, f, c),
+             flops=lambda t: 4.0 * 16384 * 8192 * 128 * (t[0] + t[1]), nbytes=lambda t: 5.0 * 16384 * 8192 * 4 * (t[0] + t[1])),
+        dict(name="aoadmm_kl_exact_f32", workload="AO-ADMM KL loss on the config-3 shape with the exact-f32 kernels (NMFX_PRECISION=f32)",
+             m=16384, n=8192, k=128, steps=2, warmup=1, init="rand_kl", admm_iter=T, precision="f32",
+             queue=lambda e, f, c: e.aoadmm_run(1, 0, 0.0, 0, 0.0, T, NEVER, 1e-3, 1e-3, f, c),
+             flops=lambda t: 4.0 * 16384 * 8192 * 128 * (t[0] + t[1]), nbytes=lambda t: 5.0 * 16384 * 8192 * 4 * (t[0] + t[1])),
+        dict(name="admm_kl_on_cfg3_shape", workload="ADMM KL loss, rho = 1, reg_w = reg_h = (0, 'nn'), V=16384x8192 f32, k=128 (split bf16)",
+             m=16384, n=8192, k=128, steps=8, warmup=2, init="rand_kl",
+             queue=lambda e, f, c: e.admm_run(1, 1.0, 0, 0.0, 0, 0.0, NEVER, 1e-3, 1e-3, f, c),
+             flops=8.0 * 16384 * 8192 * 128, nbytes=7.0 * 16384 * 8192 * 4),
         # ADMM (nmf/admm.py:292-334) beyond 128 components: V-sized products with FOUR split-bf16 terms (they are fed back through the
         # unshifted-rho Gram systems), the objective of (w, h) by one more product; algorithmic work: three V-sized products
         dict(name="admm_k256_on_cfg2_shape", workload="ADMM Euclidean, rho = 1, reg_w = (0, 'nn'), reg_h = (0.1, 'l1n'), V=16384x8192 f32, k=256, "
