@@ -1272,7 +1272,7 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
     // (slabs != nullptr: the caller sums the slabs itself -- *slabs / *nslab say where they are -- and `out` is only written when there is one)
     int rc;
     static const int big = getenv("NMFX_GXT2") ? atoi(getenv("NMFX_GXT2")) : 1;
-    if (big && M % 256 == 0 && N % 256 == 0 && M * N >= 256 * 256 * 16) {      // 256 x 256 tiles (V-sized products)
+    if (big && M % 256 == 0 && N % 256 == 0 && M * N >= 2 * 256 * 256) {      // 256 x 256 tiles (not the Gram matrices: one tile)
         const int64_t blocks = (M / 256) * (N / 256), ch = K / 32;
         int64_t S = std::max<int64_t>(1, std::min<int64_t>(2 * cap, ((int64_t)E->ncu + blocks - 1) / blocks));
         const int64_t slab_cap = std::max<int64_t>(std::max<int64_t>(8 * (int64_t)E->kp * E->np, 64 * (int64_t)E->kp * E->kp), (E->mp / 64) * (int64_t)E->kp);
