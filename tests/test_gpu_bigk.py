@@ -299,3 +299,42 @@ def test_mur_eu_16384x8192_k256_vs_oracle():
     np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=2e-5)
     direct = direct_objective(v, res.w, res.h, "eu")
     assert abs(direct - res.obj_history[-1]) <= 1e-5 * direct
+
+
+def test_mur_kl_16384x8192_k256_vs_oracle():
+    """The config-2 matrix with k = 256 and the KL divergence: 3 outer iterations against the f64 oracle.  At this size the
+    quotient kernel is persistent (16 tiles of 256 x 128 per block, its epilogue inside the next tile, waits that count loads and stores
+    alike) and the long contractions run on 256 x 256 tiles with the quotient planes as their operand -- none of which a small shape
+    reaches (r4)."""
+    from nmf_amd.mur import mur
+    m, n, k, iters = 16384, 8192, 256, 3
+    v = R.planted_matrix(m, n, 64, seed=0, dtype=np.float32)
+    kw = dict(distance_type="kl", min_iter=iters, max_iter=iters)
+    np.random.seed(0)
+    res = mur(v, k, **kw)
+    np.random.seed(0)
+    with np.errstate(all="ignore"):
+        ref = R.mur(v, k, **kw)
+    assert res.i == ref.i == iters - 1
+    err = wh_error_blocked(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY KL {m}x{n} k={k}: WH {err:.2e}, objective max rel diff "
+          f"{np.max(np.abs(np.asarray(res.obj_history) - np.asarray(ref.obj_history)) / np.abs(ref.obj_history)):.2e}")
+    assert err < WH_TOL, err
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=4e-5)
+
+
+def test_aoadmm_4096x2048_k256_inner_rounds_on_the_bf16_matrix_cores():
+    """AO-ADMM at k = 256 on a shape with whole 256 x 256 output tiles and many 64-row / 64-column blocks per sub-problem: the
+    any-rank rounds' product on three bf16 images (r4) against the oracle, inner counts included."""
+    from nmf_amd.ao_admm import ao_admm
+    m, n, k = 4096, 2048, 256
+    v = R.planted_matrix(m, n, 48, seed=5, dtype=np.float32)
+    kw = dict(distance_type="eu", reg_w=(0.05, "l1n"), reg_h=(0.02, "l1n"), min_iter=4, max_iter=4, admm_iter=10, nndsvd_init=(True, "zero"))
+    res = ao_admm(v.copy(), k, **kw)
+    ref = R.ao_admm(v.astype(np.float64), k, **kw)
+    assert res.i == ref.i
+    assert [tuple(r) for r in ao_admm.last_inner_counts] == [tuple(t) for t in ref.trace["inner"]]
+    err = wh_error(res.w, res.h, ref.w, ref.h, v)
+    print(f"\nPARITY AO-ADMM {m}x{n} k={k}: WH {err:.2e}, inner {ao_admm.last_inner_counts}")
+    assert err < WH_TOL
+    np.testing.assert_allclose(res.obj_history, ref.obj_history, rtol=1e-4)
