@@ -1382,6 +1382,8 @@ int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
 
 }  // namespace
 
+static bool gx_anls_bf16() { static const bool on = !(getenv("NMFX_GX_ANLS_BF16") && atoi(getenv("NMFX_GX_ANLS_BF16")) == 0); return on; }
+
 // ---- MUR, Euclidean ----------------------------------------------------------------------------------------------------------
 int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j) {
     int rc;
@@ -2432,7 +2434,13 @@ int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t mi
     float* W = E->W[0];
     float* xB = E->xf32;
     float* xG = E->xf32 + kp * np;
-    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;     // obj[0] (anls.py:108)
+    // r4, split-bf16 runs: the two V-sized products from the V planes and the factor images with FOUR terms (like the k <= 128 ANLS:
+    // the right-hand sides of the NNLS systems), the Euclidean objective by the persistent residual kernel; the Gram matrices,
+    // whose conditioning decides the active sets, and the KL objective stay exact f32
+    bool bf = gxb_on(E) && gx_anls_bf16();
+    if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
+    E->gxb_img_ready = false;                          // (valid inside this call only)
+    if (first == 0 && count > 0 && (rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;     // obj[0] (anls.py:108)
     for (int64_t j = first; j < first + count; ++j) {
         hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
                            E->state, E->obj_hist);
@@ -2440,14 +2448,22 @@ int nmfx_generic_anls_run(nmfx_engine* E, double lam_w, double lam_h, int64_t mi
         { ProfScope ps(E, "gram_nt");
           if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
         { ProfScope ps(E, "wphase");
-          if ((rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1))) return rc; }
+          if (bf) rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 4);
+          else rc = gx_split_product<true, true>(E, E->V, np, E->H, np, E->A_part, mp, kp, np, 1);
+          if (rc) return rc; }
         if ((rc = gx_nnls(E, E->HHt, 2.0 * lam_w, E->A_part, W, 1, kp, E->m))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = gxb_images_w(E, W))) return rc; }
         { ProfScope ps(E, "gram_tn");
           if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc; }
         { ProfScope ps(E, "hphase");
-          if ((rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8))) return rc; }
+          if (bf) rc = gxt_split_product(E, E->WThi, E->WTlo, E->gxb_v[2], E->gxb_v[3], xB, kp, np, mp, 8, 4);
+          else rc = gx_split_product<false, false>(E, W, kp, E->V, np, xB, kp, np, mp, 8);
+          if (rc) return rc; }
         if ((rc = gx_nnls(E, xG, 2.0 * lam_h, xB, E->H, np, 1, E->n))) return rc;
-        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E))) return rc;
+        if (bf) { ProfScope ps(E, "images");
+                  if ((rc = gxb_images_h(E, E->H))) return rc; }
+        if ((rc = kl ? gx_kl_objective_partial(E) : gx_objective_partial(E, bf))) return rc;
     }
     return NMFX_OK;
 }
