@@ -709,8 +709,8 @@ __global__ __launch_bounds__(256) void ao_minv_images_kernel(const float* __rest
     *reinterpret_cast<uint4*>(img + 2 * kk + 8 * i) = l.u;
 }
 
-template <bool COLS>
-__global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
+template <bool COLS, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ao_round_any_bf16_kernel(
     const float* __restrict__ Bsum, float* __restrict__ X, float* __restrict__ U, const unsigned short* __restrict__ Mimg, int kp, int64_t ld,
     int prox, float lam, int round, DevState* __restrict__ st, double* __restrict__ nrm, const double* __restrict__ nrm_global)
 {
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
     // RHS = B + rho (X + U), split into its three images: entity r, factors 8 c8 .. + 7
     if (!COLS) {
 #pragma unroll 4
-        for (int i = tid; i < 64 * (kp / 8); i += 256) {   // (kp / 32 units per thread, four units' 24 loads in flight together)
+        for (int i = tid; i < 64 * (kp / 8); i += 64 * NWV) {   // (several units' 6 loads each in flight together)
             const int r = i / (kp / 8), c8 = i % (kp / 8);
             const int64_t g = (e0 + r) * kp + 8 * c8;
             float4 t[2];
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
             *reinterpret_cast<uint4*>(rimg + (128 + r) * LDR + 8 * c8) = l.u;
         }
     } else {
-        for (int i = tid; i < 16 * (kp / 8); i += 256) {                          // four columns x eight factors per unit
+        for (int i = tid; i < 16 * (kp / 8); i += 64 * NWV) {                     // four columns x eight factors per unit
             const int cg = i & 15, c8 = i >> 4;
             float v[8][4];
 #pragma unroll
@@ -773,11 +773,11 @@ __global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
         }
     }
     __syncthreads();
-    // wave w takes the factor tiles w, w + 4, .. of all 64 entities, ONE TILE AT A TIME: the tile's X / U values are requested first
+    // wave w takes the factor tiles w, w + NWV, .. of all 64 entities, ONE TILE AT A TIME: the tile's X / U values are requested first
     // and land under its 6 x 4 x kp / 32 MFMAs; the epilogue of tile r then runs beside the other waves' matrix work (all tiles'
     // products first and all epilogues behind them left every wave waiting for its 64 scattered loads at the same time)
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-    for (int it = wave; it < JT; it += 4) {
+    for (int it = wave; it < JT; it += NWV) {
         float xo[4][4], uo[4][4];                      // [rt][g]
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void ao_round_any_bf16_kernel(
             }
         }
     }
-    block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
+    block_store_norms<NWV>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * nblk + blockIdx.x) * 4, sh);
 }
 
 // ---- all rounds of a sub-problem in ONE launch ------------------------------
@@ -1527,14 +1527,15 @@ int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U
                                E->minv_img, (const DevState*)E->state);
             NMFX_HIP(hipGetLastError());
         }
-        const size_t shm = (size_t)3 * 64 * (E->kp + 8) * sizeof(unsigned short) + 16 * sizeof(double);
+        const size_t shm = (size_t)3 * 64 * (E->kp + 8) * sizeof(unsigned short) + 32 * sizeof(double);
+        constexpr int NWV = 8;                         // (two waves per SIMD: with four, a block's phases -- tile build, products, scattered X / U traffic -- ran one after the other)
         if (cols) {
-            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<true>), (int)shm))) return rc;
-            hipLaunchKernelGGL((ao_round_any_bf16_kernel<true>), dim3((unsigned)(E->np / 64)), dim3(256), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<true, NWV>), (int)shm))) return rc;
+            hipLaunchKernelGGL((ao_round_any_bf16_kernel<true, NWV>), dim3((unsigned)(E->np / 64)), dim3(64 * NWV), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
                                (int)E->kp, E->np, prox, lam, round, E->state, E->nrm_part, (const double*)nullptr);
         } else {
-            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<false>), (int)shm))) return rc;
-            hipLaunchKernelGGL((ao_round_any_bf16_kernel<false>), dim3((unsigned)(E->mp / 64)), dim3(256), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
+            if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(ao_round_any_bf16_kernel<false, NWV>), (int)shm))) return rc;
+            hipLaunchKernelGGL((ao_round_any_bf16_kernel<false, NWV>), dim3((unsigned)(E->mp / 64)), dim3(64 * NWV), shm, E->stream, B, X, U, (const unsigned short*)E->minv_img,
                                (int)E->kp, E->kp, prox, lam, round, E->state, E->nrm_part, nrm_global);
         }
         NMFX_HIP(hipGetLastError());
