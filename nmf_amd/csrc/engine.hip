@@ -229,7 +229,7 @@ int nmfx_destroy(nmfx_handle_t E) {
                     E->Wlo[0], E->Wlo[1], E->WThi, E->WTlo, E->Hhi, E->Hlo, E->HThi, E->HTlo, E->nrm_rounds, E->bkX, E->bkU,
                     E->nnls_ginv, E->nnls_todo, E->G_big, E->kl_part, E->Bt_chunk, E->gx_part, E->gx_d, E->gx_s, E->gx_r, E->gx_w64, E->gx_nrm, E->prox_keys, E->gx_nnls_work,
                     E->gxb_v[0], E->gxb_v[1], E->gxb_v[2], E->gxb_v[3], E->gxb_vt, E->gxb_q[0], E->gxb_q[1],
-                    E->kl_S[0], E->kl_S[1], E->kl_DV[0], E->kl_DV[1], E->sk[0].seg, E->sk[0].first, E->sk[0].cnt, E->sk[0].slabs, E->sk[1].seg, E->sk[1].first, E->sk[1].cnt, E->sk[1].slabs, E->minv_img};
+                    E->kl_S[0], E->kl_S[1], E->kl_DV[0], E->kl_DV[1], E->sk[0].seg, E->sk[0].first, E->sk[0].cnt, E->sk[0].slabs, E->sk[1].seg, E->sk[1].first, E->sk[1].cnt, E->sk[1].slabs, E->minv_img, E->gx_gimg};
     for (void* b : bufs) if (b) hipFree(b);
     if (E->own_stream) hipStreamDestroy(E->own_stream);
     delete E;

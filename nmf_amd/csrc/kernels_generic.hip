@@ -1268,7 +1268,8 @@ int gxb_images_h(nmfx_engine* E, const float* H, const GxUpd& up = GxUpd()) {
 
 // split-K product on the tiled planes into the slab buffer gx_s, summed into `out` (M: rows of A, N: rows of B, K: contraction)
 int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi, const unsigned short* Blo,
-                      float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3, const float** slabs = nullptr, int* nslab = nullptr) {
+                      float* out, int64_t M, int64_t N, int64_t K, int cap, int terms = 3, const float** slabs = nullptr, int* nslab = nullptr,
+                      bool stream_hint = true) {
     // (slabs != nullptr: the caller sums the slabs itself -- *slabs / *nslab say where they are -- and `out` is only written when there is one)
     int rc;
     static const int big = getenv("NMFX_GXT2") ? atoi(getenv("NMFX_GXT2")) : 1;
@@ -1281,7 +1282,7 @@ int gxt_split_product(nmfx_engine* E, const unsigned short* Ahi, const unsigned 
         static const int nt_on = getenv("NMFX_GXT_NT") ? atoi(getenv("NMFX_GXT_NT")) : 1;
         // (an operand is read once where the other dimension is a single tile: with two column tiles -- k = 512 -- the second one finds
         //  the V planes in L2 and non-temporal requests cost 4 %; k = 256: V H^T 174.6 -> 169.4 us, W^T V 180.3 -> 176.5)
-        const int nt = !nt_on ? 0 : ((N == 256 && M > 256 ? 1 : 0) | (M == 256 && N > 256 ? 2 : 0));
+        const int nt = (!nt_on || !stream_hint) ? 0 : ((N == 256 && M > 256 ? 1 : 0) | (M == 256 && N > 256 ? 2 : 0));
         float* C = S == 1 ? out : E->gx_s;
         const int* flag = &E->state->flag;
         if (terms == 4) {
@@ -1384,6 +1385,21 @@ int gxb_prepare(nmfx_engine* E, const float* W, bool kl = false) {
 
 static bool gx_anls_bf16() { static const bool on = !(getenv("NMFX_GX_ANLS_BF16") && atoi(getenv("NMFX_GX_ANLS_BF16")) == 0); return on; }
 
+// r4: the denominator products of the Euclidean updates, D = W (H H^T) and E = (W^T W) H, from the factor images and the images of the
+// k x k Gram matrix (three terms, like the numerators they are divided into) instead of an exact-f32 product: 2 m k^2 flop that took
+// 28 us at k = 256 and 110 us at k = 512 on the f32 matrix cores.  Measured (16384 x 8192): W side k = 512 130 -> 102 us per update,
+// k = 256 no gain (the image launch and a 64-block grid eat it): used for the W side from kp = 384 on; H side never (see phase B).  left = true: out [rows][kp] = F G (F images: rows x kp);
+// false: out [kp][cols] = G F^T^T, i.e. G times the factor whose TRANSPOSED images are given (cols x kp)
+static bool gx_bf16_den() { static const bool on = !(getenv("NMFX_GX_DEN_BF16") && atoi(getenv("NMFX_GX_DEN_BF16")) == 0); return on; }
+static int gx_den_product(nmfx_engine* E, bool left, const float* G, const unsigned short* Fhi, const unsigned short* Flo, int64_t ents, float* out) {
+    int rc;
+    const int64_t kp = E->kp;
+    if ((rc = gx_alloc(E, &E->gx_gimg, 2 * kp * kp))) return rc;
+    if ((rc = gxt_split(E, G, kp, kp, 2, E->gx_gimg, E->gx_gimg + kp * kp, 0, nullptr, nullptr, true))) return rc;      // (G symmetric: rows = either index)
+    if (left) return gxt_split_product(E, Fhi, Flo, E->gx_gimg, E->gx_gimg + kp * kp, out, ents, kp, kp, 0, 3, nullptr, nullptr, false);
+    return gxt_split_product(E, E->gx_gimg, E->gx_gimg + kp * kp, Fhi, Flo, out, kp, ents, kp, 0, 3, nullptr, nullptr, false);
+}
+
 // ---- MUR, Euclidean ----------------------------------------------------------------------------------------------------------
 int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_t j) {
     int rc;
@@ -1413,7 +1429,9 @@ int nmfx_generic_mur_phase_a(nmfx_engine* E, int distance, double lambda, int64_
             { ProfScope ps(E, "wphase");               // A = V H^T
               if ((rc = gxt_split_product(E, E->gxb_v[0], E->gxb_v[1], E->Hhi, E->Hlo, E->A_part, mp, kp, np, 4, 3, &slabs, &nslab))) return rc; }
             ProfScope ps(E, "w_update");
-            if ((rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr))) return rc;
+            if (gxr_on() && gx_bf16_den() && kp >= 384) rc = gx_den_product(E, true, E->HHt, E->Whi[0], E->Wlo[0], mp, E->gx_d);      // (tiled images of W: the persistent kernels' format)
+            else rc = gx_launch<true, false>(E, GX_STORE, W, kp, E->HHt, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr);
+            if (rc) return rc;
             GxUpd up;
             up.xold = W; up.num = slabs; up.nslab = nslab; up.nstride = mp * kp; up.den = E->gx_d; up.lam = (float)lambda; up.xnew = Wn;
             if ((rc = gxb_images_w(E, Wn, up))) return rc;
@@ -1520,7 +1538,9 @@ int nmfx_generic_mur_phase_b(nmfx_engine* E, int distance, double lambda, int64_
     NMFX_HIP(hipGetLastError());
     if (!kl && gxb_on(E) && E->gxb_img_ready && gx_fuse_update()) {
         // r4: the update and the images of the new H in one launch behind E = G H (element-wise, so H is updated in place)
-        if ((rc = gx_launch<true, false>(E, GX_STORE, xG, kp, E->H, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr))) return rc;
+        if (gxr_on() && gx_bf16_den() && false) rc = gx_den_product(E, false, xG, E->HThi, E->HTlo, np, E->gx_d);      // (measured: 80 against 77 us at k = 512, 51 against 47 at k = 256 -- 32 blocks of 256 x 256 for a kp x np output)
+        else rc = gx_launch<true, false>(E, GX_STORE, xG, kp, E->H, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr);
+        if (rc) return rc;
         GxUpd up;
         up.xold = E->H; up.num = xB; up.nslab = 1; up.den = E->gx_d; up.lam = (float)lambda; up.xnew = E->H;
         if ((rc = gxb_images_h(E, E->H, up))) return rc;

@@ -93,6 +93,7 @@ struct nmfx_engine {
     double* gx_part = nullptr;
     float* gx_d = nullptr;
     float* gx_s = nullptr;
+    unsigned short* gx_gimg = nullptr;   // MUR-eu for k > 128 (r4): bf16 hi / lo images of the Gram matrix of a denominator product ([2][kp][kp], tiled)
     float* gx_r = nullptr;         // AO-ADMM for k > 128: right-hand side of a round
     double* gx_w64 = nullptr;      // ... the f64 work matrix of the Gauss-Jordan inversion
     double* gx_nrm = nullptr;      // ... norm partials of a round

@@ -10,7 +10,7 @@ from oracle import nmf_ref as R
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape,k", [((520, 700), 160), ((640, 520), 256), ((400, 900), 300)])
+@pytest.mark.parametrize("shape,k", [((520, 700), 160), ((640, 520), 256), ((400, 900), 300), ((768, 512), 400)])
 @pytest.mark.parametrize("distance", ["eu", "kl"])
 def test_mur_beyond_128_components_vs_oracle(shape, k, distance):
     from nmf_amd.mur import mur

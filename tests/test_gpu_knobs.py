@@ -73,6 +73,7 @@ CASES = [
     ({"NMFX_GXT2": "0"}, "mur", (512, 512, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
     ({"NMFX_GXT_NT": "0"}, "mur", (1024, 768, 160), dict(distance_type="eu", lambda_w=0.1, lambda_h=0.05, min_iter=8, max_iter=8)),
     ({"NMFX_GX_FUSE_UPDATE": "0"}, "mur", (512, 512, 160), dict(distance_type="eu", lambda_w=0.1, lambda_h=0.05, min_iter=10, max_iter=10)),
+    ({"NMFX_GX_DEN_BF16": "0"}, "mur", (512, 256, 400), dict(distance_type="eu", lambda_w=0.05, lambda_h=0.02, min_iter=8, max_iter=8)),   # k pads to 512: exact-f32 denominator W (H H^T)
     ({"NMFX_GX_STAGGER": "0"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
     ({"NMFX_GX_STAGGER": "16"}, "mur", (384, 256, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
     ({"NMFX_GXR": "0"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
