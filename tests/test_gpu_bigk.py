@@ -132,7 +132,8 @@ def test_mur_eu_k160_stop_rule_and_negative_data():
     np.testing.assert_allclose(res.obj_history, obj_o, rtol=4e-5)
 
 
-@pytest.mark.parametrize("shape,k,regs", [((520, 700), 160, ((0.1, "l1n"), (0.05, "l1n"))), ((640, 520), 256, ((0.02, "l1n"), (0, "nn")))])
+@pytest.mark.parametrize("shape,k,regs", [((520, 700), 160, ((0.1, "l1n"), (0.05, "l1n"))), ((640, 520), 256, ((0.02, "l1n"), (0, "nn"))),
+                                           ((400, 520), 300, ((0.05, "l1n"), (0.02, "l1n")))])      # k pads to 384: three factor tiles per wave of the bf16 rounds
 def test_aoadmm_beyond_128_components_vs_oracle(shape, k, regs):
     """AO-ADMM (least-squares loss, nn / l1n) for k > 128: Gram systems by an f64 Gauss-Jordan inversion, the rounds of
     nmf/ao_admm.py:59-64 one by one with the stop test on the device; inner round counts equal to the oracle's."""
