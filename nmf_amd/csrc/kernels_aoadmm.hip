@@ -786,12 +786,11 @@ __global__ __launch_bounds__(64 * NWV) void ao_round_any_bf16_kernel(
                 const float4 h4 = *reinterpret_cast<const float4*>(X + idx), u4 = *reinterpret_cast<const float4*>(U + idx);
                 xo[rt][0] = h4.x; xo[rt][1] = h4.y; xo[rt][2] = h4.z; xo[rt][3] = h4.w;
                 uo[rt][0] = u4.x; uo[rt][1] = u4.y; uo[rt][2] = u4.z; uo[rt][3] = u4.w;
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t idx = (e0 + 16 * rt + 4 * q + g) * kp + 16 * it + x;
-                    xo[rt][g] = X[idx]; uo[rt][g] = U[idx];
-                }
+            } else {                                   // four consecutive factors of entity row 16 rt + x (the product is formed transposed, below)
+                const int64_t idx = (e0 + 16 * rt + x) * kp + 16 * it + 4 * q;
+                const float4 h4 = *reinterpret_cast<const float4*>(X + idx), u4 = *reinterpret_cast<const float4*>(U + idx);
+                xo[rt][0] = h4.x; xo[rt][1] = h4.y; xo[rt][2] = h4.z; xo[rt][3] = h4.w;
+                uo[rt][0] = u4.x; uo[rt][1] = u4.y; uo[rt][2] = u4.z; uo[rt][3] = u4.w;
             }
         }
         f32x4 acc[4];
@@ -806,18 +805,29 @@ __global__ __launch_bounds__(64 * NWV) void ao_round_any_bf16_kernel(
             nh.u = *reinterpret_cast<const uint4*>(mrow + 32 * un); nm.u = *reinterpret_cast<const uint4*>(mrow + kk + 32 * un);
             nl.u = *reinterpret_cast<const uint4*>(mrow + 2 * kk + 32 * un);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {           // acc[rt][g]: entity 16 rt + 4 q + g, factor 16 it + x
+            for (int rt = 0; rt < 4; ++rt) {
+                // COLS: acc[rt][g] = entity (column) 16 rt + 4 q + g, factor 16 it + x; rows (W): the operands change places, so that
+                // acc[rt][g] = factor 16 it + 4 q + g of entity (row) 16 rt + x -- four consecutive floats of X / U per lane either way
                 const int off = (16 * rt + x) * LDR + 32 * u + 8 * q;
                 AoFrag8 rh, rm, rl;
                 rh.u = *reinterpret_cast<const uint4*>(rimg + off);
                 rm.u = *reinterpret_cast<const uint4*>(rimg + 64 * LDR + off);
                 rl.u = *reinterpret_cast<const uint4*>(rimg + 128 * LDR + off);
-                acc[rt] = AO_MFMA_BF16(rh, mh, acc[rt]);
-                acc[rt] = AO_MFMA_BF16(rm, mh, acc[rt]);
-                acc[rt] = AO_MFMA_BF16(rh, mm, acc[rt]);
-                acc[rt] = AO_MFMA_BF16(rl, mh, acc[rt]);
-                acc[rt] = AO_MFMA_BF16(rh, ml, acc[rt]);
-                acc[rt] = AO_MFMA_BF16(rm, mm, acc[rt]);
+                if (COLS) {
+                    acc[rt] = AO_MFMA_BF16(rh, mh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(rm, mh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(rh, mm, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(rl, mh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(rh, ml, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(rm, mm, acc[rt]);
+                } else {
+                    acc[rt] = AO_MFMA_BF16(mh, rh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(mh, rm, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(mm, rh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(mh, rl, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(ml, rh, acc[rt]);
+                    acc[rt] = AO_MFMA_BF16(mm, rm, acc[rt]);
+                }
             }
             mh = nh; mm = nm; ml = nl;
         }
@@ -837,11 +847,9 @@ __global__ __launch_bounds__(64 * NWV) void ao_round_any_bf16_kernel(
                 *reinterpret_cast<float4*>(X + idx) = make_float4(hn[0], hn[1], hn[2], hn[3]);
                 *reinterpret_cast<float4*>(U + idx) = make_float4(un2[0], un2[1], un2[2], un2[3]);
             } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t idx = (e0 + 16 * rt + 4 * q + g) * kp + 16 * it + x;
-                    X[idx] = hn[g]; U[idx] = un2[g];
-                }
+                const int64_t idx = (e0 + 16 * rt + x) * kp + 16 * it + 4 * q;
+                *reinterpret_cast<float4*>(X + idx) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                *reinterpret_cast<float4*>(U + idx) = make_float4(un2[0], un2[1], un2[2], un2[3]);
             }
         }
     }
