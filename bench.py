@@ -676,6 +676,91 @@ def pair_config(torch, dev, steps=40, warmup=5):
             "data": "synthetic, drawn on the device (torch generator, seed 0)"}
 
 
+HEADLINE_LIMIT = 4096             # bytes: the ONE stdout line must fit, whole, in the driver's stdout tail
+
+
+def _r(x, sig=5):
+    """A float rounded to `sig` significant digits (None and non-floats pass through)."""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")) and x != 0.0:
+        from math import floor, log10
+        return round(x, sig - 1 - int(floor(log10(abs(x)))))
+    return x
+
+
+def headline(detail):
+    """The compact stdout line made from the full record `detail` (which goes to bench_detail.json and stderr): the contract's keys,
+    `roofline`, `cpu_baseline`, the full-size parity figures, the exact-f32 leg, ONE pair of numbers per other BASELINE config and the
+    scaling model's N = 8 predictions as bare numbers.  No prose beyond the workload names."""
+    line = {k_: detail.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                         "scaling", "vs_baseline", "dtype", "data", "config")}
+    roof = detail.get("roofline")
+    if roof:
+        line["roofline"] = {k_: _r(roof.get(k_)) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                           "algorithmic_bytes_per_launch", "us_per_launch") if k_ in roof}
+    else:
+        line["roofline"] = None
+    cpu = detail.get("cpu_baseline")
+    line["cpu_baseline"] = ({k_: _r(cpu.get(k_)) for k_ in ("value", "unit", "cores", "kind", "sample")} if cpu else None)
+    par = detail.get("parity")
+    line["parity"] = ({k_: _r(par.get(k_), 3) for k_ in ("wh_rel_err", "obj_max_rel_diff", "iterations")} if par else None)
+    it = detail.get("iteration")
+    if it:
+        line["iteration_frac_of_hbm_peak"] = _r(it.get("frac_of_hbm_peak"), 3)
+    ttt = detail.get("time_to_tol")
+    if ttt:
+        line["time_to_tol"] = [{"tol": t["tol1"], "converged": t["converged"], "iterations": t["iterations"], "seconds": _r(t["seconds"], 4),
+                                "oracle_agrees": (t.get("oracle_stop_check") or {}).get("agree")} for t in ttt]
+    for o in detail.get("other_configs") or []:
+        name = o.get("config")
+        if name in ("cfg3", "cfg4", "cfg5_on_1_gpu", "cfg5"):
+            if "error" in o:
+                line[name] = {"error": str(o["error"])[:120]}
+                continue
+            slot = {"iter_per_s": _r(o.get("iter_per_s")), "frac_of_hbm_peak": _r(o.get("frac_of_hbm_peak"), 3)}
+            dom = o.get("dominant_kernel")
+            if dom:
+                slot["dominant_kernel"] = dom.get("name")
+                slot["dominant_frac"] = _r(dom.get("frac"), 3)
+            for k_ in ("n_gpus", "loop", "objective_f64_rel_diff", "exchange"):
+                if k_ in o:
+                    slot[k_] = _r(o[k_], 3)
+            line[name] = slot
+        elif name == "cfg2_exact_f32" and "iter_per_s" in o:
+            line["exact_f32_iter_per_s"] = _r(o["iter_per_s"])
+            line["exact_f32_frac_of_f32_mfma_peak"] = _r((o.get("dominant_kernel") or {}).get("frac"), 3)
+    sm = detail.get("scaling_model")
+    if sm and "configs" in sm:
+        pred = {}
+        for cfg, body in sm["configs"].items():
+            for row in body.get("ranks", []):
+                if "predicted_speedup_vs_1_gpu" in row and row["predicted_speedup_vs_1_gpu"] is not None:
+                    pred[f"{cfg}_n{row['n_gpus']}"] = _r(row["predicted_speedup_vs_1_gpu"], 3)
+        line["scaling_model_predicted_speedup"] = pred or None
+    line["detail"] = "bench_detail.json (cwd; also on stderr)"
+    # the limit is a promise: shed the optional slots, last first, rather than break it
+    for drop in ("time_to_tol", "scaling_model_predicted_speedup", "iteration_frac_of_hbm_peak", "cfg5", "cfg3", "cfg4", "cfg5_on_1_gpu"):
+        if len(json.dumps(line)) < HEADLINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def emit(detail, json_fd):
+    """Full record -> bench_detail.json (cwd, and gpurun_out/ when that exists, so that it is pulled back) and stderr; compact line -> stdout."""
+    text = json.dumps(detail)
+    for d in (os.getcwd(), os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text + "\n")
+            except OSError as e:
+                sys.stderr.write(f"bench.py: could not write bench_detail.json in {d}: {e}\n")
+    sys.stderr.write("bench_detail: " + text + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(headline(detail)) + "\n").encode())
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torchrun: become the launcher.  Nothing has touched the GPU yet (torch is
     not even imported), so starting `python -m torch.distributed.run ... bench.py <same arguments>` as a child process is safe; its
@@ -987,8 +1072,7 @@ def main():
             "other_configs": others,
             "scaling_model": smodel,
         }
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(line, json_fd)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
