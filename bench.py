@@ -748,13 +748,15 @@ def headline(detail):
 def emit(detail, json_fd):
     """Full record -> bench_detail.json (cwd, and gpurun_out/ when that exists, so that it is pulled back) and stderr; compact line -> stdout."""
     text = json.dumps(detail)
-    for d in (os.getcwd(), os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_detail.json"), "w") as f:
-                    f.write(text + "\n")
-            except OSError as e:
-                sys.stderr.write(f"bench.py: could not write bench_detail.json in {d}: {e}\n")
+    # (NMFX_BENCH_DETAIL=<path>: that file only -- tests)
+    targets = [os.environ["NMFX_BENCH_DETAIL"]] if os.environ.get("NMFX_BENCH_DETAIL") else \
+        [os.path.join(d, "bench_detail.json") for d in (os.getcwd(), os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    for path in targets:
+        try:
+            with open(path, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:
+            sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
     sys.stderr.write("bench_detail: " + text + "\n")
     sys.stderr.flush()
     sys.stdout.flush()

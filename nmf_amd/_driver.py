@@ -32,6 +32,7 @@ class Referee:
         self.mode = os.environ.get("NMFX_VERIFY_STOP", "auto")
         self.guard = 0.0
         self.jitter6 = 0.0                           # the 6 sigma part of the guard (without the head start for the curvature)
+        self.guard_since = 0                         # loop index from which the guard now in force has been tested with (see confirms)
         self.walked = 0
         self.confirmed = 0                           # candidates accepted from the recorded history alone (see confirms)
         self.final_rule = 0
@@ -75,6 +76,7 @@ class Referee:
             g = 0.0
         if g != self.guard:
             self.guard = g
+            self.guard_since = len(history) - 1      # (history holds obj[0 .. done]: the next iteration queued is index `done`)
             self.eng.set_stop_guard(g)
 
     def confirms(self, history, candidate_i):
@@ -83,8 +85,12 @@ class Referee:
         before min_iter, or a decrease that falls faster than the head start assumed -- would come back one iteration late
         (ADVICE r3).  If the RECORDED pair of objectives satisfies the plain rule with the whole jitter estimate to spare,
         `new >= old - tol2 + 6 sigma`, the float64 values satisfy it too: the candidate is the stop.  (The index before it did
-        not fire with the guard, i.e. its recorded decrease exceeded tol2 by more than the jitter, so the rule did not hold there.)"""
+        not fire with the guard, i.e. its recorded decrease exceeded tol2 by more than the jitter, so the rule did not hold there --
+        which is only known if that index WAS tested with the guard now in force: the guard is armed or raised between batches, so a
+        candidate at the first index of the batch behind that change is left to the walk)"""
         if candidate_i + 1 >= len(history) or candidate_i <= self.min_iter:
+            return False
+        if candidate_i - 1 > self.min_iter and candidate_i - 1 < self.guard_since:
             return False
         new, old = history[candidate_i + 1], history[candidate_i]
         if new >= old - self.tol2 + self.jitter6:

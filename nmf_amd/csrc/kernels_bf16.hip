@@ -626,7 +626,8 @@ extern "C" int nmfx_debug_set_reverse(void* stream, int v) {
 // so a second dispatch's single workgroup waits for ITS slot even with other CUs idle, and the fork / join events cost 15 us.)
 struct XytSide {                 // the side job: Minv = (sum of gslabs slabs of gsrc + rho I)^-1, rho = trace / k (fixed_rho < 0) -- nmf/ao_admm.py:53-55
     const float* gsrc; int gslabs; int k; float* Minv; DevState* st; double fixed_rho;
-};
+    int defer;                   // 1: a non-positive pivot is noted in st->notpd_pending and the launch that records obj[j] decides (the H side, whose
+};                               // objective may stop the run first); 0: it ends the run here, as nmf/ao_admm.py:55 does (the W side: no stop rule follows it)
 // VAUX = true (r4; with WITH_OBJ, without the A-product): the m x n auxiliaries of the KL-loss ADMM variants instead of the residual --
 // nmf/ao_admm.py:87-93, nmf/admm.py:306-314: with P = Z Y (= w h_aux, or its transpose) where the accumulator stands,
 //   v_bar = P - dual_v;  v_aux = ((v_bar - 1) + sqrt((v_bar - 1)^2 + 4 v)) / 2;  dual_v += v_aux - P;  S = v_aux + dual_v
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     if constexpr (SK) {
         if ((int)blockIdx.x == sk_workers) {           // the side job (see above); its LDS use (72 KiB at KP = 128) is inside this kernel's
             ao_prepare_body<KP, false>(reinterpret_cast<double*>(smem), side.gsrc, side.gslabs, side.k, side.Minv, side.st,
-                                       side.fixed_rho, true);
+                                       side.fixed_rho, side.defer != 0);
 #ifdef NMFX_EXP_BLOCKTIME
             if (threadIdx.x == 0 && blockIdx.x < 1024) nmfx_dbg_times[WITH_OBJ][1][blockIdx.x] = wall_clock64();
 #endif
@@ -2596,6 +2597,7 @@ int nmfx_bf16_sk_product(nmfx_engine* E, int side, bool obj, const float* gsrc, 
     const unsigned short* Zhi = !obj ? nullptr : side == 0 ? E->HThi : E->Whi[0];
     const unsigned short* Zlo = !obj ? nullptr : side == 0 ? E->HTlo : E->Wlo[0];
     XytSide job; job.gsrc = gsrc; job.gslabs = gslabs; job.k = E->k; job.Minv = E->Minv; job.st = E->state; job.fixed_rho = fixed_rho;
+    job.defer = side == 0 ? 1 : 0;
     const dim3 grid((unsigned)(P.workers + (gsrc ? 1 : 0))), block(512);
     const size_t shm = 160 * 1024;
     auto kern = obj ? xyt32_bf16_kernel<true, 3, 0, false, 128, 1, false, true, 8, true>

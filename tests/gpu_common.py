@@ -79,3 +79,42 @@ def oracle_after(ref_fn, v, k, seed, iterations, **kw):
     with np.errstate(all="ignore"):
         out = ref_fn(np.asarray(v, dtype=np.float64), k, **kw)
     return out.w, out.h, np.asarray(out.obj_history)
+
+
+# ---- oracle results that take tens of seconds (scipy's per-column NNLS beyond 100 components) --------------------------------
+# The oracle run of such a case is committed as data under tests/golden/slow/ (made by oracle/make_slow_cases.py from the very
+# functions the tests call: same seeded input, same keywords) and only re-computed when the file is missing or was made for other
+# inputs -- the GPU suite has a 900 s limit and spent 170 s of it in these.
+SLOW_DIR = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "slow")
+
+
+class SlowOutcome:
+    def __init__(self, w, h, i, obj_history):
+        self.w, self.h, self.i, self.obj_history = w, h, int(i), list(np.asarray(obj_history, dtype=np.float64))
+
+
+def slow_signature(v, k, kw, w0=None, h0=None):
+    """What pins a case: shape, rank, keywords and checksums of the inputs (JSON text)."""
+    import json
+    sig = {"shape": list(v.shape), "k": int(k), "kw": {key: (list(val) if isinstance(val, tuple) else val) for key, val in sorted(kw.items())},
+           "vsum": repr(float(np.sum(np.asarray(v, dtype=np.float64))))}
+    if w0 is not None:
+        sig["w0sum"], sig["h0sum"] = repr(float(np.sum(w0))), repr(float(np.sum(h0)))
+    return json.dumps(sig, sort_keys=True)
+
+
+def slow_oracle(name, signature, compute):
+    """The oracle's outcome for the case `name`: from tests/golden/slow/<name>.npz when that was made for `signature`, else
+    compute() (and, with NMFX_WRITE_SLOW_ORACLE=1 -- oracle/make_slow_cases.py --, written there)."""
+    import os
+    path = os.path.join(SLOW_DIR, name + ".npz")
+    if os.path.exists(path) and os.environ.get("NMFX_WRITE_SLOW_ORACLE") != "1":
+        z = np.load(path, allow_pickle=False)
+        if str(z["signature"]) == signature:
+            return SlowOutcome(z["w"], z["h"], z["i"], z["obj_history"])
+    with np.errstate(all="ignore"):
+        out = compute()
+    if os.environ.get("NMFX_WRITE_SLOW_ORACLE") == "1":
+        os.makedirs(SLOW_DIR, exist_ok=True)
+        np.savez_compressed(path, w=out.w, h=out.h, i=out.i, obj_history=np.asarray(out.obj_history, dtype=np.float64), signature=signature)
+    return SlowOutcome(out.w, out.h, out.i, out.obj_history)

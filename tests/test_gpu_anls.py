@@ -3,7 +3,7 @@ FCNNLS paths: same minimisers)."""
 import numpy as np
 import pytest
 
-from gpu_common import WH_TOL, run_fixture, snapshot_errors, wh_error
+from gpu_common import WH_TOL, run_fixture, slow_oracle, slow_signature, snapshot_errors, wh_error
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,8 @@ def test_anls_k64_k128_both_precisions_vs_oracle(precision, shape, monkeypatch):
     m, n, k = shape
     v = R.planted_matrix(m, n, k, seed=m + k, dtype=np.float32)
     kw = dict(lambda_w=0.05, lambda_h=0.02, min_iter=4, max_iter=4, nndsvd_init=(True, "zero"))
-    ref = R.anls(v.astype(np.float64), k, **kw)
+    # (k = 100: 12 s of scipy NNLS per run -- committed under tests/golden/slow/, see gpu_common.slow_oracle)
+    ref = slow_oracle(f"anls_{m}x{n}_k{k}", slow_signature(v, k, kw), lambda: R.anls(v.astype(np.float64), k, **kw))
     res = anls(v.copy(), k, **kw)
     err = np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
     assert err < 1e-4, err
@@ -95,7 +96,8 @@ def test_anls_rank_deficient_passive_set_at_lambda_zero(k, case):
     assert np.isfinite(obj).all() and obj[-1] < obj[0]
     vd = v.astype(np.float64)
     if case == "dead":
-        ref = R.anls(vd, k, lambda_w=0, lambda_h=0, min_iter=iters, max_iter=iters, w0=w0, h0=h0)
+        kw = dict(lambda_w=0, lambda_h=0, min_iter=iters, max_iter=iters)
+        ref = slow_oracle(f"anls_dead_{m}x{n}_k{k}", slow_signature(v, k, kw, w0, h0), lambda: R.anls(vd, k, w0=w0, h0=h0, **kw))
         assert wh_error(w, h, ref.w, ref.h, v) < WH_TOL
         np.testing.assert_allclose(obj, ref.obj_history, rtol=1e-5)      # (measured: 5e-7)
         assert not w[:, 2].any() and not h[2].any()          # the component stays dead, as in the reference

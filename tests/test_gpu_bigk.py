@@ -4,7 +4,7 @@ planes for MUR, AO-ADMM-LS and ADMM-LS (the default), exact f32 for the rest (te
 import numpy as np
 import pytest
 
-from gpu_common import WH_TOL, direct_objective, oracle_after, wh_error, wh_error_blocked
+from gpu_common import WH_TOL, direct_objective, oracle_after, slow_oracle, slow_signature, wh_error, wh_error_blocked
 from oracle import nmf_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -222,7 +222,7 @@ def test_anls_beyond_128_components_vs_oracle(shape, k, distance):
     v = R.planted_matrix(m, n, 24, seed=m + k, dtype=np.float32)
     kw = dict(distance_type=distance, lambda_w=0.05, lambda_h=0.02, min_iter=3, max_iter=3, nndsvd_init=(True, "zero"))     # (the oracle's scipy NNLS sets the run time)
     res = anls(v.copy(), k, **kw)
-    ref = R.anls(v.astype(np.float64), k, **kw)
+    ref = slow_oracle(f"anls_{distance}_{m}x{n}_k{k}", slow_signature(v, k, kw), lambda: R.anls(v.astype(np.float64), k, **kw))
     assert res.w.shape == (m, k) and res.h.shape == (k, n)
     assert res.i == ref.i and len(res.obj_history) == res.i + 2
     err = wh_error(res.w, res.h, ref.w, ref.h, v)

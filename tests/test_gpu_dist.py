@@ -55,6 +55,26 @@ def _case_wide(k):
 KW = dict(distance_type="eu", min_iter=14, max_iter=14, lambda_w=0.01, lambda_h=0.02)
 
 
+def _run_mur_case(nd, Shard, make_comm, rank, world, outdir, tag, k=12, wide=False):
+    """One MUR case over this process group; returns False when negotiate() refused (recorded)."""
+    m, n, k, v, w0, h0 = (_case_wide if wide else _case)(k)
+    r0, r1 = nd.row_range(m, rank, world)
+    shard = Shard(v[r0:r1], k, w0[r0:r1], h0, 0)
+    comm = make_comm(shard)
+    try:
+        shard.negotiate(comm)
+    except RuntimeError as e:
+        np.savez(os.path.join(outdir, f"{tag}rank{rank}.npz"), refused=str(e))
+        shard.close()
+        return False
+    pieces = shard.chunk_ranges(0, nd._exchange_chunks())
+    res = nd.mur_sharded(shard, comm, batch=5, **KW)
+    np.savez(os.path.join(outdir, f"{tag}rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
+             pieces=len(pieces) if pieces else 1, merged=int(shard.merge_objective()))
+    shard.close()
+    return True
+
+
 def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -69,36 +89,100 @@ def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
     if rank == 1 and os.environ.get("NMFX_TEST_RANK1_ENV"):          # one rank in another mode (negotiate() must settle it)
         key, val = os.environ["NMFX_TEST_RANK1_ENV"].split("=")
         os.environ[key] = val
-    m, n, k, v, w0, h0 = (_case_wide if wide else _case)(k)
-    r0, r1 = nd.row_range(m, rank, world)
-    shard = Shard(v[r0:r1], k, w0[r0:r1], h0, 0)
-    comm = make_comm(shard)
-    try:
-        shard.negotiate(comm)
-    except RuntimeError as e:
-        np.savez(os.path.join(outdir, f"rank{rank}.npz"), refused=str(e))
-        shard.close()
-        dist.barrier()
-        dist.destroy_process_group()
-        return
-    pieces = shard.chunk_ranges(0, nd._exchange_chunks())
-    res = nd.mur_sharded(shard, comm, batch=5, **KW)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
-             pieces=len(pieces) if pieces else 1, merged=int(shard.merge_objective()))
-    shard.close()
+    _run_mur_case(nd, Shard, make_comm, rank, world, outdir, "", k, wide)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [12, 40, 100, 160])     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128; generic path (k > 128)
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
-def test_sharded_device_path(world, backend, k, tmp_path):
-    import torch.multiprocessing as mp
+MUR_KS = [12, 40, 100, 160]     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128; generic path (k > 128)
+WIDE_KS = [40, 100]
+SOLVERS = ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "admm",
+           "admm_bf16", "admm_kl", "admm_k160", "anls", "anls_k160"]
+BACKENDS = [(1, "nccl"), (2, "gloo"), (1, "native")]
+
+
+def _batch_worker(rank, world, rdzv, backend, outdir):
+    """Every (world, backend) case of this file in ONE set of rank processes (r5: the suite spawned 54 process groups for them, 3 s of
+    interpreter + torch start-up each): the MUR cases, the chunked-exchange cases and the twelve solver cases, one after the other
+    over the same process group, each with its own shard, communicator and output files `<job>.rank<r>.npz`.  A job that raises
+    leaves `<job>.rank<r>.err` and ends this rank's batch (its peers' collectives fail with it)."""
+    import traceback
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["NMF_AMD_QUIET"] = "1"
+    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    Shard, make_comm = _join(backend, rdzv, rank, world)
+    from nmf_amd import dist as nd
+    jobs = [(f"mur{k}", "mur", k) for k in MUR_KS] + [(f"wide{k}", "wide", k) for k in WIDE_KS] + [(f"solver_{s}", "solver", s) for s in SOLVERS]
+    for tag, kind, arg in jobs:
+        try:
+            os.environ.pop("NMFX_DIST_CHUNKS", None)
+            if kind == "wide":
+                os.environ["NMFX_DIST_CHUNKS"] = "2"
+            if kind in ("mur", "wide"):
+                _run_mur_case(nd, Shard, make_comm, rank, world, outdir, tag + ".", arg, kind == "wide")
+            else:
+                _run_solver_case(nd, Shard, make_comm, rank, world, outdir, tag + ".", arg)
+        except BaseException:  # noqa: BLE001
+            with open(os.path.join(outdir, f"{tag}.rank{rank}.err"), "w") as fh:
+                fh.write(traceback.format_exc())
+            break
+    os.environ.pop("NMFX_DIST_CHUNKS", None)
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001  (a peer that left early: the error file says why)
+        pass
+
+
+@pytest.fixture(scope="module")
+def batch(tmp_path_factory):
+    """batch(world, backend) -> directory with the outputs of _batch_worker, run once per (world, backend)."""
+    done = {}
+
+    def get(world, backend):
+        key = (world, backend)
+        if key not in done:
+            d = tmp_path_factory.mktemp(f"batch_{world}_{backend}")
+            try:
+                spawn_ranks(_batch_worker, (world, None, backend, str(d)), world)
+            except Exception as e:  # noqa: BLE001  (the jobs that finished are still checked; the others report the failure)
+                (d / "spawn.err").write_text(repr(e))
+            done[key] = d
+        return done[key]
+    return get
+
+
+def _parts(d, tag, world):
+    import glob
+    errs = sorted(glob.glob(str(d / "*.err")))
+    missing = [r for r in range(world) if not (d / f"{tag}.rank{r}.npz").exists()]
+    if missing:
+        pytest.fail(f"job {tag}: no output of rank(s) {missing}; " + " | ".join(f"{os.path.basename(e)}: {open(e).read()[-1500:]}" for e in errs))
+    return [np.load(d / f"{tag}.rank{r}.npz") for r in range(world)]
+
+
+_ORACLE_CACHE = {}
+
+
+def _mur_oracle(k, wide):
     from oracle import nmf_ref as R
-    spawn_ranks(_worker, (world, None, backend, str(tmp_path), k), world)
-    m, n, k, v, w0, h0 = _case(k)
-    ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
-    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    key = ("mur", k, wide)
+    if key not in _ORACLE_CACHE:
+        m, n, k, v, w0, h0 = (_case_wide if wide else _case)(k)
+        _ORACLE_CACHE[key] = (v, R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW))
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("k", MUR_KS)
+@pytest.mark.parametrize("world,backend", BACKENDS)
+def test_sharded_device_path(world, backend, k, batch):
+    parts = _parts(batch(world, backend), f"mur{k}", world)
+    v, ref = _mur_oracle(k, False)
     w = np.concatenate([p["w"] for p in parts])
     h = parts[0]["h"]
     err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
@@ -109,19 +193,14 @@ def test_sharded_device_path(world, backend, k, tmp_path):
         np.testing.assert_array_equal(p["h"], h)        # replicated H is bit-identical on all ranks
 
 
-@pytest.mark.parametrize("k", [40, 100])
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
-def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, tmp_path, monkeypatch):
+@pytest.mark.parametrize("k", WIDE_KS)
+@pytest.mark.parametrize("world,backend", BACKENDS)
+def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, batch):
     """NMFX_DIST_CHUNKS=2: phase A in two column chunks (nmfx_mur_phase_a_head / _cols), each chunk's range of the exchange
     buffer reduced on its own -- over RCCL asynchronously, behind the product of the next chunk.  Same bars as the
     one-piece exchange (the chunks only change the summation order of the product's splits); H bit-identical on all ranks."""
-    import torch.multiprocessing as mp
-    from oracle import nmf_ref as R
-    monkeypatch.setenv("NMFX_DIST_CHUNKS", "2")
-    spawn_ranks(_worker, (world, None, backend, str(tmp_path), k, True), world)
-    m, n, k, v, w0, h0 = _case_wide(k)
-    ref = R.mur(v.astype(np.float64), k, w0=w0, h0=h0, **KW)
-    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    parts = _parts(batch(world, backend), f"wide{k}", world)
+    v, ref = _mur_oracle(k, True)
     assert all(int(p["pieces"]) == 2 for p in parts)
     w = np.concatenate([p["w"] for p in parts])
     h = parts[0]["h"]
@@ -290,17 +369,7 @@ def _solver_case(solver):
     return m, n, k, v, w0, h0, kw
 
 
-def _solver_gpu_worker(rank, world, rdzv, backend, solver, outdir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, HERE)
-    os.environ["NMF_AMD_QUIET"] = "1"
-    os.environ["NMFX_DIST_INIT_METHOD"] = rdzv          # (file:// rendezvous made by conftest.spawn_ranks; nmf_amd.dist reads it too)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(0)
-    Shard, make_comm = _join(backend, rdzv, rank, world)
-    from nmf_amd import dist as nd
+def _run_solver_case(nd, Shard, make_comm, rank, world, outdir, tag, solver):
     m, n, k, v, w0, h0, kw = _solver_case(solver)
     r0, r1 = nd.row_range(m, rank, world)
     shard = Shard(v[r0:r1], k, w0[r0:r1], h0, 0)
@@ -312,24 +381,30 @@ def _solver_gpu_worker(rank, world, rdzv, backend, solver, outdir):
     else:
         res = nd.anls_sharded(shard, comm, batch=3, **kw)
     inner = (shard.eng.inner_counts(0, res.i + 1) & 0xFFFF) if solver.startswith("ao_admm") else np.zeros(0)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
+    np.savez(os.path.join(outdir, f"{tag}rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
              inner=inner)
     shard.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "admm",
-                                    "admm_bf16", "admm_kl", "admm_k160", "anls", "anls_k160"])
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (1, "native")])
-def test_sharded_aoadmm_anls_device_path(world, backend, solver, tmp_path):
-    import torch.multiprocessing as mp
+def _solver_oracle(solver):
+    from gpu_common import slow_oracle, slow_signature
     from oracle import nmf_ref as R
-    spawn_ranks(_solver_gpu_worker, (world, None, backend, solver, str(tmp_path)), world)
-    m, n, k, v, w0, h0, kw = _solver_case(solver)
-    oracle = R.ao_admm if solver.startswith("ao_admm") else R.admm if solver.startswith("admm") else R.anls
-    ref = oracle(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
-    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    if solver not in _ORACLE_CACHE:
+        m, n, k, v, w0, h0, kw = _solver_case(solver)
+        oracle = R.ao_admm if solver.startswith("ao_admm") else R.admm if solver.startswith("admm") else R.anls
+        if solver == "anls_k160":      # (13 s of scipy NNLS: committed under tests/golden/slow/)
+            ref = slow_oracle("dist_anls_k160", slow_signature(v, k, kw, w0, h0), lambda: oracle(v.astype(np.float64), k, w0=w0, h0=h0, **kw))
+        else:
+            ref = oracle(v.astype(np.float64), k, w0=w0, h0=h0, **kw)
+        _ORACLE_CACHE[solver] = (v, ref)
+    return _ORACLE_CACHE[solver]
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("world,backend", BACKENDS)
+def test_sharded_aoadmm_anls_device_path(world, backend, solver, batch):
+    parts = _parts(batch(world, backend), f"solver_{solver}", world)
+    v, ref = _solver_oracle(solver)
     w = np.concatenate([p["w"] for p in parts])
     h = parts[0]["h"]
     err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
@@ -437,7 +512,7 @@ def test_factorize_takes_the_native_exchange_only_on_request_and_falls_back_toge
 
 
 @pytest.mark.parametrize("launch", ["torchrun", "self"])
-def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
+def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch, tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) and as a plain
     `python bench.py --gpus 2` (no WORLD_SIZE: bench.py starts torch.distributed.run itself, as a child, before anything touches the
     GPU), rehearsed with two ranks on ONE GPU (gloo staged through the host, shrunken shapes): the strong-scaling leg of config 2
@@ -447,7 +522,7 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NMFX_BENCH_BACKEND="gloo", NMFX_BENCH_CFG5_SHAPE="2048x1024x128", NMFX_BENCH_SHAPE="1024x512x64",
-               NMF_AMD_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               NMF_AMD_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NMFX_BENCH_DETAIL=str(tmp_path / "detail.json"))
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NMFX_DIST_INIT_METHOD"):
         env.pop(key, None)
     tail = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic",
@@ -465,8 +540,11 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["rows_per_gpu"] == 512
-    assert "strong_scaling_quoted_on" in line
-    leg = line["other_configs"][0]
+    assert len(lines[0]) < 4096                          # (the compact headline: the full record is in the detail file)
+    assert line["cfg5"]["n_gpus"] == 2 and line["cfg5"]["iter_per_s"] > 0, line
+    detail = json.loads((tmp_path / "detail.json").read_text())
+    assert "strong_scaling_quoted_on" in detail and detail["value"] == line["value"]
+    leg = detail["other_configs"][0]
     assert leg.get("config") == "cfg5" and "error" not in leg, leg
     assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 1024 and leg["objective_decreasing"] and leg["iter_per_s"] > 0
 

@@ -72,24 +72,33 @@ def test_config2_time_to_tol_stop_index_equals_the_f64_oracle():
 
 
 def test_config2_tight_tolerance_stop_is_refereed_in_float64():
-    """tol1 = tol2 = 1e-3 (1.4e-6 of the objective): the f32-evaluated objective's jitter (3e-9 relative) fired the plain rule at
-    iteration 14 748; the f64 oracle continued from the device's iterate 40 iterations earlier stops at 14 812 (tools/lab/
-    stop_check.py, 80 s of host time -- an oracle restarted closer to the stop is still in the transient of shedding the f32
-    iterate's rounding noise, which inflates its decreases by more than the 4e-8 per iteration the true decrease moves by).  The
-    loop's float64 referee (guarded candidate, then nmfx_objective_f64 deciding one iteration at a time) stops exactly there; the
-    run is bit-stable, so the index is pinned."""
-    bench, eng, v, w0, h0, rule, stop_i, secs, ref = _config2_to_tol(1e-3)
+    """tol1 = tol2 = 1e-3 (1.4e-6 of the objective): the f32-evaluated objective's jitter (3e-9 relative) fires the plain rule some
+    60 iterations early (iteration 14 748 against 14 812 on the box DESIGN 2 records, where the f64 oracle continued from the
+    device's iterate 100 iterations before the stop was shown to stop at that same index: tools/lab/stop_check.py, 80 s of host
+    time -- too long for this suite, r5).  Pinned here: the loop's float64 referee (guarded candidate, then nmfx_objective_f64
+    deciding one iteration at a time) armed, and the index it returns is the FIRST one at which the reference's rule
+    (nmf/utils.py:4-15) holds for the float64 objective of the device's own iterates, evaluated on the host by the oracle's
+    objective function -- the run is bit-stable, so the iterates around the stop are recovered by running it again."""
+    tol = 1e-3
+    bench, eng, v, w0, h0, rule, stop_i, secs, ref = _config2_to_tol(tol)
     try:
         print(f"\nSTOP tol=1e-3: iteration {stop_i} in {secs:.2f} s, guard {ref.guard:.2e}, {ref.walked} iterations refereed")
         assert rule == 2 and ref.guard > 0 and ref.walked > 0
-        # r4 (VERDICT r3, weak 1c): the index is re-derived here instead of asserting the constant a lab run once gave (14 812): the
-        # float64 oracle continued from the device's iterate 100 iterations before its stop (the lead DESIGN 2 describes: closer
-        # in, the restarted oracle is still shedding the f32 iterate's rounding noise) must stop at the same index by the same rule
-        chk = bench.oracle_stop_check(eng, v, w0, h0, 1e-3, rule, stop_i, lead=100, span=140)
+        never = 10 ** 15
+        eng.set_factors(w0, h0)
+        eng.mur_run(0, 0.0, 0.0, never, tol, tol, 0, stop_i - 1)         # iterations 0 .. stop_i - 2
+        objs = []
+        for t in range(3):                                              # iterates after stop_i - 1, stop_i, stop_i + 1 iterations
+            w, h = eng.get_factors()
+            objs.append(direct_objective(v, w, h, "eu"))
+            if t < 2:
+                eng.mur_run(0, 0.0, 0.0, never, tol, tol, stop_i - 1 + t, 1)
     finally:
         eng.close()
-    print(f"STOP CHECK tol=1e-3: {chk}")
-    assert chk["agree"], chk
+    print(f"STOP CHECK tol=1e-3: f64 objectives of the device's iterates around the stop {objs}, decreases {-np.diff(objs)}")
+    assert R.stop_rule(objs[2], objs[1], tol, tol) == rule              # fires at stop_i ...
+    assert R.stop_rule(objs[1], objs[0], tol, tol) == 0                 # ... and not one iteration earlier
+    np.testing.assert_allclose(ref.history[-1], objs[2], rtol=1e-5)     # (the recorded value of that pair: split-bf16 products, measured 1.5e-6)
 
 
 def test_config4_mur_kl_32768x16384_k64_vs_oracle():

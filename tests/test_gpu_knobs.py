@@ -87,7 +87,8 @@ CASES = [
 @pytest.mark.parametrize("env,method,shape,kwargs", CASES, ids=[f"{list(c[0].items())[0][0]}={list(c[0].items())[0][1]}-{c[1]}-{c[3].get('distance_type', '')}" for c in CASES])
 def test_alternative_paths_keep_parity(env, method, shape, kwargs):
     spec = json.dumps({"method": method, "shape": list(shape), "kwargs": kwargs})
-    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, spec], env=dict(os.environ, **env),
+    # (NMF_AMD_NO_TORCH: the child never touches torch; its import is 1.5 s of each of these fifty processes)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, spec], env=dict(os.environ, NMF_AMD_NO_TORCH="1", **env),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])
@@ -256,3 +257,40 @@ def test_refereed_stop_at_the_first_tested_index(monkeypatch):
     assert rf.guard > 0 and rf.confirmed == 1 and rf.walked == 0, (rf.guard, rf.confirmed, rf.walked)
     assert res.i == ref.i and len(res.obj_history) == ref.i + 2, (res.i, ref.i, len(res.obj_history))
     assert np.linalg.norm(res.w @ res.h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64)) < 1e-4
+
+
+CHILD_NOTPD = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+os.environ["NMF_AMD_QUIET"] = "1"
+import numpy as np
+from oracle import nmf_ref as R
+from nmf_amd.ao_admm import ao_admm
+m, n, k = 384, 320, 100
+v = R.planted_matrix(m, n, 32, seed=11, dtype=np.float32)
+kw = dict(distance_type="eu", reg_w=(0, "nn"), reg_h=(1e6, "l1n"), admm_iter=10, nndsvd_init=(True, "zero"))
+out = {}
+for who, fn, x in (("ref", R.ao_admm, v.astype(np.float64)), ("dev", ao_admm, v)):
+    raised_at = None
+    for t in (1, 2):
+        try:
+            with np.errstate(all="ignore"):
+                fn(x.copy(), k, min_iter=t, max_iter=t, **kw)
+        except np.linalg.LinAlgError:
+            raised_at = t
+            break
+    out[who] = raised_at
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_aoadmm_k128_bf16_w_side_not_positive_definite_raises_in_the_reference_iteration(overlap):
+    """ADVICE r4 (medium): a huge l1n lambda wipes H out inside the first H sub-problem, so H H^T + rho I = 0 and the W side's Cholesky
+    (nmf/ao_admm.py:55) raises in that SAME outer iteration -- also when the inversion runs as the side job of the stream-K product
+    (the default at k padded to 128, split bf16, admm_iter >= 2), where no objective or stop rule follows the W side."""
+    out = subprocess.run([sys.executable, "-c", CHILD_NOTPD % {"root": ROOT}], env=dict(os.environ, NMFX_AO_OVERLAP=overlap, NMFX_PRECISION="bf16", NMF_AMD_NO_TORCH="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["ref"] == 1 and got["dev"] == got["ref"], got
