@@ -261,7 +261,6 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
     h0 = np.abs(rs.randn(k, n))
     dev = torch.device(f"cuda:{local_rank}")
     on_gpu = dist.get_backend() == "nccl"
-    shard, err, comm, loop = None, None, None, "?"
     made = []
 
     def build(cls):
@@ -279,76 +278,119 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
                 made[-1].eng.close()
             raise RuntimeError(f"config-5 shard could not be set up on every rank (rank {rank}: {made[-1]!r})")
         return made[-1]
-    shard, comm, loop = make_sharded(torch, dist, nd, rank, world, local_rank, build)
+    # Which loop and which exchange is fastest can only be settled on a multi-GPU node, so the same run times them all (VERDICT r3
+    # item 4d, r4 item 5): {torch.distributed collectives between the phase calls, RCCL behind the C ABI} x {one all-reduce per
+    # iteration, two column chunks with the all-reduce of chunk 0 behind the product of chunk 1, reduce-scatter . sliced H update .
+    # all-gather}.  The slot's iter_per_s is the FASTEST form that ran (named in `exchange`); every form's time rides along.  With
+    # NMFX_DIST_NATIVE / NMFX_DIST_CHUNKS / NMFX_DIST_EXCHANGE set, only the form they ask for runs.
+    forms = [("allreduce", 1), ("allreduce", 2), ("rsag", 1)]
+    loops = ["torch", "native"] if on_gpu else ["torch"]
+    if os.environ.get("NMFX_DIST_NATIVE") is not None:
+        loops = ["native" if os.environ["NMFX_DIST_NATIVE"] == "1" else "torch"]
+    if os.environ.get("NMFX_DIST_CHUNKS") or os.environ.get("NMFX_DIST_EXCHANGE"):
+        forms = [(nd.exchange_mode(), max(1, int(os.environ.get("NMFX_DIST_CHUNKS", "1") or 1)))]
+    saved_env = {key: os.environ.get(key) for key in ("NMFX_DIST_CHUNKS", "NMFX_DIST_EXCHANGE", "NMFX_DIST_NATIVE")}
+    times, names, slot = {}, {}, None
     try:
-        def fence():
-            shard.eng.synchronize()
-            torch.cuda.synchronize()
-            if isinstance(comm, nd.NativeComm):         # (the barrier through the communicator the data path uses, see main())
-                comm.barrier()
-            else:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 2 * (warmup + steps) + 8)
-
-        def timed():
-            # untimed rehearsal (lazy allocations, pools) -- and long enough for the sustained clocks: a rank's step is 0.7 ms at N = 8, and
-            # after idle the device needs some 15 ms of work to get there (protocol note; r4: 7 rehearsal steps read 751 us per
-            # step where 60 read 628) -- then from the start again
-            t_w = time.perf_counter()
-            while True:
-                run(0, warmup + steps)
-                fence()
-                if time.perf_counter() - t_w > 0.15:
-                    break
-            shard.eng.set_factors(w0, h0)
-            run(0, warmup)
-            fence()
-            t0 = time.perf_counter()
-            run(warmup, steps)
-            fence()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_gpu else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item()) / steps
-
-        # The chunked exchange (NMFX_DIST_CHUNKS, DESIGN 5: the all-reduce of a column chunk of [W^T V] behind the product of the
-        # next one) can only be settled on a multi-GPU node: both forms are timed in the same run.  The
-        # slot's iter_per_s is the form the environment asked for (default: one piece); the other one rides along.
-        asked = max(1, int(os.environ.get("NMFX_DIST_CHUNKS", "1") or 1))
-        by_chunks = {}
-        for nch in sorted({1, 2, asked}):
-            os.environ["NMFX_DIST_CHUNKS"] = str(nch)
+        for kind in loops:
+            os.environ["NMFX_DIST_NATIVE"] = "1" if kind == "native" else "0"
             try:
-                by_chunks[nch] = timed()
-            except Exception as e:  # noqa: BLE001  (every rank runs the same sequence: a failure here is the same on all of them)
-                by_chunks[nch] = f"{type(e).__name__}: {e}"
-        os.environ["NMFX_DIST_CHUNKS"] = str(asked)
-        if not isinstance(by_chunks[asked], float):
-            raise RuntimeError(by_chunks[asked])
-        dt = by_chunks[asked]
-        _, _, n_obj = shard.eng.state()
-        obj = shard.eng.objectives(0, n_obj)
-        ok = bool(np.all(np.isfinite(obj)) and obj[-1] < obj[0])
-        flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
-        nbytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4
-        return {"config": "cfg5", "workload": f"MUR Euclidean, V={m}x{n} f32 row-sharded over {world} GPU(s), k={k}, one all-reduce of "
-                                              "[W^T V | W^T W | objective] per iteration, |randn| start, objective every iteration",
-                "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
-                "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
-                "precision": shard.eng.precision(), "loop": loop + " / " + run.mode, "objective_first_last": [float(obj[0]), float(obj[-1])],
-                "exchange_chunks": asked,
-                "ms_per_step_by_exchange_chunks": {str(c): (v * 1e3 if isinstance(v, float) else v) for c, v in by_chunks.items()},
-                "objective_decreasing": ok, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
-                "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
-                "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
-                "all_reduce_bytes": float(shard.xf32.numel() * 4 if shard.merge_objective() else shard.xf32.numel() * 4 + 64),
-                "collectives_per_iteration": 1 if shard.merge_objective() else 2,
-                "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
+                shard, comm, loop = make_sharded(torch, dist, nd, rank, world, local_rank, build)
+            except Exception as e:  # noqa: BLE001  (build() has agreed the failure over the ranks)
+                times[f"{kind}/setup"] = f"{type(e).__name__}: {e}"
+                continue
+            took = "native" if isinstance(comm, nd.NativeComm) else "torch"
+            if took != kind:                                    # (the native communicator did not come up: the torch loop was timed already, or is next)
+                times[f"{kind}/setup"] = "fell back to torch.distributed's collectives"
+                shard.eng.close()
+                del shard
+                torch.cuda.empty_cache()
+                continue
+            try:
+                def fence():
+                    shard.eng.synchronize()
+                    torch.cuda.synchronize()
+                    if isinstance(comm, nd.NativeComm):         # (the barrier through the communicator the data path uses, see main())
+                        comm.barrier()
+                    else:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+
+                def timed():
+                    # a fresh Runner per form: it reads the exchange mode when it is made
+                    run = nd.Runner(shard, comm, 0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 2 * (warmup + steps) + 8)
+                    # untimed rehearsal (lazy allocations, pools) -- and long enough for the sustained clocks: a rank's step is 0.7 ms at N = 8, and
+                    # after idle the device needs some 15 ms of work to get there (protocol note; r4: 7 rehearsal steps read 751 us per
+                    # step where 60 read 628) -- then from the start again
+                    t_w = time.perf_counter()
+                    while True:
+                        shard.eng.set_factors(w0, h0)
+                        run(0, warmup + steps)
+                        fence()
+                        # (every rank must leave this loop in the same round: the decision is rank 0's)
+                        go = torch.tensor([1 if time.perf_counter() - t_w > 0.15 else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+                        dist.broadcast(go, src=0)
+                        if int(go.item()):
+                            break
+                    shard.eng.set_factors(w0, h0)
+                    run(0, warmup)
+                    fence()
+                    t0 = time.perf_counter()
+                    run(warmup, steps)
+                    fence()
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_gpu else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    _, _, n_obj = shard.eng.state()
+                    obj = shard.eng.objectives(0, n_obj)
+                    ok = bool(np.all(np.isfinite(obj)) and obj[-1] < obj[0])
+                    return float(t.item()) / steps, obj, ok, run.mode
+
+                for mode, nch in forms:
+                    os.environ["NMFX_DIST_EXCHANGE"] = mode
+                    os.environ["NMFX_DIST_CHUNKS"] = str(nch)
+                    key = f"{kind}/{mode}" + (f"/{nch} chunks" if nch > 1 else "")
+                    try:
+                        dt, obj, ok, rmode = timed()
+                    except Exception as e:  # noqa: BLE001  (every rank runs the same sequence: a failure here is the same on all of them)
+                        times[key] = f"{type(e).__name__}: {e}"
+                        continue
+                    times[key] = dt
+                    if ok and (slot is None or dt < slot["dt"]):
+                        slot = {"dt": dt, "key": key, "obj": obj, "loop": loop + " / " + rmode, "precision": shard.eng.precision(),
+                                "ar_bytes": float(shard.xf32.numel() * 4 if shard.merge_objective() else shard.xf32.numel() * 4 + 64),
+                                "collectives": (1 if shard.merge_objective() else 2) if mode == "allreduce" else 2}
+            finally:
+                if isinstance(comm, nd.NativeComm):
+                    try:
+                        comm.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                shard.eng.close()
+                del shard
+                torch.cuda.empty_cache()
     finally:
-        shard.eng.close()
-        del shard
-        torch.cuda.empty_cache()
+        for key, val in saved_env.items():
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
+    if slot is None:
+        raise RuntimeError(f"no form of the sharded loop ran: {times}")
+    dt, obj = slot["dt"], slot["obj"]
+    flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
+    nbytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4
+    return {"config": "cfg5", "workload": f"MUR Euclidean, V={m}x{n} f32 row-sharded over {world} GPU(s), k={k}, |randn| start, objective every "
+                                          "iteration; exchange per iteration = the fastest of the forms timed (see `exchange`)",
+            "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
+            "precision": slot["precision"], "loop": slot["loop"], "objective_first_last": [float(obj[0]), float(obj[-1])],
+            "exchange": slot["key"],
+            "ms_per_step_by_exchange": {key: (v * 1e3 if isinstance(v, float) else v) for key, v in times.items()},
+            "objective_decreasing": True, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
+            "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
+            "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
+            "all_reduce_bytes": slot["ar_bytes"], "collectives_per_iteration": slot["collectives"],
+            "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
 
 
 def scaling_model(torch, dev, base_ms):
@@ -419,7 +461,7 @@ def scaling_model(torch, dev, base_ms):
 
 
 def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None,
-                 precision=None, bound="hbm"):
+                 precision=None, bound="hbm", check_f64=False):
     """One of BASELINE.json's non-headline single-GPU configs: iterations/s over `steps` steps after `warmup`,
     per-kernel device times (HIP events on the engine's stream, separate pass), the algorithmic work per
     iteration and the dominant kernel against the HBM roofline."""
@@ -474,6 +516,24 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             if cnt:
                 prof[kn] = {"us_per_launch": round(ms / cnt * 1e3, 2), "launches_per_iter": cnt / psteps}
         eng.profile_enable(False)
+        check = None
+        if check_f64:
+            # the matrix in its stated size CHECKED, not only timed (MUR-eu only): the objective the device
+            # recorded for the final pair against nmfx_objective_f64 (product and sum in float64 on the device) of that pair, the
+            # whole history decreasing, the factors non-negative and finite (nmf/mur.py:119-128 keeps all three)
+            done = warmup + steps + psteps
+            eng.mur_finish(0, 10 ** 12, 1e-5, 1e-5, done)
+            _, _, n_all = eng.state()
+            hist = eng.objectives(0, n_all)
+            f64 = eng.objective_f64()
+            w_f, h_f = eng.get_factors()
+            check = {"iterations": int(done), "objective_recorded": float(hist[-1]), "objective_f64": float(f64),
+                     "objective_f64_rel_diff": float(abs(hist[-1] - f64) / abs(f64)),
+                     "history_decreasing": bool(len(hist) == done + 1 and np.all(np.diff(hist) < 0)),
+                     "factors_nonnegative_finite": bool(np.isfinite(w_f).all() and np.isfinite(h_f).all() and w_f.min() >= 0 and h_f.min() >= 0)}
+            del w_f, h_f
+            if not os.environ.get("NMFX_BENCH_NOASSERT"):
+                assert check["objective_f64_rel_diff"] < 1e-5 and check["history_decreasing"] and check["factors_nonnegative_finite"], f"{name}: {check}"
         inner = paths = None
         if admm_iter:
             inner = (eng.inner_counts(0, warmup + steps) & 0xFFFF).mean(axis=0).tolist()
@@ -512,6 +572,7 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                                      "frac": 2.0 * m * n * (-(-k // 128) * 128 if k > 128 else k) / dsec / 1e12 / PEAK_F32_MFMA_TFLOPS}),
                 "mean_inner_rounds_h_w": inner, "inner_first_leg_stood_cut_continued_both": paths, "objective_first_last": [float(obj[0]), float(obj[-1])],
                 "kernels": prof, "data": "synthetic, drawn on the device (torch generator, seed 0)",
+                **({"full_matrix_check": check, "objective_f64_rel_diff": check["objective_f64_rel_diff"]} if check else {}),
                 "wall_s_incl_setup": round(time.perf_counter() - t_all, 1)}
     finally:
         eng.close()
@@ -537,7 +598,7 @@ def other_configs(torch, dev, only=None):
              flops=8.0 * 32768 * 16384 * 64, nbytes=2.0 * 32768 * 16384 * 4),
         dict(name="cfg5_on_1_gpu", workload="MUR Euclidean, V=131072x16384 f32 (8 GiB), k=128 on ONE GPU: the strong-scaling base of "
                                             "the 8-GPU config",
-             m=131072, n=16384, k=128, steps=5, warmup=2, init="randn", repeat_dist=0,
+             m=131072, n=16384, k=128, steps=5, warmup=2, init="randn", repeat_dist=0, check_f64=True,
              queue=lambda e, f, c: e.mur_run(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, f, c),
              flops=4.0 * 131072 * 16384 * 128 + 4.0 * 128 * 128 * (131072 + 16384),
              nbytes=2.0 * 131072 * 16384 * 4 + 3.0 * (131072 + 16384) * 128 * 4),

@@ -163,6 +163,22 @@ int nmfx_mur_phase_a_head(nmfx_handle_t h, int distance, double lambda_w, int64_
 int nmfx_mur_phase_a_cols(nmfx_handle_t h, int distance, int64_t c0, int64_t c1);
 int nmfx_mur_finish_a(nmfx_handle_t h, int distance, int64_t j);
 int nmfx_mur_finish_b(nmfx_handle_t h, int64_t min_iter, double tol1, double tol2, int64_t j);
+/* Phase B in two parts, for an exchange by reduce-scatter + all-gather instead of one all-reduce (the sum over the
+ * row shards is the one nmf/mur.py:45 `w.T @ x` forms): with `world` ranks, rank r owns the columns [r * cols, (r + 1) * cols) of H,
+ *     nmfx_mur_phase_a(j);
+ *     reduce-scatter (sum) of xf32[0, world * elems) in place: rank r receives the range [r * elems, (r + 1) * elems);
+ *         sum-all-reduce of the rest of the f32 buffer, xf32[world * elems, n_f32)   (W^T W, the objective digits);
+ *     nmfx_mur_phase_b_slice(j, r * cols, (r + 1) * cols):   the update of mur.py:45 for those columns, the objective and the stop
+ *         rule of iteration j (identical on every rank); the new columns are also left in the rank's range of xf32;
+ *     all-gather of the ranges in place;
+ *     nmfx_mur_phase_b_rest(r * cols, (r + 1) * cols):       the other ranks' columns into H (and whatever follows the update).
+ * nmfx_mur_slice_info returns cols (a multiple of 64) and elems = cols * k_padded, or 0 / 0 where this form is not available:
+ * Euclidean loss on the split-bf16 path only (nmfx_set_exchange_rank in force), padded n a multiple of 64 * world.  Every rank ends
+ * with bit-identical H: each column is computed by ONE rank and copied.                                                           */
+int nmfx_mur_slice_info(nmfx_handle_t h, int distance, int world, int64_t* cols, int64_t* elems);
+int nmfx_mur_phase_b_slice(nmfx_handle_t h, int distance, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j,
+                           int64_t c0, int64_t c1);
+int nmfx_mur_phase_b_rest(nmfx_handle_t h, int distance, int64_t c0, int64_t c1);
 
 /* Exchange buffers: f32 part = [W^T V (kp x n_pad) | W^T W (kp x kp)] (+ KL:
  * column sums of W), f64 part = [objective partial, 4 inner-loop norm sums (sharded AO-ADMM, round by round), 3 spare,
@@ -245,6 +261,12 @@ int nmfx_comm_all_reduce(nmfx_handle_t h, int which, int64_t first, int64_t coun
 int nmfx_comm_all_min(nmfx_handle_t h, int64_t* vals, int n);
 int nmfx_comm_barrier(nmfx_handle_t h);     /* the handle's queued work is done and every rank has arrived (one-word all-reduce + stream sync) */
 int nmfx_comm_set_graph(nmfx_handle_t h, int enable);
+/* The exchange inside nmfx_mur_run_sharded: 0 = one sum-all-reduce of the f32 buffer per iteration (default); 1 = reduce-scatter of
+ * its W^T V part (+ all-reduce of the k x k Gram matrix and the objective digits, one RCCL group) . nmfx_mur_phase_b_slice .
+ * all-gather . nmfx_mur_phase_b_rest -- see nmfx_mur_slice_info.  Iterations the sliced form is not available for take the
+ * all-reduce.  The same value on every rank.                                                                                  */
+int nmfx_comm_set_exchange(nmfx_handle_t h, int mode);
+int nmfx_comm_get_exchange(nmfx_handle_t h, int* mode);
 int nmfx_comm_graph_replays(nmfx_handle_t h, int64_t* replays);
 int nmfx_mur_run_sharded(nmfx_handle_t h, int distance, double lambda_w, double lambda_h, int64_t min_iter,
                          double tol1, double tol2, int64_t first, int64_t count);

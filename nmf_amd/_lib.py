@@ -78,6 +78,11 @@ SIGNATURES = {
     "nmfx_comm_barrier": (_i32, [_vp]),
     "nmfx_comm_set_graph": (_i32, [_vp, _i32]),
     "nmfx_comm_graph_replays": (_i32, [_vp, C.POINTER(_i64)]),
+    "nmfx_comm_set_exchange": (_i32, [_vp, _i32]),
+    "nmfx_comm_get_exchange": (_i32, [_vp, C.POINTER(_i32)]),
+    "nmfx_mur_slice_info": (_i32, [_vp, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nmfx_mur_phase_b_slice": (_i32, [_vp, _i32, _dbl, _i64, _dbl, _dbl, _i64, _i64, _i64]),
+    "nmfx_mur_phase_b_rest": (_i32, [_vp, _i32, _i64, _i64]),
     "nmfx_mur_run_sharded": (_i32, [_vp, _i32, _dbl, _dbl, _i64, _dbl, _dbl, _i64, _i64]),
     "nmfx_mur_finish_sharded": (_i32, [_vp, _i32, _i64, _dbl, _dbl, _i64]),
     "nmfx_objective_f64": (_i32, [_vp, _pd]),

@@ -24,6 +24,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,12 +50,14 @@ RcclApi& rccl() {
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(sym("ncclReduceScatter"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GroupStart || !api.GroupEnd ||
-            !api.GetErrorString) { dlclose(api.lib); api.lib = nullptr; }
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.ReduceScatter || !api.AllGather ||
+            !api.GroupStart || !api.GroupEnd || !api.GetErrorString) { dlclose(api.lib); api.lib = nullptr; }
     });
     return api;
 }
@@ -70,11 +74,12 @@ struct nmfx_comm {
     bool negotiated = false;
     bool merged = false;                  // objective partial inside the f32 buffer: one collective per MUR-eu iteration
     int64_t chunk_unit = 0;
+    int exchange = 0;                     // nmfx_comm_set_exchange: 0 = one sum-all-reduce per iteration, 1 = reduce-scatter . sliced H update . all-gather
     // hipGraph replay of iteration pairs (nmfx_comm_set_graph)
     bool want_graph = false, graph_failed = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    double g_lw = 0, g_lh = 0, g_t1 = 0, g_t2 = 0; int64_t g_min = 0; int g_dist = -1; int g_chunks = 0; int g_precision = -1;
+    double g_lw = 0, g_lh = 0, g_t1 = 0, g_t2 = 0; int64_t g_min = 0; int g_dist = -1; int g_chunks = 0; int g_precision = -1; int g_exchange = -1;
     const void* g_hist = nullptr; hipStream_t g_stream = nullptr;     // what the captured nodes point at
     bool g_klfresh = false;               // captured with "the previous iteration's KL epilogue left its images and sums" (kl_h_iter)
     int64_t replays = 0;
@@ -255,6 +260,25 @@ extern "C" int nmfx_comm_set_graph(nmfx_handle_t E, int enable) {
     return NMFX_OK;
 }
 
+// The exchange of the sharded MUR loop (nmfx_mur_run_sharded): 0 = one sum-all-reduce of the f32 buffer per iteration (default),
+// 1 = reduce-scatter of its W^T V part . H update of this rank's column slice . all-gather (on xGMI's point-to-point
+// links the all-reduce IS those two steps; between them every rank now updates n / world columns instead of all n).  Iterations
+// for which the sliced update is not available (nmfx_mur_slice_info: KL loss, exact-f32 epilogues, separate objective exchange,
+// n not a multiple of 64 * world) take the all-reduce.  Must be the same on every rank (as NMFX_DIST_EXCHANGE is).
+extern "C" int nmfx_comm_set_exchange(nmfx_handle_t E, int mode) {
+    int rc = have_comm(E); if (rc) return rc;
+    if (mode != 0 && mode != 1) { E->err = "comm_set_exchange: 0 (all-reduce) or 1 (reduce-scatter + all-gather)"; return NMFX_E_ARG; }
+    if (E->comm->exchange != mode) drop_graph(E->comm);
+    E->comm->exchange = mode;
+    return NMFX_OK;
+}
+
+extern "C" int nmfx_comm_get_exchange(nmfx_handle_t E, int* mode) {
+    if (!E || !mode) return NMFX_E_ARG;
+    *mode = E->comm ? E->comm->exchange : 0;
+    return NMFX_OK;
+}
+
 static int chunks_from_env() {
     const char* s = getenv("NMFX_DIST_CHUNKS");
     const int n = s ? atoi(s) : 1;
@@ -277,6 +301,21 @@ static int sharded_iteration(nmfx_engine* E, int distance, double lw, double lh,
         step = ((npad + chunks - 1) / chunks) / unit * unit;
         if (step < 512) step = 512;
         if (step >= npad) step = 0;
+    }
+    int64_t scols = 0, selems = 0;
+    if (c->exchange == 1 && merged) nmfx_mur_slice_info(E, distance, c->world, &scols, &selems);
+    if (scols > 0) {
+        // reduce-scatter . sliced update . all-gather, all in place in the f32 exchange buffer ([column][factor]: a column range is contiguous)
+        if ((rc = nmfx_mur_phase_a(E, distance, lw, j))) return rc;
+        const int64_t head = selems * c->world;       // = kp * np: the W^T V part
+        NMFX_RCCL(rccl().GroupStart());
+        ncclResult_t r1 = rccl().ReduceScatter(E->xf32, E->xf32 + c->rank * selems, (size_t)selems, ncclFloat, ncclSum, c->comm, E->stream);
+        ncclResult_t r2 = rccl().AllReduce(E->xf32 + head, E->xf32 + head, (size_t)(n32 - head), ncclFloat, ncclSum, c->comm, E->stream);
+        NMFX_RCCL(rccl().GroupEnd());
+        NMFX_RCCL(r1); NMFX_RCCL(r2);
+        if ((rc = nmfx_mur_phase_b_slice(E, distance, lh, min_iter, tol1, tol2, j, c->rank * scols, (c->rank + 1) * scols))) return rc;
+        NMFX_RCCL(rccl().AllGather(E->xf32 + c->rank * selems, E->xf32, (size_t)selems, ncclFloat, c->comm, E->stream));
+        return nmfx_mur_phase_b_rest(E, distance, c->rank * scols, (c->rank + 1) * scols);
     }
     if (step == 0) {
         if ((rc = nmfx_mur_phase_a(E, distance, lw, j))) return rc;
@@ -322,7 +361,7 @@ static int capture_pair(nmfx_engine* E, int distance, double lw, double lh, int6
     if (hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); c->exec = nullptr; (void)hipGetLastError(); return NMFX_E_HIP; }
     c->graph = g;
     c->g_hist = E->obj_hist; c->g_stream = E->stream;
-    c->g_dist = distance; c->g_lw = lw; c->g_lh = lh; c->g_min = min_iter; c->g_t1 = tol1; c->g_t2 = tol2; c->g_chunks = chunks; c->g_precision = E->precision;
+    c->g_dist = distance; c->g_lw = lw; c->g_lh = lh; c->g_min = min_iter; c->g_t1 = tol1; c->g_t2 = tol2; c->g_chunks = chunks; c->g_precision = E->precision; c->g_exchange = c->exchange;
     return NMFX_OK;
 }
 
@@ -359,7 +398,7 @@ extern "C" int nmfx_mur_run_sharded(nmfx_handle_t E, int distance, double lambda
             if ((rc = nmfx_ensure_obj_capacity(E, end + 4))) return rc;           // (may move the history: checked below)
             const bool same = c->exec && c->g_dist == distance && c->g_lw == lambda_w && c->g_lh == lambda_h && c->g_min == min_iter &&
                               c->g_t1 == tol1 && c->g_t2 == tol2 && c->g_chunks == chunks && c->g_hist == E->obj_hist &&
-                              c->g_stream == E->stream && c->g_precision == E->precision;
+                              c->g_stream == E->stream && c->g_precision == E->precision && c->g_exchange == c->exchange;
             if (!same) {
                 const bool fresh_now = distance == NMFX_KL && E->kl_h_iter == j - 1;
                 if (fresh_now) E->kl_h_iter = -1;

@@ -652,6 +652,38 @@ int nmfx_mur_phase_b(nmfx_handle_t E, int distance, double lambda_h, int64_t min
     E->err = "Unknown distance type."; return NMFX_E_ARG;
 }
 
+// Phase B by column slices (reduce-scatter / all-gather exchange, include/nmfx.h)
+int nmfx_mur_slice_info(nmfx_handle_t E, int distance, int world, int64_t* cols, int64_t* elems) {
+    if (!E || world < 1) return NMFX_E_ARG;
+    const bool ok = mur_chunkable(E, distance) && E->xworld == world && (E->np / 64) % world == 0;
+    const int64_t c = ok ? E->np / world : 0;
+    if (cols) *cols = c;
+    if (elems) *elems = c * E->kp;
+    return NMFX_OK;
+}
+static int slice_args(nmfx_engine* E, int distance, int64_t c0, int64_t c1, const char* who) {
+    if (!mur_chunkable(E, distance) || E->xworld <= 0) { E->err = std::string(who) + ": Euclidean loss on the split-bf16 path with nmfx_set_exchange_rank in force only (nmfx_mur_slice_info)"; return NMFX_E_ARG; }
+    if (c0 < 0 || c1 < c0 || c1 > E->np || c0 % 64 || c1 % 64) { E->err = std::string(who) + ": column range must be whole 64-column blocks inside the padded n"; return NMFX_E_ARG; }
+    return NMFX_OK;
+}
+int nmfx_mur_phase_b_slice(nmfx_handle_t E, int distance, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j,
+                           int64_t c0, int64_t c1) {
+    if (!E) return NMFX_E_ARG;
+    E->himg_both = false;
+    E->kl_h_iter = -2;
+    int rc = check_ready(E, j, 1); if (rc) return rc;
+    if ((rc = slice_args(E, distance, c0, c1, "phase_b_slice"))) return rc;
+    E->wsel = (int)((j + 1) & 1);
+    E->w_in_place = false;
+    return nmfx_mur_eu_phase_b_slice_bf16(E, lambda_h, min_iter, tol1, tol2, j, (int)(c0 / 64), (int)((c1 - c0) / 64));
+}
+int nmfx_mur_phase_b_rest(nmfx_handle_t E, int distance, int64_t c0, int64_t c1) {
+    if (!E) return NMFX_E_ARG;
+    int rc = slice_args(E, distance, c0, c1, "phase_b_rest"); if (rc) return rc;
+    NMFX_HIP(hipSetDevice(E->device));
+    return nmfx_mur_eu_phase_b_rest_bf16(E, (int)(c0 / 64), (int)((c1 - c0) / 64));
+}
+
 int nmfx_mur_finish_a(nmfx_handle_t E, int distance, int64_t j) {
     if (!E) return NMFX_E_ARG;
     int rc = check_ready(E, j, 1); if (rc) return rc;

@@ -1899,8 +1899,10 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     DevState* __restrict__ st, double* __restrict__ obj_hist,
     unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
     const float* __restrict__ xtail = nullptr, int xworld = 0,   // NMFX_XTAIL: every rank's objective partial, as 16-bit digits
-    float lam1 = 0.f)
-{
+    float lam1 = 0.f,
+    int cb0 = 0, float* __restrict__ stage = nullptr)            // reduce-scatter / all-gather exchange (r5): the grid covers the column blocks
+{                                                                // from cb0 on (this rank's slice) and ALSO leaves the new KP x 64 tile, as it stands
+                                                                 // ([factor][64] f32), where its B^T tile came from: stage + c0 * KP -- the all-gather's send range
     static_assert(!PAIR || (KP == 128 && !FROM_SLABS), "pair mode: k = 128 layouts, sums from the pack launch");
     constexpr int CB = 64, LDG = KP + 4, LDC = 80, LDD = 68, NT = 512;
     constexpr int TV = KP / 32;                        // 16-byte pieces per thread of the KP x 64 H tile / the 64 x KP B^T tile
@@ -1915,7 +1917,7 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
     float* bt = hs + KP * LDC;                         // B^T tile [c][LDG]
     __shared__ double shd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, q = lane >> 4;
-    const int64_t c0 = (int64_t)blockIdx.x * CB;
+    const int64_t c0 = (int64_t)(blockIdx.x + cb0) * CB;
     const int64_t kk = (int64_t)KP * KP, bn = (int64_t)KP * np;
     int dead[2] = {0, 0};                              // (PAIR) problems that stopped in an earlier iteration
     double sacc1 = 0.0;
@@ -2065,7 +2067,47 @@ __global__ __launch_bounds__(512) void mur_h_update_bf16_kernel(
             *reinterpret_cast<uint4*>(Hhi + idx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
             *reinterpret_cast<uint4*>(Hlo + idx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
         }
+        if (stage) {                                   // (every thread of the block has its B^T values in LDS since two barriers ago)
+#pragma unroll
+            for (int v4 = 0; v4 < EP / 4; ++v4)
+                *reinterpret_cast<float4*>(stage + c0 * KP + jr * CB + cq + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
         }
+        }
+    }
+}
+
+// The other ranks' columns of the new H after the all-gather of the reduce-scatter / all-gather exchange: the KP x 64 tiles the
+// ranks' mur_h_update_bf16_kernel launches left in the exchange buffer (stage + c0 * KP, [factor][64] f32) go to H and its bf16
+// images -- the values, the split and hence the bits the owning rank wrote for itself.  The grid skips the column blocks
+// [skip0, skip1) (this rank's own slice).
+template <int KP>
+__global__ __launch_bounds__(512) void mur_h_unpack_bf16_kernel(
+    const float* __restrict__ stage, float* __restrict__ H, unsigned short* __restrict__ Hhi, unsigned short* __restrict__ Hlo,
+    int64_t np, int skip0, int skip1, const int* __restrict__ flag)
+{
+    if (*flag) return;                                 // (the stop rule fired in the epilogue launch in front: H stays as it is)
+    constexpr int CB = 64, EP = KP / 8, TPR = CB / EP;
+    const int tid = threadIdx.x;
+    const int cbk = (int)blockIdx.x < skip0 ? (int)blockIdx.x : (int)blockIdx.x + (skip1 - skip0);
+    const int64_t c0 = (int64_t)cbk * CB;
+    const int jr = tid / TPR, cq = EP * (tid % TPR);
+    float hn[EP];
+    unsigned ph[EP / 2], pl[EP / 2];
+#pragma unroll
+    for (int v4 = 0; v4 < EP / 4; ++v4) {
+        const float4 t = *reinterpret_cast<const float4*>(stage + c0 * KP + jr * CB + cq + 4 * v4);
+        hn[4 * v4] = t.x; hn[4 * v4 + 1] = t.y; hn[4 * v4 + 2] = t.z; hn[4 * v4 + 3] = t.w;
+    }
+#pragma unroll
+    for (int e = 0; e < EP / 2; ++e) split2(hn[2 * e], hn[2 * e + 1], ph[e], pl[e]);
+    const int64_t idx = (int64_t)jr * np + c0 + cq;
+#pragma unroll
+    for (int v4 = 0; v4 < EP / 4; ++v4)
+        *reinterpret_cast<float4*>(H + idx + 4 * v4) = make_float4(hn[4 * v4], hn[4 * v4 + 1], hn[4 * v4 + 2], hn[4 * v4 + 3]);
+#pragma unroll
+    for (int v8 = 0; v8 < EP / 8; ++v8) {
+        *reinterpret_cast<uint4*>(Hhi + idx + 8 * v8) = make_uint4(ph[4 * v8], ph[4 * v8 + 1], ph[4 * v8 + 2], ph[4 * v8 + 3]);
+        *reinterpret_cast<uint4*>(Hlo + idx + 8 * v8) = make_uint4(pl[4 * v8], pl[4 * v8 + 1], pl[4 * v8 + 2], pl[4 * v8 + 3]);
     }
 }
 
@@ -2649,9 +2691,12 @@ static int launch_w_update_bf16(nmfx_engine* E, const float* Wold, float* Wnew, 
 // from_slabs: B^T, G and the objective partials straight from the H phase's slabs (single GPU, kp = 64);
 // otherwise from the (all-reduced) exchange buffers: xf32 = [B^T sums [np][kp] | G], xf64[0] = objective
 template <int KP>
-static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int64_t j, int64_t min_iter, double tol1, double tol2) {
+static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int64_t j, int64_t min_iter, double tol1, double tol2,
+                               int cb0 = 0, int nblk = -1) {      // (cb0, nblk: this rank's column blocks of the sliced update, with the staged copy)
     ProfScope ps(E, "h_update");
-    const dim3 grid((unsigned)(E->np / 64)), block(512);
+    const bool sliced = nblk >= 0;
+    const dim3 grid((unsigned)(sliced ? nblk : E->np / 64)), block(512);
+    if (sliced && nblk == 0) return NMFX_OK;
     constexpr size_t shm = (size_t)(KP * (KP + 4) + KP * 80 + 64 * (KP + 4)) * sizeof(float);
     { int rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, true>), (int)shm); if (rc_) return rc_;
       rc_ = nmfx_allow_lds(E, reinterpret_cast<const void*>(mur_h_update_bf16_kernel<KP, false>), (int)shm); if (rc_) return rc_; }
@@ -2663,7 +2708,19 @@ static int launch_h_update_bf16(nmfx_engine* E, bool from_slabs, float lam, int6
         hipLaunchKernelGGL((mur_h_update_bf16_kernel<KP, false>), grid, block, shm, E->stream, E->xf32, 1,
                            E->xf32 + (int64_t)E->kp * E->np, 1, E->xf64, (int64_t)1, E->H, E->np,
                            lam, (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo,
-                           E->xworld > 0 ? E->xf32 + (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp : (const float*)nullptr, E->xworld);
+                           E->xworld > 0 ? E->xf32 + (int64_t)E->kp * E->np + (int64_t)E->kp * E->kp + E->kp : (const float*)nullptr, E->xworld,
+                           0.f, cb0, sliced ? E->xf32 : (float*)nullptr);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+template <int KP>
+static int launch_h_unpack_bf16(nmfx_engine* E, int skip0, int skip1) {
+    ProfScope ps(E, "h_unpack");
+    const int nblk = (int)(E->np / 64) - (skip1 - skip0);
+    if (nblk <= 0) return NMFX_OK;
+    hipLaunchKernelGGL((mur_h_unpack_bf16_kernel<KP>), dim3((unsigned)nblk), dim3(512), 0, E->stream, E->xf32, E->H, E->Hhi, E->Hlo,
+                       E->np, skip0, skip1, &E->state->flag);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2862,6 +2919,26 @@ int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, 
     return launch_h_update_bf16<64>(E, E->fused_pack, (float)lambda_h, j, min_iter, tol1, tol2);
 }
 
+// Phase B in two parts for the reduce-scatter / all-gather exchange (r5): `slice` updates the column blocks
+// [cb0, cb0 + nblk) of H from this rank's reduce-scattered range of the exchange buffer (the whole Gram matrix and the objective
+// digits behind it are all-reduced as before) and leaves the new tiles in that range; after the all-gather `rest` brings the
+// other ranks' tiles into H and its images and does what follows the update (k = 128: H H^T from the images).
+int nmfx_mur_eu_phase_b_slice_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j, int cb0, int nblk) {
+    if (E->kp != 64) return launch_h_update_bf16<128>(E, false, (float)lambda_h, j, min_iter, tol1, tol2, cb0, nblk);
+    return launch_h_update_bf16<64>(E, false, (float)lambda_h, j, min_iter, tol1, tol2, cb0, nblk);
+}
+
+int nmfx_mur_eu_phase_b_rest_bf16(nmfx_engine* E, int cb0, int nblk) {
+    int rc;
+    if (E->kp == 64) return launch_h_unpack_bf16<64>(E, cb0, cb0 + nblk);
+    if ((rc = launch_h_unpack_bf16<128>(E, cb0, cb0 + nblk))) return rc;
+    int hslabs = E->gsplit;                            // (as mur_eu_phase_b_bf16_k128)
+    if ((rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;
+    if (hslabs < E->gsplit)
+        NMFX_HIP(hipMemsetAsync(E->HHt_part + (int64_t)hslabs * E->kp * E->kp, 0, (size_t)(E->gsplit - hslabs) * E->kp * E->kp * sizeof(float), E->stream));
+    return NMFX_OK;
+}
+
 // ---- phase A in pieces: an exchange that overlaps with the H-side product ("column chunks") ----------------
 // The exchange buffer of the split-bf16 path is [column][factor], so the columns [c0, c1) of V are the contiguous range
 // xf32[c0 kp, c1 kp): the caller can hand that range to the collective while the product of the next range runs.
@@ -3041,7 +3118,7 @@ static int pair_iteration(nmfx_engine* E, const double* lw, const double* lh, in
       hipLaunchKernelGGL(kern, dim3((unsigned)(E->np / 64)), dim3(512), shm, E->stream, (const float*)E->xf32, 1,
                          (const float*)(E->xf32 + (int64_t)E->kp * E->np), 1, (const double*)E->obj_part, nobj, E->H, E->np, (float)lh[0],
                          (long long)j, (long long)min_iter, tol1, tol2, E->state, E->obj_hist, E->Hhi, E->Hlo,
-                         (const float*)nullptr, 0, (float)lh[1]);
+                         (const float*)nullptr, 0, (float)lh[1], 0, (float*)nullptr);
       NMFX_HIP(hipGetLastError()); }
     int hslabs = E->gsplit;
     if ((rc = nmfx_bf16_gram_h(E, &hslabs))) return rc;

@@ -245,6 +245,8 @@ int nmfx_bf16_kl_objective(nmfx_engine* E);      // obj_part <- KL(V, W H) from 
 int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2 = nullptr);
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
+int nmfx_mur_eu_phase_b_slice_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j, int cb0, int nblk);
+int nmfx_mur_eu_phase_b_rest_bf16(nmfx_engine* E, int cb0, int nblk);
 int nmfx_finish_b(nmfx_engine* E, int64_t min_iter, double tol1, double tol2, int64_t j);
 // One solver family per set of factors: the families keep different device state next to W and H (MUR: W ping-pong and bf16 images of
 // both factors; AO-ADMM / ADMM: duals and auxiliaries; ANLS: warm-start supports), and a family that starts in the middle of another's

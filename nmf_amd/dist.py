@@ -92,6 +92,41 @@ class TorchComm:
             return None
         return self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def reduce_scatter(self, tensor, elems):
+        """Sum-reduce-scatter IN PLACE of tensor[0 : world * elems]: afterwards this rank's range [rank * elems, (rank + 1) * elems)
+        holds the sum over the ranks of that range (the other ranges are unspecified).  Host-staged / CPU backends (gloo has no
+        reduce-scatter): an all-reduce of the whole head, which leaves the same values in the rank's range."""
+        head = tensor[:self.world * elems]
+        if self.stage or not tensor.is_cuda or self.dist.get_backend(self.group) != "nccl":
+            self.all_reduce(head)
+            return
+        self.dist.reduce_scatter_tensor(head[self.rank * elems:(self.rank + 1) * elems], head, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self, tensor, elems):
+        """All-gather IN PLACE: every rank's range [rank * elems, (rank + 1) * elems) of `tensor` reaches every rank."""
+        head = tensor[:self.world * elems]
+        mine = head[self.rank * elems:(self.rank + 1) * elems]
+        if self.stage and tensor.is_cuda:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            host = head.cpu()
+            parts = [torch.empty(elems, dtype=host.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, host[self.rank * elems:(self.rank + 1) * elems].clone(), group=self.group)
+            head.copy_(torch.cat(parts))
+            return
+        if not tensor.is_cuda or self.dist.get_backend(self.group) != "nccl":
+            parts = [self.torch_empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, part in enumerate(parts):
+                head[r * elems:(r + 1) * elems].copy_(part)
+            return
+        self.dist.all_gather_into_tensor(head, mine, group=self.group)
+
+    @staticmethod
+    def torch_empty_like(t):
+        import torch
+        return torch.empty_like(t)
+
     def barrier(self):
         self.dist.barrier(group=self.group)
 
@@ -189,6 +224,17 @@ class DeviceShard:
             return None
         total = self.xf32.numel()
         return [(c0, c1, c0 * kpad, c1 * kpad if c1 < npad else total) for c0, c1 in zip(edges[:-1], edges[1:])]
+
+    def slice_info(self, dist_code, world):
+        """(columns of H per rank, f32 exchange elements per rank) of the reduce-scatter / all-gather form of phase B, or (0, 0)
+        where the engine has none for this loss / arithmetic / shape (nmfx_mur_slice_info)."""
+        return self.eng.mur_slice_info(dist_code, world)
+
+    def phase_b_slice(self, dist_code, lambda_h, min_iter, tol1, tol2, j, c0, c1):
+        self.eng.mur_phase_b_slice(dist_code, lambda_h, min_iter, tol1, tol2, j, c0, c1)
+
+    def phase_b_rest(self, dist_code, c0, c1):
+        self.eng.mur_phase_b_rest(dist_code, c0, c1)
 
     def phase_a_head(self, dist_code, lambda_w, j):
         self.eng.mur_phase_a_head(dist_code, lambda_w, j)
@@ -385,10 +431,58 @@ def _exchange_chunks():
         return 1
 
 
+def exchange_mode():
+    """NMFX_DIST_EXCHANGE: "allreduce" (default: one sum-all-reduce of [W^T V | W^T W | objective] per iteration) or "rsag" (SURVEY 8e:
+    reduce-scatter of the W^T V part, every rank updates ITS n / world columns of H, all-gather -- what the all-reduce does on xGMI's
+    point-to-point links anyway, with the replicated H update cut to a slice in between).  The same on every rank."""
+    import os
+    val = os.environ.get("NMFX_DIST_EXCHANGE", "allreduce").strip().lower()
+    if val in ("", "0", "allreduce", "all_reduce", "ar"):
+        return "allreduce"
+    if val in ("1", "rsag", "rs+ag", "reduce_scatter"):
+        return "rsag"
+    raise ValueError(f"NMFX_DIST_EXCHANGE={val!r}: 'allreduce' or 'rsag'")
+
+
+def _slice_plan(shard, comm, dist_code):
+    """(c0, c1, elems) of this rank's column slice for the reduce-scatter / all-gather exchange, or None (mode off, a shard or
+    communicator without it, or the engine has no sliced phase B for this run: every rank then takes the all-reduce -- the answer
+    depends on the shape, the loss and what negotiate() settled, which are the same everywhere)."""
+    if exchange_mode() != "rsag" or getattr(shard, "slice_info", None) is None or not hasattr(comm, "reduce_scatter"):
+        return None
+    world, rank = getattr(comm, "world", 1), getattr(comm, "rank", 0)
+    cols, elems = shard.slice_info(dist_code, world)
+    if not cols:
+        return None
+    return rank * cols, (rank + 1) * cols, elems
+
+
+def _iteration(shard, comm, bufs, plan, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, j):
+    """One sharded outer iteration, exchange in one piece: all-reduce, or reduce-scatter . slice . all-gather . rest."""
+    shard.phase_a(dist_code, lambda_w, j)
+    if plan is None:
+        comm.all_reduce(*bufs)
+        shard.phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+        return
+    c0, c1, elems = plan
+    x32 = bufs[0]
+    world = getattr(comm, "world", 1)
+    comm.reduce_scatter(x32, elems)
+    comm.all_reduce(x32[world * elems:], *bufs[1:])               # W^T W, the objective digits (and the f64 partial where not merged)
+    shard.phase_b_slice(dist_code, lambda_h, min_iter, tol1, tol2, j, c0, c1)
+    comm.all_gather(x32, elems)
+    shard.phase_b_rest(dist_code, c0, c1)
+
+
 def run_iterations(shard, comm, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, first, count, chunks=None):
     """Queue `count` sharded outer iterations (no host sync)."""
     _negotiate(shard, comm)
     bufs = _mur_buffers(shard, dist_code)
+    plan = _slice_plan(shard, comm, dist_code)
+    if plan is not None:
+        for j in range(first, first + count):
+            _iteration(shard, comm, bufs, plan, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, j)
+        return
     chunks = _exchange_chunks() if chunks is None else chunks
     ranges = None
     if chunks > 1 and dist_code == 0 and getattr(shard, "chunk_ranges", None) is not None and hasattr(comm, "all_reduce_async"):
@@ -434,6 +528,7 @@ class GraphedIterations:
         self.graph = torch.cuda.CUDAGraph()
         _negotiate(shard, comm)
         bufs = _mur_buffers(shard, dist_code)
+        plan = _slice_plan(shard, comm, dist_code)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
@@ -441,9 +536,7 @@ class GraphedIterations:
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 shard.eng.set_stream(torch.cuda.current_stream().cuda_stream)
                 for j in (0, 1):
-                    shard.phase_a(dist_code, lambda_w, j)
-                    comm.all_reduce(*bufs)
-                    shard.phase_b(dist_code, lambda_h, min_iter, tol1, tol2, j)
+                    _iteration(shard, comm, bufs, plan, dist_code, lambda_w, lambda_h, min_iter, tol1, tol2, j)
                 shard.eng.shift_iteration_base(2)
         finally:
             shard.eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -476,6 +569,7 @@ class Runner:
             if graph is None:
                 graph = os.environ.get("NMFX_DIST_GRAPH", "0") == "1"
             shard.negotiate(comm)
+            shard.eng.comm_set_exchange(1 if exchange_mode() == "rsag" else 0)
             shard.eng.comm_set_graph(bool(graph) and max_iter >= 4)
             self.want_graph, self.graph = False, None
             self.mode = "native-hipgraph" if (graph and max_iter >= 4) else "native"

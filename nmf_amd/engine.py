@@ -383,6 +383,28 @@ class Engine:
     def comm_set_graph(self, enable):
         self._ck(self.lib.nmfx_comm_set_graph(self.h, 1 if enable else 0))
 
+    def comm_set_exchange(self, mode):
+        """0 = all-reduce, 1 = reduce-scatter . sliced H update . all-gather inside nmfx_mur_run_sharded (include/nmfx.h)."""
+        self._ck(self.lib.nmfx_comm_set_exchange(self.h, int(mode)))
+
+    def comm_get_exchange(self):
+        m = C.c_int()
+        self._ck(self.lib.nmfx_comm_get_exchange(self.h, C.byref(m)))
+        return m.value
+
+    def mur_slice_info(self, dist, world):
+        """(columns of H per rank, f32 elements per rank) of the sliced phase B, or (0, 0) where it is not available."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_mur_slice_info(self.h, int(dist), int(world), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def mur_phase_b_slice(self, dist, lambda_h, min_iter, tol1, tol2, j, c0, c1):
+        self._ck(self.lib.nmfx_mur_phase_b_slice(self.h, int(dist), float(lambda_h), int(min_iter), float(tol1), float(tol2), int(j),
+                                                 int(c0), int(c1)))
+
+    def mur_phase_b_rest(self, dist, c0, c1):
+        self._ck(self.lib.nmfx_mur_phase_b_rest(self.h, int(dist), int(c0), int(c1)))
+
     def comm_graph_replays(self):
         n = C.c_int64()
         self._ck(self.lib.nmfx_comm_graph_replays(self.h, C.byref(n)))

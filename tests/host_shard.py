@@ -447,3 +447,42 @@ class ChunkedHostShard(HostShard):
         g = x[k * n:k * n + k * k].reshape(k, k)
         self.w = self.w_new
         self.h = self.h * b / (g @ self.h + lambda_h * self.h + R.EPS)
+
+
+class SlicedHostShard(ChunkedHostShard):
+    """ChunkedHostShard with the phase B of the reduce-scatter / all-gather exchange (nmfx_mur_slice_info / _phase_b_slice /
+    _phase_b_rest): this rank updates its n / world columns of H from its reduce-scattered range of the [column][factor] buffer,
+    leaves them in that range, and takes the other ranks' columns from theirs after the all-gather."""
+
+    def slice_info(self, kind, world):
+        n, k = self.v.shape[1], self.k
+        if kind != 0 or n % world:
+            return 0, 0
+        self.slices_seen = getattr(self, "slices_seen", [])
+        return n // world, (n // world) * k
+
+    def phase_b_slice(self, kind, lambda_h, min_iter, tol1, tol2, j, c0, c1):
+        assert kind == 0
+        self.slices_seen.append((c0, c1))
+        self._stopped_now = bool(self.flag or self._record(min_iter, tol1, tol2, j))
+        if self._stopped_now:
+            return
+        k, n = self.k, self.v.shape[1]
+        x = self.x32.numpy()
+        b = x[c0 * k:c1 * k].reshape(c1 - c0, k).T
+        g = x[k * n:k * n + k * k].reshape(k, k)
+        self.w = self.w_new
+        h = self.h[:, c0:c1]
+        new = h * b / (g @ h + lambda_h * h + R.EPS)
+        self.h = self.h.copy()
+        self.h[:, c0:c1] = new
+        x[c0 * k:c1 * k] = new.T.ravel()                 # what the all-gather sends
+
+    def phase_b_rest(self, kind, c0, c1):
+        if self._stopped_now:
+            return
+        k, n = self.k, self.v.shape[1]
+        full = self.x32.numpy()[:k * n].reshape(n, k).T
+        keep = self.h[:, c0:c1].copy()
+        self.h = full.copy()
+        self.h[:, c0:c1] = keep

@@ -41,11 +41,16 @@ def _worker(rank, world, rdzv, case, outdir):
         from host_shard import ChunkedHostShard
         os.environ["NMFX_DIST_CHUNKS"] = str(case["chunks"])
         shard = ChunkedHostShard(v[r0:r1], k, w0[r0:r1], h0)
+    elif case.get("exchange"):
+        from host_shard import SlicedHostShard
+        os.environ["NMFX_DIST_EXCHANGE"] = case["exchange"]
+        shard = SlicedHostShard(v[r0:r1], k, w0[r0:r1], h0)
     else:
         shard = HostShard(v[r0:r1], k, w0[r0:r1], h0)
     res = nd.mur_sharded(shard, nd.TorchComm(), batch=case["batch"], **case["kw"])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=res.w, h=res.h, i=res.i,
-             obj=np.asarray(res.obj_history), r0=r0, r1=r1, pieces=len(getattr(shard, "cols_seen", [0])))
+             obj=np.asarray(res.obj_history), r0=r0, r1=r1, pieces=len(getattr(shard, "cols_seen", [0])),
+             slices=np.asarray(sorted(set(getattr(shard, "slices_seen", []))), dtype=np.int64).reshape(-1, 2))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,10 +67,20 @@ CASES = [
          kw=dict(distance_type="eu", min_iter=12, max_iter=12, lambda_w=0.05, lambda_h=0.1)),
     dict(m=131, n=77, k=4, seed=4, batch=16, chunks=2,
          kw=dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-9, tol2=2e-4)),
+    # NMFX_DIST_EXCHANGE=rsag: reduce-scatter of the W^T V part, each rank updates its half of H's columns, all-gather (r5)
+    dict(m=150, n=90, k=5, seed=3, batch=7, exchange="rsag",
+         kw=dict(distance_type="eu", min_iter=12, max_iter=12, lambda_w=0.05, lambda_h=0.1)),
+    dict(m=131, n=80, k=4, seed=4, batch=16, exchange="rsag",     # converges mid-batch: the stop must leave H alone on every rank
+         kw=dict(distance_type="eu", min_iter=5, max_iter=400, tol1=1e-9, tol2=2e-4)),
+    dict(m=96, n=64, k=3, seed=5, batch=5, exchange="rsag",       # KL loss: no sliced form -> every rank takes the all-reduce
+         kw=dict(distance_type="kl", min_iter=9, max_iter=9, lambda_w=0.0, lambda_h=0.02)),
+    dict(m=150, n=91, k=5, seed=3, batch=7, exchange="rsag",      # n not a multiple of the world: all-reduce as well
+         kw=dict(distance_type="eu", min_iter=12, max_iter=12, lambda_w=0.05, lambda_h=0.1)),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=["eu_lambda", "eu_converge", "kl", "eu_lambda_3_chunks", "eu_converge_2_chunks"])
+@pytest.mark.parametrize("case", CASES, ids=["eu_lambda", "eu_converge", "kl", "eu_lambda_3_chunks", "eu_converge_2_chunks",
+                                             "eu_lambda_rsag", "eu_converge_rsag", "kl_rsag_falls_back", "eu_odd_n_rsag_falls_back"])
 def test_sharded_mur_equals_single_process_oracle(case, tmp_path):
     world = 2
     spawn_ranks(_worker, (world, None, case, str(tmp_path)), world)
@@ -80,6 +95,11 @@ def test_sharded_mur_equals_single_process_oracle(case, tmp_path):
     assert [(int(p["r0"]), int(p["r1"])) for p in parts] == [(0, m // 2), (m // 2, m)]
     if case.get("chunks"):
         assert all(int(p["pieces"]) >= 2 for p in parts)          # (the last iteration's phase A came in pieces)
+    if case.get("exchange") == "rsag":
+        sliced = case["kw"]["distance_type"] == "eu" and n % world == 0
+        for r, p in enumerate(parts):                            # each rank updated exactly its own columns -- or none at all
+            assert p["slices"].tolist() == ([[r * n // world, (r + 1) * n // world]] if sliced else [])
+        np.testing.assert_array_equal(parts[0]["h"], parts[1]["h"])      # replicated H bit-identical (each column computed once, copied)
     for p in parts:
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=1e-10)

@@ -69,8 +69,12 @@ def _run_mur_case(nd, Shard, make_comm, rank, world, outdir, tag, k=12, wide=Fal
         return False
     pieces = shard.chunk_ranges(0, nd._exchange_chunks())
     res = nd.mur_sharded(shard, comm, batch=5, **KW)
+    if isinstance(comm, nd.NativeComm):                  # did the iterations take the reduce-scatter / all-gather exchange?
+        sliced = shard.eng.comm_get_exchange() == 1 and shard.eng.mur_slice_info(0, world)[0] > 0
+    else:
+        sliced = nd._slice_plan(shard, comm, 0) is not None
     np.savez(os.path.join(outdir, f"{tag}rank{rank}.npz"), w=res.w, h=res.h, i=res.i, obj=np.asarray(res.obj_history),
-             pieces=len(pieces) if pieces else 1, merged=int(shard.merge_objective()))
+             pieces=len(pieces) if pieces else 1, merged=int(shard.merge_objective()), sliced=int(sliced))
     shard.close()
     return True
 
@@ -96,6 +100,7 @@ def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
 
 MUR_KS = [12, 40, 100, 160]     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128; generic path (k > 128)
 WIDE_KS = [40, 100]
+RSAG_KS = [12, 40, 100]         # (12: exact-f32 epilogues have no sliced phase B -> all-reduce; 40, 100: k padded to 64 / 128)
 SOLVERS = ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "admm",
            "admm_bf16", "admm_kl", "admm_k160", "anls", "anls_k160"]
 BACKENDS = [(1, "nccl"), (2, "gloo"), (1, "native")]
@@ -117,13 +122,17 @@ def _batch_worker(rank, world, rdzv, backend, outdir):
     torch.cuda.set_device(0)
     Shard, make_comm = _join(backend, rdzv, rank, world)
     from nmf_amd import dist as nd
-    jobs = [(f"mur{k}", "mur", k) for k in MUR_KS] + [(f"wide{k}", "wide", k) for k in WIDE_KS] + [(f"solver_{s}", "solver", s) for s in SOLVERS]
+    jobs = [(f"mur{k}", "mur", k) for k in MUR_KS] + [(f"wide{k}", "wide", k) for k in WIDE_KS] + [(f"rsag{k}", "rsag", k) for k in RSAG_KS] + \
+           [(f"solver_{s}", "solver", s) for s in SOLVERS]
     for tag, kind, arg in jobs:
         try:
             os.environ.pop("NMFX_DIST_CHUNKS", None)
+            os.environ.pop("NMFX_DIST_EXCHANGE", None)
             if kind == "wide":
                 os.environ["NMFX_DIST_CHUNKS"] = "2"
-            if kind in ("mur", "wide"):
+            if kind == "rsag":
+                os.environ["NMFX_DIST_EXCHANGE"] = "rsag"
+            if kind in ("mur", "wide", "rsag"):
                 _run_mur_case(nd, Shard, make_comm, rank, world, outdir, tag + ".", arg, kind == "wide")
             else:
                 _run_solver_case(nd, Shard, make_comm, rank, world, outdir, tag + ".", arg)
@@ -132,6 +141,7 @@ def _batch_worker(rank, world, rdzv, backend, outdir):
                 fh.write(traceback.format_exc())
             break
     os.environ.pop("NMFX_DIST_CHUNKS", None)
+    os.environ.pop("NMFX_DIST_EXCHANGE", None)
     try:
         dist.barrier()
         dist.destroy_process_group()
@@ -210,6 +220,34 @@ def test_sharded_device_path_with_a_chunked_exchange(world, backend, k, batch):
         assert int(p["i"]) == ref.i
         np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-5)
         np.testing.assert_array_equal(p["h"], h)
+
+
+@pytest.mark.parametrize("k", RSAG_KS)
+@pytest.mark.parametrize("world,backend", BACKENDS)
+def test_sharded_device_path_with_the_reduce_scatter_all_gather_exchange(world, backend, k, batch):
+    """NMFX_DIST_EXCHANGE=rsag (r5): reduce-scatter of the W^T V part of the exchange buffer, every rank updates ITS
+    columns of H (nmfx_mur_phase_b_slice) and leaves them in its range, all-gather, the other ranks' columns into H and the bf16
+    images (nmfx_mur_phase_b_rest) -- through torch.distributed ("nccl": world of one), staged through the host (two ranks on
+    one GPU) and inside nmfx_mur_run_sharded ("native").  Same bars as the all-reduce; H bit-identical on all ranks; and on this box
+    (world of one: the scatter is a copy; staged: the scatter IS an all-reduce) the very bits of the all-reduce run.  k = 12 runs
+    the exact-f32 epilogues, which have no sliced phase B: every rank takes the all-reduce."""
+    d = batch(world, backend)
+    parts = _parts(d, f"rsag{k}", world)
+    base = _parts(d, f"mur{k}", world)
+    v, ref = _mur_oracle(k, False)
+    assert all(int(p["sliced"]) == (1 if k > 32 else 0) for p in parts), [int(p["sliced"]) for p in parts]
+    assert all(int(p["sliced"]) == 0 for p in base)
+    w = np.concatenate([p["w"] for p in parts])
+    h = parts[0]["h"]
+    err = np.linalg.norm(w @ h - ref.w @ ref.h) / np.linalg.norm(v.astype(np.float64))
+    assert err < 1e-4, err
+    for p, q in zip(parts, base):
+        assert int(p["i"]) == ref.i
+        np.testing.assert_allclose(p["obj"], ref.obj_history, rtol=2e-5)
+        np.testing.assert_array_equal(p["h"], h)
+        np.testing.assert_array_equal(p["h"], q["h"])
+        np.testing.assert_array_equal(p["w"], q["w"])
+        np.testing.assert_array_equal(p["obj"], q["obj"])
 
 
 def test_ranks_agree_on_the_collective_sequence_before_the_first_exchange(tmp_path, monkeypatch):
@@ -297,12 +335,14 @@ def _graph_worker(rank, world, rdzv, outdir, backend="nccl", k=12):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,k", [("nccl", 12), ("native", 12), ("native", 40)])
-def test_graphed_loop_equals_eager_loop(backend, k, tmp_path):
+@pytest.mark.parametrize("backend,k,exchange", [("nccl", 12, None), ("native", 12, None), ("native", 40, None), ("native", 40, "rsag"), ("nccl", 40, "rsag")])
+def test_graphed_loop_equals_eager_loop(backend, k, exchange, tmp_path, monkeypatch):
     """hipGraph replays of the sharded iteration (RCCL all-reduce captured inside) give the very
     same iterates, objective history and stop index as the eager loop -- captured by torch around the phase calls ("nccl") or
     by the library itself inside nmfx_mur_run_sharded ("native": the whole loop is one C call, no torch on the data path)."""
     import torch.multiprocessing as mp
+    if exchange:                                         # (r5: the reduce-scatter . slice . all-gather . rest sequence inside the captured pair)
+        monkeypatch.setenv("NMFX_DIST_EXCHANGE", exchange)
     spawn_ranks(_graph_worker, (1, None, str(tmp_path), backend, k), 1)
     z = np.load(tmp_path / "graph.npz")
     for name in ("stop", "full", "kl"):
