@@ -108,8 +108,10 @@ __device__ __forceinline__ void pinu(uint4& v) { asm volatile("" : "+v"(v.x), "+
 // two floats -> packed bf16 hi pair and lo pair (round to nearest even both times)
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));
+    typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+    const split_f32x2 ab = {a, b}, hh = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const split_f32x2 d = ab - hh;                     // (r5: ONE v_pk_add_f32 with the negation modifiers -- the same two IEEE subtractions)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(d.x), "v"(d.y));
 }
 __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& hi, Frag8& lo) {
     split2(p.x, p.y, hi.u.x, lo.u.x); split2(p.z, p.w, hi.u.y, lo.u.y);
@@ -2614,15 +2616,30 @@ static int sk_plan(nmfx_engine* E, int side) {
     first[workers] = (int)seg.size();
     int maxslab = 1;
     for (int64_t b = 0; b < rb; ++b) maxslab = std::max(maxslab, cnt[b]);
-    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.seg), seg.size() * sizeof(int4)));
-    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.first), first.size() * sizeof(int)));
-    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.cnt), cnt.size() * sizeof(int)));
-    NMFX_HIP(hipMalloc(reinterpret_cast<void**>(&P.slabs), (size_t)maxslab * R * E->kp * sizeof(float)));
-    NMFX_HIP(hipMemcpy(P.seg, seg.data(), seg.size() * sizeof(int4), hipMemcpyHostToDevice));
-    NMFX_HIP(hipMemcpy(P.first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
-    NMFX_HIP(hipMemcpy(P.cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    // validate first, build in locals, publish last: a plan that failed half way must not look finished to the next call (ADVICE r4:
+    // `if (P.seg) return NMFX_OK` would then launch with an oversized nseg or a null slab buffer)
+    if ((int64_t)seg.size() > E->obj_part_cap) { E->err = "stream-K plan: more segments than objective partials"; return NMFX_E_ARG; }
+    int4* d_seg = nullptr; int* d_first = nullptr; int* d_cnt = nullptr; float* d_slabs = nullptr;
+    const bool ok =
+        hipMalloc(reinterpret_cast<void**>(&d_seg), seg.size() * sizeof(int4)) == hipSuccess &&
+        hipMalloc(reinterpret_cast<void**>(&d_first), first.size() * sizeof(int)) == hipSuccess &&
+        hipMalloc(reinterpret_cast<void**>(&d_cnt), cnt.size() * sizeof(int)) == hipSuccess &&
+        hipMalloc(reinterpret_cast<void**>(&d_slabs), (size_t)maxslab * R * E->kp * sizeof(float)) == hipSuccess &&
+        hipMemcpy(d_seg, seg.data(), seg.size() * sizeof(int4), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (d_seg) hipFree(d_seg);
+        if (d_first) hipFree(d_first);
+        if (d_cnt) hipFree(d_cnt);
+        if (d_slabs) hipFree(d_slabs);
+        E->err = "stream-K plan: device allocation or copy failed";
+        return NMFX_E_HIP;
+    }
+    P.first = d_first; P.cnt = d_cnt; P.slabs = d_slabs;
     P.workers = (int)workers; P.nseg = (int)seg.size(); P.maxslab = maxslab;
-    if ((int64_t)P.nseg > E->obj_part_cap) { E->err = "stream-K plan: more segments than objective partials"; return NMFX_E_ARG; }
+    P.seg = d_seg;                                     // (last: what `if (P.seg) return NMFX_OK` looks at)
     return NMFX_OK;
 }
 

@@ -1966,6 +1966,11 @@ int nmfx_generic_aoadmm_phase(nmfx_engine* E, int phase, int prox, double lam, i
     float* xB = E->xf32;
     float* xG = E->xf32 + kp * np;
     bool bf = gxb_on(E);
+    // The bf16 images of W and H are READ by the products of phases 0 and 2 only; phases 1 and 4 rebuild the images of the factor they
+    // have updated.  So they are (re)built from the factors at the head of every outer iteration (phase 0: whatever ran on this handle
+    // before, the images are those of the current pair) and left alone in the other phases -- r4 rebuilt both factors' images in EVERY
+    // phase call, the admm_iter W rounds of phase 3 included.  The planes of V and the buffers are made on first use.
+    if (phase != 0) E->gxb_img_ready = true;
     if (bf) { rc = gxb_prepare(E, W); if (rc == GXB_NOFIT) bf = false; else if (rc) return rc; }
     E->gxb_img_ready = false;
     switch (phase) {

@@ -14,7 +14,11 @@ parameters; the per-combination cost is the initial factors and the iterations o
 
 Order of the runs, keyword names and defaults are those of the legacy driver; each run draws from
 the global numpy RNG exactly as a separate call of the solver would."""
+import contextlib
+import inspect
+import io
 import os
+import sys
 from importlib import import_module
 from itertools import product
 
@@ -86,6 +90,7 @@ def _mur_eu_grid_in_pairs(data, solver, features, lambda_w, lambda_h, save_dir, 
     grid); combinations with k > 64, a combination left over, and engines on the exact-f32 path run as before.  Results, printed
     lines and RNG consumption are those of the sequential grid."""
     from .mur import mur_pair
+    defaults = {name: par.default for name, par in inspect.signature(solver).parameters.items() if par.default is not inspect.Parameter.empty}
     combos = [(k, lw, lh) for k in features for lw, lh in product(lambda_w, lambda_h)]
     out = [None] * len(combos)
     small = [i for i, c in enumerate(combos) if c[0] <= 64]
@@ -114,16 +119,22 @@ def _mur_eu_grid_in_pairs(data, solver, features, lambda_w, lambda_h, save_dir, 
             if big is not None and combos[i][0] <= 64 and nxt < len(combos) and combos[nxt][0] <= 64:
                 a, b = combos[i], combos[nxt]
                 rng_state = np.random.get_state()
-                res = mur_pair(data, a[0], [dict(k=a[0], lambda_w=a[1], lambda_h=a[2]), dict(k=b[0], lambda_w=b[1], lambda_h=b[2])],
-                               engine=big, device=device, **pair_kw)
+                # (the pair's per-iteration lines are held back until it is known that the pair is kept: a pair that is run again singly
+                #  below would otherwise print its lines twice -- ADVICE r4)
+                held = io.StringIO()
+                with contextlib.redirect_stdout(held):
+                    res = mur_pair(data, a[0], [dict(k=a[0], lambda_w=a[1], lambda_h=a[2]), dict(k=b[0], lambda_w=b[1], lambda_h=b[2])],
+                                   engine=big, device=device, **pair_kw)
                 # A pair runs on the plain device rule; single runs referee the rule in float64 once the recorded objective's jitter
                 # is no longer negligible against tol2 (nmf_amd._driver.Referee).  Where that referee would have armed, the pair's
                 # stop index may differ from the sequential grid's: run the two combinations again singly, from the same RNG state
                 # (tight tolerances on large matrices only).
-                tol2 = common.get('tol2', 1e-5)
-                if any(r.i < common.get('max_iter', 100000) - 1 and Referee.would_arm(r.obj_history, tol2) for r in res):
+                tol2 = common.get('tol2', defaults['tol2'])
+                if any(r.i < common.get('max_iter', defaults['max_iter']) - 1 and Referee.would_arm(r.obj_history, tol2) for r in res):
                     np.random.set_state(rng_state)
                     res = [run_single(i), run_single(nxt)]
+                else:
+                    sys.stdout.write(held.getvalue())
                 out[i], out[nxt] = res
                 done_now = (i, nxt)
                 i += 2

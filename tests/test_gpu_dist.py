@@ -335,7 +335,7 @@ def _graph_worker(rank, world, rdzv, outdir, backend="nccl", k=12):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,k,exchange", [("nccl", 12, None), ("native", 12, None), ("native", 40, None), ("native", 40, "rsag"), ("nccl", 40, "rsag")])
+@pytest.mark.parametrize("backend,k,exchange", [("nccl", 12, None), ("native", 12, None), ("native", 40, None), ("nccl", 40, None), ("native", 40, "rsag"), ("nccl", 40, "rsag")])
 def test_graphed_loop_equals_eager_loop(backend, k, exchange, tmp_path, monkeypatch):
     """hipGraph replays of the sharded iteration (RCCL all-reduce captured inside) give the very
     same iterates, objective history and stop index as the eager loop -- captured by torch around the phase calls ("nccl") or
