@@ -108,11 +108,9 @@ __device__ __forceinline__ void pinu(uint4& v) { asm volatile("" : "+v"(v.x), "+
 // two floats -> packed bf16 hi pair and lo pair (round to nearest even both times)
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    typedef float split_f32x2 __attribute__((ext_vector_type(2)));
-    const split_f32x2 ab = {a, b}, hh = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-    const split_f32x2 d = ab - hh;                     // (r5: ONE v_pk_add_f32 with the negation modifiers -- the same two IEEE subtractions)
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(d.x), "v"(d.y));
-}
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));    // (r5: the two subtractions as ONE v_pk_add_f32 -- 6 % fewer VALU
+}                                                                                  //  instructions in the KL loops -- measured no faster, k = 128 1 % slower: not kept)
 __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& hi, Frag8& lo) {
     split2(p.x, p.y, hi.u.x, lo.u.x); split2(p.z, p.w, hi.u.y, lo.u.y);
     split2(q.x, q.y, hi.u.z, lo.u.z); split2(q.z, q.w, hi.u.w, lo.u.w);
