@@ -111,6 +111,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));    // (r5: the two subtractions as ONE v_pk_add_f32 -- 6 % fewer VALU
 }                                                                                  //  instructions in the KL loops -- measured no faster, k = 128 1 % slower: not kept)
+__device__ __forceinline__ void hi8(const float4& p, const float4& q, Frag8& hi) {       // the bf16 image alone (round to nearest even)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.x) : "v"(p.x), "v"(p.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.y) : "v"(p.z), "v"(p.w));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.z) : "v"(q.x), "v"(q.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.w) : "v"(q.z), "v"(q.w));
+}
 __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& hi, Frag8& lo) {
     split2(p.x, p.y, hi.u.x, lo.u.x); split2(p.z, p.w, hi.u.y, lo.u.y);
     split2(q.x, q.y, hi.u.z, lo.u.z); split2(q.z, q.w, hi.u.w, lo.u.w);
@@ -1135,6 +1141,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // per group, the DMA requests in pairs between the MFMAs as in the Euclidean pipeline.  (A second barrier per group that
     // frees the slot of V(g) as soon as every wave holds the tile, with V(g + 3) requested behind it -- three groups in
     // flight instead of two -- measured no faster: W phase 537 vs 524 us, H phase 448 vs 450, tools/lab/ab_phase.py.)
+#ifdef NMFX_EXP_Q1             // experiment (r5): the quotient enters the second product as ONE bf16 image (q_hi Y_hi + q_hi Y_lo):
+                               // config 4 W phase 550 -> 495 us, H phase 466 -> 441 -- and WH against the oracle 5e-7 -> 3.4e-5 .. 6e-5 at contractions of
+                               // 4096 .. 16384, 1.3e-4 at 384 (tools/lab/kl_q1_check.py): half a digit inside north_star's 1e-4.  Not the default, not shipped.
+    constexpr bool Q1 = KL && KP == 64;
+#else
+    constexpr bool Q1 = false;
+#endif
     auto kl_iter = [&](int grp, VRegs& cur, VRegs& prv, auto do_d_t, auto do_a_t) {
         constexpr bool DO_D = decltype(do_d_t)::value, DO_A = decltype(do_a_t)::value;
         const unsigned char* ybuf = smem + ycur * YBUF;                              // Y(grp)
@@ -1210,11 +1223,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 cur.d[4 * a] = q01.x; cur.d[4 * a + 1] = q01.y; cur.d[4 * a + 2] = q23.x; cur.d[4 * a + 3] = q23.y;
             }
         };
+        NMFX_STAMP(ts0);
         if (DO_D) {
             if (yrole) dma_wait_le<0>();               // Y(grp)
             else if (grp + 1 < g1) dma_wait_le<8>();   // V(grp); V(grp + 1) may stay in flight
             else dma_wait_le<0>();
             __syncthreads();
+            NMFX_STAMP(ts1);
             dma_on = !(ABL & 1) && (yrole ? grp + 1 < g1 : grp + 2 < g1);
             f32x16& d = cur.d;
             cur.slow = 0u;
@@ -1243,9 +1258,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 NMFX_FENCE();
             }
         } else {
+            NMFX_STAMP(ts1);
             issue_a(0, 0); issue_a(1, 1);
             NMFX_FENCE();
         }
+        NMFX_STAMP(ts2);
         if (DO_A) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1254,8 +1271,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 NMFX_FENCE();
                 if (DO_D) quot(2 * ks); else if (WITH_OBJ) kl_chunk(2 * ks);
                 NMFX_FENCE();
+                if (!Q1) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vl[ks], fh[ks][t], accA[t]);
+                    for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vl[ks], fh[ks][t], accA[t]);
+                }
                 NMFX_FENCE();
                 if (DO_D) quot(2 * ks + 1); else if (WITH_OBJ) kl_chunk(2 * ks + 1);
                 NMFX_FENCE();
@@ -1266,20 +1285,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                     for (int t = 0; t < 2; ++t) accA[t] = MFMA32X(prv.vl[ks], fl[ks][t], accA[t]);
                 }
                 NMFX_FENCE();
-                if (DO_D) split8(qa[ks][0], qa[ks][1], cur.vh[ks], cur.vl[ks]);
+                if (DO_D) { if (Q1) hi8(qa[ks][0], qa[ks][1], cur.vh[ks]); else split8(qa[ks][0], qa[ks][1], cur.vh[ks], cur.vl[ks]); }
                 NMFX_FENCE();
             }
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) quot(a);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) split8(qa[s2][0], qa[s2][1], cur.vh[s2], cur.vl[s2]);
+            for (int s2 = 0; s2 < 2; ++s2) { if (Q1) hi8(qa[s2][0], qa[s2][1], cur.vh[s2]); else split8(qa[s2][0], qa[s2][1], cur.vh[s2], cur.vl[s2]); }
         }
         if (WITH_OBJ) {
             if (DO_A) olog += (double)klog;
             if (DO_D) osum += (double)(klin2.x + klin2.y);
             asm volatile("" : "+v"(osum), "+v"(olog));
         }
+#ifdef NMFX_EXP_STAMPS                                 // (KL: wait + barrier | first product with the objective terms of the group before | second product with quotient + split)
+        NMFX_STAMP(ts3);
+        acc_wait += ts1 - ts0; acc_head += ts2 - ts1; acc_mfma += ts3 - ts2;
+#endif
         if (DO_D) {
             ycur = (ycur == YR - 1) ? 0 : ycur + 1;
             vcur = (NW == 4) ? vcur + 1 - 3 * (vcur >> 1) : ((vcur == VRING - 1) ? 0 : vcur + 1);

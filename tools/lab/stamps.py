@@ -14,13 +14,15 @@ import numpy as np  # noqa: E402
 from nmf_amd.engine import Engine  # noqa: E402
 from nmf_amd.synth import planted_matrix  # noqa: E402
 
-m, n, k = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (16384, 8192, 64)
+kl = "--kl" in sys.argv          # MUR-KL: segments = wait + barrier | first product (+ objective terms of the group before) | second product (+ quotient, split)
+argv = [a for a in sys.argv if a != "--kl"]
+m, n, k = (int(x) for x in argv[1:4]) if len(argv) > 3 else (16384, 8192, 64)
 v = planted_matrix(m, n, k, seed=0, dtype=np.float32)
 rs = np.random.RandomState(0)
 eng = Engine(m, n, k)
 eng.upload_v(v)
 eng.set_factors(np.abs(rs.randn(m, k)), np.abs(rs.randn(k, n)))
-eng.mur_run(0, 0, 0, 10 ** 12, 1e-5, 1e-5, 0, 600 if k <= 64 else 150)
+eng.mur_run(1 if kl else 0, 0, 0, 10 ** 12, 1e-5, 1e-5, 0, (100 if kl else 600) if k <= 64 else 150)
 eng.synchronize()
 out = np.zeros((2, 256, 8, 6), dtype=np.uint64)
 assert eng.lib.nmfx_debug_stamps(out.ctypes.data_as(C.c_void_p)) == 0
@@ -34,5 +36,7 @@ for kind, name in ((1, "W phase (objective)"), (0, "H phase")):
     for role, ws in (("V loaders (waves 0-3)", slice(0, 4)), ("Y loaders (waves 4-7)", slice(4, 8))):
         seg = np.median(a[:, ws, :4].reshape(-1, 4), axis=0)
         groups = (n // 64) / max(1, round(256 / (m // 128)))     # groups per block: the contraction over the splits that fill 256 CUs
-        print("   %-22s wait+barrier %6.0f  head (LDS reads + split) %6.0f  early barrier %6.0f  MFMA stages %6.0f  | per group (%d groups): %s"
-              % (role, *seg, groups, np.round(seg / groups, 0)))
+        labels = ("wait+barrier", "first product (+ objective)", "-", "second product (+ quotient, split)") if kl else \
+            ("wait+barrier", "head (LDS reads + split)", "early barrier", "MFMA stages")
+        print("   %-22s %s %6.0f  %s %6.0f  %s %6.0f  %s %6.0f  | per group (%d groups): %s"
+              % (role, labels[0], seg[0], labels[1], seg[1], labels[2], seg[2], labels[3], seg[3], groups, np.round(seg / groups, 0)))
