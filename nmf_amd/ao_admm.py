@@ -10,11 +10,12 @@ is evaluated on the device too.
 Regularisers: 'nn' and 'l1n' are built (any number of components, both losses).  'l2n' raises
 ValueError exactly like the reference does on numpy >= 1.24 (ao_admm.py:128 builds a ragged array; it is also the reference's
 DEFAULT reg_h, so callers must pass reg_h explicitly).  'l1inf' / 'l1inf_transpose' (nmf/ao_admm.py:143-195, word for word the
-operator of nmf/admm.py:158-210) run on the device with the least-squares loss and at most 128 components (r4): in the reference
-they wipe a factor out within a few outer iterations -- W = 0 after the first one as `reg_w`, H = 0 inside the first one as
-`reg_h` -- and the next Cholesky factorisation raises numpy.linalg.LinAlgError; here the same pivot test (NMFX_E_NOTPD) raises the
-same exception in the same outer iteration, and a run whose `max_iter` ends before it returns the reference's Results
-(tests/golden/ao_admm_l1inf_*.npz).  With the KL loss or beyond 128 components they still raise that exception up front."""
+operator of nmf/admm.py:158-210) run on the device with either loss and at most 128 components (r4: least squares; r5: KL): in the
+reference they wipe a factor out within a few outer iterations -- least squares: W = 0 after the first one as `reg_w`, H = 0 inside
+the first one as `reg_h`; KL: after one to four -- and the next Cholesky factorisation raises numpy.linalg.LinAlgError; here the
+same pivot test (NMFX_E_NOTPD) raises the same exception in the same outer iteration, and a run whose `max_iter` ends before it
+returns the reference's Results (tests/golden/aoadmm_{eu,kl}_*_l1inf*.npz).  Beyond 128 components they still raise that exception
+up front."""
 from collections import namedtuple
 
 import numpy as np
@@ -53,7 +54,7 @@ def ao_admm(v, k, *, distance_type='eu', reg_w=(0, 'nn'), reg_h=(0, 'l2n'), min_
     dist = L.EU if distance_type == 'eu' else L.KL
     init = utils.initial_factors(v, k, nndsvd_init, defer_device=True)
     # the reference meets the H regulariser first (ao_admm.py:261), then W's
-    on_device = distance_type == 'eu' and k <= 128
+    on_device = k <= 128
     prox_h = _prox_code(reg_h[1], on_device)
     prox_w = _prox_code(reg_w[1], on_device)
 

@@ -1805,25 +1805,33 @@ __global__ __launch_bounds__(256) void ao_l1inf_norms_kernel(
     block_store_norms<4>(n0, n1, n2, n3, nrm + ((int64_t)(round & 1) * gridDim.x + blockIdx.x) * 4, sh);
 }
 
-static int ao_l1inf_subproblem(nmfx_engine* E, bool cols, int prox, double lam, int admm_iter, int32_t* slot) {
+// One inner round with prox 'l1inf' / 'l1inf_transpose' (nmf/ao_admm.py:143-195): the "solve only" mode of the round kernel (aux), the
+// operator on (aux, dual) -> X, dual, and the four norm sums of the round -- for either loss: the right-hand side (xf32 / Asum) is
+// whatever the caller's products left (least squares: W^T V, once per sub-problem; KL: W^T (v_aux + dual_v), every round)
+static int ao_l1inf_round(nmfx_engine* E, bool cols, int prox, double lam, int r) {
     int rc;
-    if ((rc = nmfx_admm_state_alloc(E))) return rc;     // auxH / Asum: the aux matrices of the "solve only" rounds
-    if ((rc = ao_fused_alloc(E, admm_iter))) return rc; // bkX: X_prev
     const int nblk = (int)((cols ? E->np : E->mp) / 64);
     const int64_t count = cols ? (int64_t)E->kp * E->np : E->mp * (int64_t)E->kp;
     float* X = cols ? E->H : E->W[0];
     float* U = cols ? E->dualH : E->dualW;
     float* aux = cols ? E->auxH : E->auxW;
-    for (int r = 0; r < admm_iter; ++r) {
-        if (cols) rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox, (float)lam, r);
-        else rc = nmfx_inner_rows(E, E->Asum, E->W[0], E->Minv, E->auxW, 1, prox, (float)lam, r);
-        if (rc) return rc;
-        NMFX_HIP(hipMemcpyAsync(E->bkX, X, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, E->stream));
-        if ((rc = nmfx_launch_prox_l1inf(E, cols, prox == NMFX_PROX_L1INF_T, -1.0, lam, 1.0, true, true))) return rc;
-        hipLaunchKernelGGL(ao_l1inf_norms_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, X, E->bkX, aux, U, count, r,
-                           E->state, E->nrm_part);
-        NMFX_HIP(hipGetLastError());
-    }
+    if (cols) rc = nmfx_inner_cols(E, E->Minv, E->auxH, 1, prox, (float)lam, r);
+    else rc = nmfx_inner_rows(E, E->Asum, E->W[0], E->Minv, E->auxW, 1, prox, (float)lam, r);
+    if (rc) return rc;
+    NMFX_HIP(hipMemcpyAsync(E->bkX, X, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, E->stream));
+    if ((rc = nmfx_launch_prox_l1inf(E, cols, prox == NMFX_PROX_L1INF_T, -1.0, lam, 1.0, true, true))) return rc;
+    hipLaunchKernelGGL(ao_l1inf_norms_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, X, E->bkX, aux, U, count, r,
+                       E->state, E->nrm_part);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static int ao_l1inf_subproblem(nmfx_engine* E, bool cols, int prox, double lam, int admm_iter, int32_t* slot) {
+    int rc;
+    if ((rc = nmfx_admm_state_alloc(E))) return rc;     // auxH / Asum: the aux matrices of the "solve only" rounds
+    if ((rc = ao_fused_alloc(E, admm_iter))) return rc; // bkX: X_prev
+    const int nblk = (int)((cols ? E->np : E->mp) / 64);
+    for (int r = 0; r < admm_iter; ++r) if ((rc = ao_l1inf_round(E, cols, prox, lam, r))) return rc;
     return nmfx_inner_finish(E, nblk, admm_iter, slot);
 }
 static bool ao_is_l1inf(int prox) { return prox == NMFX_PROX_L1INF || prox == NMFX_PROX_L1INF_T; }
@@ -1952,7 +1960,9 @@ static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
             if ((rc = nmfx_launch_hphase(E, W, false, E->S, stop))) return rc;
             if ((rc = nmfx_launch_pack(E, stop))) return rc;
         }
-        if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, r))) return rc;
+        if (ao_is_l1inf(prox_h)) rc = ao_l1inf_round(E, true, prox_h, lam_h, r);      // (r5: the reference runs these too, until its Cholesky fails)
+        else rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, r);
+        if (rc) return rc;
         if ((rc = nmfx_launch_kl_vaux(E, W, E->auxH, stop))) return rc;
     }
     if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
@@ -1963,7 +1973,9 @@ static int aoadmm_kl_iteration(nmfx_engine* E, int prox_w, double lam_w, int pro
     for (int r = 0; r < admm_iter; ++r) {
         if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->H, E->S, stop))) return rc;
         if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->wsplit, E->mp * E->kp, E->Asum))) return rc;
-        if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, r))) return rc;
+        if (ao_is_l1inf(prox_w)) rc = ao_l1inf_round(E, false, prox_w, lam_w, r);
+        else rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, r);
+        if (rc) return rc;
         if ((rc = nmfx_launch_kl_vaux(E, E->auxW, E->H, stop))) return rc;
     }
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
@@ -2049,8 +2061,9 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
     if (distance != NMFX_EU && distance != NMFX_KL) { E->err = "Unknown loss function type."; return NMFX_E_ARG; }
     auto known = [](int p) { return p == NMFX_PROX_NN || p == NMFX_PROX_L1N || p == NMFX_PROX_L1INF || p == NMFX_PROX_L1INF_T; };
     if (!known(prox_w) || !known(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
-    if ((ao_is_l1inf(prox_w) || ao_is_l1inf(prox_h)) && (distance != NMFX_EU || E->kp > 128)) {
-        E->err = "ao_admm with prox 'l1inf' / 'l1inf_transpose': least-squares loss and at most 128 components in this build"; return NMFX_E_ARG; }
+    const bool any_l1inf = ao_is_l1inf(prox_w) || ao_is_l1inf(prox_h);
+    if (any_l1inf && E->kp > 128) {
+        E->err = "ao_admm with prox 'l1inf' / 'l1inf_transpose': at most 128 components in this build"; return NMFX_E_ARG; }
     if (first < 0 || count < 0 || admm_iter < 0) { E->err = "negative range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     E->anls_a_ready = false; E->kl_h_iter = -2;
@@ -2067,17 +2080,24 @@ extern "C" int nmfx_aoadmm_run(nmfx_handle_t E, int distance, int prox_w, double
             ? nmfx_generic_aoadmm_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count)
             : nmfx_generic_aoadmm_kl_run(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, first, count);
     if (distance != NMFX_EU) { E->lazy_objective = false; E->himg_both = false; }
-    if (distance == NMFX_KL && ao_kl_bf16(E) && (first == 0 || E->obj_count <= 0)) E->wimg_ok = false;
+    // (KL loss with 'l1inf*': the exact-f32 launches -- the operator's rounds read the f32 right-hand sides those leave; the runs
+    //  end after a few outer iterations anyway, in the reference's LinAlgError)
+    const bool kl_bf = distance == NMFX_KL && ao_kl_bf16(E) && !any_l1inf;
+    if (distance == NMFX_KL && any_l1inf) {
+        if ((rc = nmfx_admm_state_alloc(E))) return rc;     // auxH / Asum of the "solve only" rounds
+        if ((rc = ao_fused_alloc(E, admm_iter))) return rc; // bkX: X_prev
+    }
+    if (kl_bf && (first == 0 || E->obj_count <= 0)) E->wimg_ok = false;
     if (first == 0 && count > 0 && !(distance == NMFX_EU && ao_bf16(E))) {   // obj[0] of the initial factors (ao_admm.py:256)
-        if (distance == NMFX_KL && ao_kl_bf16(E)) rc = ao_kl_objective(E);
+        if (kl_bf) rc = ao_kl_objective(E);
         else rc = nmfx_launch_wphase(E, E->W[0], false, true, distance == NMFX_KL);
         if (rc) return rc;
     }
     for (int64_t j = first; j < first + count; ++j) {
         rc = distance == NMFX_EU
             ? aoadmm_eu_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
-            : ao_kl_bf16(E) ? aoadmm_kl_iteration_bf16(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
-                            : aoadmm_kl_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
+            : kl_bf ? aoadmm_kl_iteration_bf16(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j)
+                    : aoadmm_kl_iteration(E, prox_w, lambda_w, prox_h, lambda_h, admm_iter, min_iter, tol1, tol2, j);
         if (rc) return rc;
     }
     return NMFX_OK;

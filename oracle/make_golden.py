@@ -291,29 +291,33 @@ def main():
     # and `raises_at` = the max_iter at which it raises (-1: it does not within 6).
     L = dict(kind="planted", rank=6, seed=21, m=96, n=80)
     raises = {}
-    for tag, reg_w, reg_h in (("w_l1inf", (0.1, "l1inf"), (0, "nn")), ("w_l1inf_t", (0.1, "l1inf_transpose"), (0, "nn")),
-                              ("h_l1inf", (0, "nn"), (0.1, "l1inf")), ("h_l1inf_t", (0, "nn"), (0.1, "l1inf_transpose"))):
-        name = "aoadmm_eu_" + tag
-        if ONLY and name not in ONLY:
-            continue
-        last_ok, raises_at = 0, -1
-        for mx in range(1, 7):
-            kw = dict(distance_type="eu", reg_w=reg_w, reg_h=reg_h, min_iter=mx, max_iter=mx, admm_iter=10)
-            try:
-                run_solver("ao_admm", make_v(L), 6, 22, kw)
-                last_ok = mx
-            except np.linalg.LinAlgError:
-                raises_at = mx
-                break
-        raises[tag] = raises_at
-        if last_ok:
-            solver_case(name, "ao_admm", L, 6, 22,
-                        dict(distance_type="eu", reg_w=reg_w, reg_h=reg_h, min_iter=last_ok, max_iter=last_ok, admm_iter=10),
-                        snaps=(), extra=dict(raises_at=np.int64(raises_at)))
-        else:
-            print(f"{name:34s} raises LinAlgError in its first outer iteration (no fixture)")
+    for loss in ("eu", "kl"):                            # (r5: the KL loss as well -- admm_kl_update applies the same operator, ao_admm.py:71-101)
+        for tag, reg_w, reg_h in (("w_l1inf", (0.1, "l1inf"), (0, "nn")), ("w_l1inf_t", (0.1, "l1inf_transpose"), (0, "nn")),
+                                  ("h_l1inf", (0, "nn"), (0.1, "l1inf")), ("h_l1inf_t", (0, "nn"), (0.1, "l1inf_transpose"))):
+            name = f"aoadmm_{loss}_" + tag
+            if ONLY and name not in ONLY:
+                continue
+            last_ok, raises_at = 0, -1
+            for mx in range(1, 7):
+                kw = dict(distance_type=loss, reg_w=reg_w, reg_h=reg_h, min_iter=mx, max_iter=mx, admm_iter=10)
+                try:
+                    with np.errstate(all="ignore"):
+                        run_solver("ao_admm", make_v(L), 6, 22, kw)
+                    last_ok = mx
+                except np.linalg.LinAlgError:
+                    raises_at = mx
+                    break
+            raises[(loss, tag)] = raises_at
+            if last_ok:
+                with np.errstate(all="ignore"):
+                    solver_case(name, "ao_admm", L, 6, 22,
+                                dict(distance_type=loss, reg_w=reg_w, reg_h=reg_h, min_iter=last_ok, max_iter=last_ok, admm_iter=10),
+                                snaps=(), extra=dict(raises_at=np.int64(raises_at)))
+            else:
+                print(f"{name:34s} raises LinAlgError in its first outer iteration (no fixture)")
     if raises and not ONLY:
-        assert raises["h_l1inf"] == 1, raises        # (tests/test_gpu_aoadmm.py relies on it: no fixture for this placement)
+        assert raises[("eu", "h_l1inf")] == 1, raises        # (tests/test_gpu_aoadmm.py relies on it: no fixture for this placement)
+    print("l1inf raises_at:", raises)
     # ---- ADMM ----
     D = dict(kind="planted", rank=8, seed=15, m=128, n=96)
     solver_case("admm_eu_nn", "admm", D, 8, 16,

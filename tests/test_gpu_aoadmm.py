@@ -54,7 +54,8 @@ def test_aoadmm_error_behaviour():
             U.initial_factors = orig
 
 
-@pytest.mark.parametrize("name", ["aoadmm_eu_w_l1inf", "aoadmm_eu_w_l1inf_t", "aoadmm_eu_h_l1inf_t"])
+@pytest.mark.parametrize("name", ["aoadmm_eu_w_l1inf", "aoadmm_eu_w_l1inf_t", "aoadmm_eu_h_l1inf_t",
+                                  "aoadmm_kl_w_l1inf", "aoadmm_kl_w_l1inf_t", "aoadmm_kl_h_l1inf", "aoadmm_kl_h_l1inf_t"])      # (r5: the KL loss too)
 def test_aoadmm_l1inf_runs_like_the_reference_until_its_cholesky_fails(name):
     """SURVEY a12 (nmf/ao_admm.py:143-195): with 'l1inf' / 'l1inf_transpose' the reference completes 0-2 outer iterations -- the
     operator wipes a factor out -- and then raises scipy's LinAlgError in the next Cholesky factorisation.  The fixtures are the
