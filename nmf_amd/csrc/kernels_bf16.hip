@@ -932,7 +932,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             d = MFMA32X(fh[1][ss], zh[WITH_D ? 2 + ss : 0], d);
+#ifndef NMFX_EXP_R2
             d = MFMA32X(fl[1][ss], zh[WITH_D ? 2 + ss : 0], d);
+#endif
             if (ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(0); NMFX_FENCE(); }
             d = MFMA32X(fh[1][ss], zl[WITH_D ? 2 + ss : 0], d);
         }
@@ -1037,7 +1039,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 for (int ss = 0; ss < 2; ++ss) {
                     const int s = WITH_D ? 2 * (st - NA) + ss : 0;
                     d = MFMA32X(fh[set][ss], zh[s], d);
+#ifndef NMFX_EXP_R2            // experiment (r5): the residual product with TWO terms (Y_lo Z_hi dropped): W phase -11 % (k = 128), -8 % (k = 64);
+                               // recorded objective +1.2e-5 .. +4.3e-4 off nmfx_objective_f64 (three terms: 1.6e-8), jitter 1.5e-6 (7e-9): not shipped, LAB_NOTES R5
                     d = MFMA32X(fl[set][ss], zh[s], d);
+#endif
                     if (PIPE && ss == 0) { NMFX_FENCE(); if (dma_on) dma_step(st + 1); NMFX_FENCE(); }
                     d = MFMA32X(fh[set][ss], zl[s], d);
                 }
