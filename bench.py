@@ -247,7 +247,7 @@ def make_sharded(torch, dist, nd, rank, world, local_rank, build):
                            break_native=os.environ.get("NMFX_BENCH_BREAK_NATIVE") == "1")
 
 
-def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
+def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2, progress=None):
     """BASELINE.json's config 5 as it is meant: MUR Euclidean, V = 131072 x 16384 f32, k = 128, rows of V and W sharded over
     the `world` GPUs, one RCCL all-reduce of [W^T V | W^T W | objective] per iteration (nmf_amd.dist.run_iterations).  The same
     global matrix as other_configs' cfg5_on_1_gpu (device_planted draws any row range of it), so that
@@ -290,7 +290,24 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
     if os.environ.get("NMFX_DIST_CHUNKS") or os.environ.get("NMFX_DIST_EXCHANGE"):
         forms = [(nd.exchange_mode(), max(1, int(os.environ.get("NMFX_DIST_CHUNKS", "1") or 1)))]
     saved_env = {key: os.environ.get(key) for key in ("NMFX_DIST_CHUNKS", "NMFX_DIST_EXCHANGE", "NMFX_DIST_NATIVE")}
-    times, names, slot = {}, {}, None
+    times, slot = {}, None
+    flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
+    nbytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4
+
+    def result():
+        dt, obj = slot["dt"], slot["obj"]
+        return {"config": "cfg5", "workload": f"MUR Euclidean, V={m}x{n} f32 row-sharded over {world} GPU(s), k={k}, |randn| start, objective every "
+                                              "iteration; exchange per iteration = the fastest of the forms timed (see `exchange`)",
+                "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
+                "precision": slot["precision"], "loop": slot["loop"], "objective_first_last": [float(obj[0]), float(obj[-1])],
+                "exchange": slot["key"],
+                "ms_per_step_by_exchange": {key: (v * 1e3 if isinstance(v, float) else v) for key, v in times.items()},
+                "objective_decreasing": True, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
+                "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
+                "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
+                "all_reduce_bytes": slot["ar_bytes"], "collectives_per_iteration": slot["collectives"],
+                "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
     try:
         for kind in loops:
             os.environ["NMFX_DIST_NATIVE"] = "1" if kind == "native" else "0"
@@ -349,6 +366,8 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
                     os.environ["NMFX_DIST_EXCHANGE"] = mode
                     os.environ["NMFX_DIST_CHUNKS"] = str(nch)
                     key = f"{kind}/{mode}" + (f"/{nch} chunks" if nch > 1 else "")
+                    if progress is not None:
+                        progress["running"] = key          # (what a deadline that expires would name)
                     try:
                         dt, obj, ok, rmode = timed()
                     except Exception as e:  # noqa: BLE001  (every rank runs the same sequence: a failure here is the same on all of them)
@@ -359,6 +378,8 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
                         slot = {"dt": dt, "key": key, "obj": obj, "loop": loop + " / " + rmode, "precision": shard.eng.precision(),
                                 "ar_bytes": float(shard.xf32.numel() * 4 if shard.merge_objective() else shard.xf32.numel() * 4 + 64),
                                 "collectives": (1 if shard.merge_objective() else 2) if mode == "allreduce" else 2}
+                    if progress is not None and slot is not None:
+                        progress["result"] = result()      # (the best of the forms that have run so far)
             finally:
                 if isinstance(comm, nd.NativeComm):
                     try:
@@ -376,21 +397,7 @@ def cfg5_sharded(torch, dist, nd, rank, world, local_rank, steps=5, warmup=2):
                 os.environ[key] = val
     if slot is None:
         raise RuntimeError(f"no form of the sharded loop ran: {times}")
-    dt, obj = slot["dt"], slot["obj"]
-    flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
-    nbytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4
-    return {"config": "cfg5", "workload": f"MUR Euclidean, V={m}x{n} f32 row-sharded over {world} GPU(s), k={k}, |randn| start, objective every "
-                                          "iteration; exchange per iteration = the fastest of the forms timed (see `exchange`)",
-            "n_gpus": world, "rows_per_gpu": r1 - r0, "iter_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
-            "warmup": warmup, "scaling": "strong (base: other_configs.cfg5_on_1_gpu of the --gpus 1 line, the same matrix)",
-            "precision": slot["precision"], "loop": slot["loop"], "objective_first_last": [float(obj[0]), float(obj[-1])],
-            "exchange": slot["key"],
-            "ms_per_step_by_exchange": {key: (v * 1e3 if isinstance(v, float) else v) for key, v in times.items()},
-            "objective_decreasing": True, "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
-            "tflops": flops / dt / 1e12, "hbm_gbs_per_gpu": nbytes / dt / 1e9 / world,
-            "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS / world,
-            "all_reduce_bytes": slot["ar_bytes"], "collectives_per_iteration": slot["collectives"],
-            "data": "synthetic, drawn on the device (torch generator, seed 0; each rank its own rows of the same matrix)"}
+    return result()
 
 
 def scaling_model(torch, dev, base_ms):
@@ -824,6 +831,38 @@ def emit(detail, json_fd):
     os.write(json_fd, (json.dumps(headline(detail)) + "\n").encode())
 
 
+class Deadline:
+    """The config-5 leg of an N > 1 run times forms of the exchange that no multi-GPU box has run before this line is printed (RCCL
+    behind the C ABI with more than one rank, reduce-scatter + all-gather).  A collective that never completes on some rank would take
+    the WHOLE line with it -- the strong-scaling figure of config 2 included -- so the leg runs under a deadline: when it expires,
+    rank 0 prints the line with the forms that HAVE run (naming the one that did not come back) and every rank leaves with exit code
+    0.  A watchdog thread, because a rank stuck inside a C call never returns to the interpreter for a signal handler."""
+
+    def __init__(self, seconds, rank, on_expiry):
+        import threading
+        self.done = threading.Event()
+        self.seconds, self.rank, self.on_expiry = seconds, rank, on_expiry
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+
+    def start(self):
+        self.thread.start()
+        return self
+
+    def cancel(self):
+        self.done.set()
+
+    def _watch(self):
+        if self.done.wait(self.seconds + (0.0 if self.rank == 0 else 5.0)):      # (rank 0 prints first)
+            return
+        try:
+            if self.rank == 0:
+                self.on_expiry()
+        finally:
+            sys.stderr.write(f"bench.py: rank {self.rank}: the config-5 leg did not come back within {self.seconds:.0f} s -- leaving\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torchrun: become the launcher.  Nothing has touched the GPU yet (torch is
     not even imported), so starting `python -m torch.distributed.run ... bench.py <same arguments>` as a child process is safe; its
@@ -1066,14 +1105,61 @@ def main():
         w_g, h_g = eng.get_factors()
         par_gpu = (w_g, h_g, eng.objectives(0, p_it + 1))
 
+    loop_name = (loop + " / " + run.mode) if sharded else "library"
+
+    def build_line(others, smodel, roof, cpu, parity, ttt):
+        ms = dt / args.steps * 1e3
+        iter_flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
+        iter_bytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4           # SURVEY 8d: V once per phase, W and H read + write
+        return {
+            "metric": "NMF outer iterations/sec (MUR-eu, V=16384x8192 f32, k=64)",
+            "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "preheat_iterations": args.preheat,
+            "strong_scaling_quoted_on": ("`value` = config 2 (V=16384x8192, k=64), the fixed matrix row-sharded over n_gpus ranks: a 0.22 ms "
+                                         "iteration on one GPU, so its curve is bound by launch + all-reduce latency, not bandwidth.  The "
+                                         "bandwidth-bound strong-scaling figure (north_star's >= 6x at 8 GPUs) is config 5 (V=131072x16384, "
+                                         "k=128): other_configs[config == 'cfg5'].iter_per_s of the N-GPU line over "
+                                         "other_configs[config == 'cfg5_on_1_gpu'] of the N = 1 line (same matrix)"),
+            "dtype": "bf16 hi+lo split MFMA (3 terms), f32 accumulate, f64 objective" if precision == "bf16" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
+                                   "|randn| init, objective every iteration",
+                       "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}",
+                       "loop": loop_name},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "time_to_tol": ttt,
+            "iteration": {"algorithmic_gflop": iter_flops / 1e9,
+                          "algorithmic_gbytes": iter_bytes / 1e9,
+                          "tflops": iter_flops / (dt / args.steps) / 1e12,
+                          "hbm_gbs": iter_bytes / (dt / args.steps) / 1e9,
+                          "frac_of_hbm_peak": iter_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS / world},
+            "kernels": prof,
+            "other_configs": others,
+            "scaling_model": smodel,
+        }
+
     others = None
     if sharded and not args.no_others and ((m, n, k) == (M, N, K) or os.environ.get("NMFX_BENCH_CFG5_SHAPE")):
         # config 5 proper (the 8-GPU config of BASELINE.json), sharded over this run's ranks: every rank takes part
         eng.close()
+        progress = {}
+
+        def expired():
+            leg = dict(progress.get("result") or {"config": "cfg5"})
+            leg["timed_out_in"] = progress.get("running", "set-up")
+            if "iter_per_s" not in leg:
+                leg["error"] = f"the config-5 leg did not come back (in {leg['timed_out_in']})"
+            emit(build_line([leg], None, roof, None, None, ttt), json_fd)
+
+        guard = Deadline(float(os.environ.get("NMFX_BENCH_CFG5_DEADLINE", "240")), rank, expired).start()
         try:
-            others = [cfg5_sharded(torch, dist, nd, rank, world, local_rank)]
+            others = [cfg5_sharded(torch, dist, nd, rank, world, local_rank, progress=progress)]
         except Exception as e:  # noqa: BLE001  (reported in its slot, never hidden; a rank that failed alone would hang the others'
-            others = [{"config": "cfg5", "error": f"{type(e).__name__}: {e}"}]          # collectives -- the driver's timeout ends that)
+            others = [{"config": "cfg5", "error": f"{type(e).__name__}: {e}"}]          # collectives -- the deadline above ends that)
+        guard.cancel()
     smodel = None
     if rank == 0 and world == 1 and not sharded and not args.no_others and (m, n, k) == (M, N, K):
         eng.close()               # free the HBM: config 5 on one GPU holds three 8 GiB copies of V
@@ -1103,39 +1189,7 @@ def main():
                          f"BLAS pool of {HOST_THREADS} threads = the container's CPU quota (os.cpu_count() = {os.cpu_count()})"}
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        iter_flops = 4.0 * m * n * k + 4.0 * k * k * (m + n)
-        iter_bytes = 2.0 * m * n * 4 + 3.0 * (m + n) * k * 4           # SURVEY 8d: V once per phase, W and H read + write
-        line = {
-            "metric": "NMF outer iterations/sec (MUR-eu, V=16384x8192 f32, k=64)",
-            "value": args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "preheat_iterations": args.preheat,
-            "strong_scaling_quoted_on": ("`value` = config 2 (V=16384x8192, k=64), the fixed matrix row-sharded over n_gpus ranks: a 0.22 ms "
-                                         "iteration on one GPU, so its curve is bound by launch + all-reduce latency, not bandwidth.  The "
-                                         "bandwidth-bound strong-scaling figure (north_star's >= 6x at 8 GPUs) is config 5 (V=131072x16384, "
-                                         "k=128): other_configs[config == 'cfg5'].iter_per_s of the N-GPU line over "
-                                         "other_configs[config == 'cfg5_on_1_gpu'] of the N = 1 line (same matrix)"),
-            "dtype": "bf16 hi+lo split MFMA (3 terms), f32 accumulate, f64 objective" if precision == "bf16" else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"MUR Euclidean, V={m}x{n} float32, k={k}, planted low-rank + 1% noise, "
-                                   "|randn| init, objective every iteration",
-                       "rows_per_gpu": (m + world - 1) // world, "parallelism": f"row-shard x{world}",
-                       "loop": (loop + " / " + run.mode if sharded else "library")},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "parity": parity,
-            "time_to_tol": ttt,
-            "iteration": {"algorithmic_gflop": iter_flops / 1e9,
-                          "algorithmic_gbytes": iter_bytes / 1e9,
-                          "tflops": iter_flops / (dt / args.steps) / 1e12,
-                          "hbm_gbs": iter_bytes / (dt / args.steps) / 1e9,
-                          "frac_of_hbm_peak": iter_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS / world},
-            "kernels": prof,
-            "other_configs": others,
-            "scaling_model": smodel,
-        }
-        emit(line, json_fd)
+        emit(build_line(others, smodel, roof, cpu, parity, ttt), json_fd)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -561,7 +561,7 @@ def test_factorize_takes_the_native_exchange_only_on_request_and_falls_back_toge
     np.testing.assert_array_equal(z["torch_obj"], z["broken_obj"])
 
 
-@pytest.mark.parametrize("launch", ["torchrun", "self"])
+@pytest.mark.parametrize("launch", ["torchrun", "self", "deadline"])
 def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch, tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) and as a plain
     `python bench.py --gpus 2` (no WORLD_SIZE: bench.py starts torch.distributed.run itself, as a child, before anything touches the
@@ -577,8 +577,10 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch, tmp_path):
         env.pop(key, None)
     tail = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0", "--profile-steps", "2", "--no-cpu", "--no-traffic",
             "--tol-max-iter", "0"]
-    for _ in range(1 if launch == "self" else 4):        # (torchrun binds the port probed here a moment later; bench.py's own launch handles that itself)
-        head = [sys.executable] if launch == "self" else \
+    if launch == "deadline":                             # (r5) the config-5 leg "never comes back": the line is printed without it, exit code 0
+        env["NMFX_BENCH_CFG5_DEADLINE"] = "0.01"
+    for _ in range(1 if launch != "torchrun" else 4):    # (torchrun binds the port probed here a moment later; bench.py's own launch handles that itself)
+        head = [sys.executable] if launch != "torchrun" else \
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", str(_free_port())]
         p = subprocess.run(head + [os.path.join(root, "bench.py")] + tail, env=env, cwd=root, capture_output=True, text=True, timeout=600)
@@ -591,6 +593,9 @@ def test_bench_two_ranks_on_one_gpu_runs_both_sharded_legs(launch, tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["rows_per_gpu"] == 512
     assert len(lines[0]) < 4096                          # (the compact headline: the full record is in the detail file)
+    if launch == "deadline":
+        assert "error" in line["cfg5"] and "did not come back" in line["cfg5"]["error"], line
+        return
     assert line["cfg5"]["n_gpus"] == 2 and line["cfg5"]["iter_per_s"] > 0, line
     detail = json.loads((tmp_path / "detail.json").read_text())
     assert "strong_scaling_quoted_on" in detail and detail["value"] == line["value"]
