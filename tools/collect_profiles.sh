@@ -8,9 +8,10 @@ export TMPDIR=/tmp
 out=gpurun_out/profiles_$tag
 rm -rf "$out"; mkdir -p "$out"
 # 1. the bench line as the driver runs it (no profiler attached)
-python3 bench.py --steps 20 --warmup 5 > "$out/bench_n1.json" 2> "$out/bench_n1.err" || { tail -5 "$out/bench_n1.err"; exit 1; }
+NMFX_BENCH_DETAIL="$out/bench_n1_detail.json" python3 bench.py --steps 20 --warmup 5 > "$out/bench_n1.json" 2> "$out/bench_n1.err" || { tail -5 "$out/bench_n1.err"; exit 1; }
+grep -v "^bench_detail: " "$out/bench_n1.err" > "$out/bench_n1.err.tmp"; mv "$out/bench_n1.err.tmp" "$out/bench_n1.err"      # (the full record is in bench_n1_detail.json)
 # 2. kernel trace of the same command (CPU leg and PMC children off: they are not kernels of the product)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --no-cpu --no-traffic --steps 200 --warmup 5 \
+NMFX_BENCH_DETAIL="$out/bench_under_rocprof_detail.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --no-cpu --no-traffic --steps 200 --warmup 5 \
     > "$out/bench_under_rocprof.json" 2> "$out/trace.err" || { tail -5 "$out/trace.err"; exit 1; }
 find "$out/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
 rm -rf "$out/trace"
