@@ -2180,15 +2180,33 @@ extern "C" int nmfx_aoadmm_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t
 // After the inner stop has fired the remaining rounds are no-ops on every rank (the decision is taken from replicated /
 // all-reduced numbers), their exchanges move stale buffers that nothing reads.
 static int ao_kl_sharded_ready(nmfx_engine* E, int64_t j) {
+    if (E && E->kp > 128) {                            // r5: beyond 128 components the phases are composed from the generic kernels (any k the handle takes)
+        if (!E->have_v || !E->have_f) { E->err = "upload V and set factors first"; return NMFX_E_STATE; }
+        if (j < 0) { E->err = "negative iteration index"; return NMFX_E_ARG; }
+        NMFX_HIP(hipSetDevice(E->device));
+        E->anls_a_ready = false; E->kl_h_iter = -2;
+        E->wimg_ok = false; E->ao_images = false;
+        int rc;
+        if ((rc = nmfx_enter_family(E, 2))) return rc;
+        if ((rc = nmfx_aoadmm_alloc(E))) return rc;
+        if ((rc = nmfx_kl_state_alloc(E))) return rc;
+        if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;
+        if ((rc = nmfx_ensure_obj_capacity(E, j + 3))) return rc;
+        E->wsel = 0; E->w_in_place = true;
+        E->lazy_objective = false; E->himg_both = false;
+        return NMFX_OK;
+    }
     int rc = ao_sharded_ready(E, j); if (rc) return rc;
     if ((rc = nmfx_kl_state_alloc(E))) return rc;
     E->lazy_objective = false; E->himg_both = false;
     return NMFX_OK;
 }
+static bool kl_prox_ok(int p) { return p == NMFX_PROX_NN || p == NMFX_PROX_L1N; }
 
 extern "C" int nmfx_aoadmm_kl_phase_h_products(nmfx_handle_t E, int64_t j, int round) {
     int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
     if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if (E->kp > 128) return nmfx_generic_aoadmm_kl_phase(E, 0, 0, 0.0, 0, 0, 0.0, 0.0, j, round);
     float* W = E->W[0];
     if (round == 0) {
         if (j == 0 && (rc = nmfx_launch_wphase(E, W, false, true, true))) return rc;      // obj[0] partials (ao_admm.py:256)
@@ -2205,8 +2223,9 @@ extern "C" int nmfx_aoadmm_kl_phase_h_products(nmfx_handle_t E, int64_t j, int r
 extern "C" int nmfx_aoadmm_kl_phase_h_round(nmfx_handle_t E, int prox_h, double lambda_h, int round, int64_t min_iter,
                                             double tol1, double tol2, int64_t j) {
     int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
-    if (prox_h != NMFX_PROX_NN && prox_h != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (!kl_prox_ok(prox_h)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if (E->kp > 128) return nmfx_generic_aoadmm_kl_phase(E, 1, prox_h, lambda_h, 0, min_iter, tol1, tol2, j, round);
     if (round == 0 && (rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
     if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lambda_h, round))) return rc;
     return nmfx_launch_kl_vaux(E, E->W[0], E->auxH, &E->state->inner_stop);
@@ -2215,6 +2234,7 @@ extern "C" int nmfx_aoadmm_kl_phase_h_round(nmfx_handle_t E, int prox_h, double 
 extern "C" int nmfx_aoadmm_kl_phase_h_close(nmfx_handle_t E, int admm_iter, int64_t min_iter, double tol1, double tol2,
                                             int64_t j) {
     int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_aoadmm_kl_phase(E, 2, 0, 0.0, admm_iter, min_iter, tol1, tol2, j, 0);
     const int64_t kk = (int64_t)E->kp * E->kp;
     if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
@@ -2226,8 +2246,9 @@ extern "C" int nmfx_aoadmm_kl_phase_h_close(nmfx_handle_t E, int admm_iter, int6
 // buffer [1..4] for the caller to all-reduce (round r + 1 takes the stop decision of round r from the reduced sums).
 extern "C" int nmfx_aoadmm_kl_phase_w_round(nmfx_handle_t E, int prox_w, double lambda_w, int round) {
     int rc = ao_kl_sharded_ready(E, 0); if (rc) return rc;
-    if (prox_w != NMFX_PROX_NN && prox_w != NMFX_PROX_L1N) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
+    if (!kl_prox_ok(prox_w)) { E->err = "Unknown prox_type."; return NMFX_E_ARG; }
     if (round < 0) { E->err = "negative round"; return NMFX_E_ARG; }
+    if (E->kp > 128) return nmfx_generic_aoadmm_kl_phase(E, 3, prox_w, lambda_w, 0, 0, 0.0, 0.0, 0, round);
     float* W = E->W[0];
     const int* stop = &E->state->inner_stop;
     if ((rc = nmfx_launch_wphase(E, W, true, false, false, E->H, E->S, stop))) return rc;
@@ -2243,6 +2264,7 @@ extern "C" int nmfx_aoadmm_kl_phase_w_round(nmfx_handle_t E, int prox_w, double 
 
 extern "C" int nmfx_aoadmm_kl_phase_w_close(nmfx_handle_t E, int admm_iter, int64_t j) {
     int rc = ao_kl_sharded_ready(E, j); if (rc) return rc;
+    if (E->kp > 128) return nmfx_generic_aoadmm_kl_phase(E, 4, 0, 0.0, admm_iter, 0, 0.0, 0.0, j, 0);
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
     return nmfx_launch_wphase(E, E->W[0], false, true, true);                             // KL objective partials (utils.py:21-26)
 }

@@ -2152,6 +2152,121 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
     return NMFX_OK;
 }
 
+// The KL-loss iteration beyond 128 components in the pieces a ROW-SHARDED run needs (r5; nmfx_aoadmm_kl_phase_* dispatch here): the
+// V-sized products sit inside the inner rounds (ao_admm.py:85), so the H sub-problem exchanges once per round and the W sub-problem
+// its four norm sums per round --
+//   0 h_products(j, r): r = 0: (j = 0: the KL objective partial of the initial pair -> xf64[0]) W^T W of the rank's rows -> xf32 behind
+//                       the k n part; every r: W^T S of the rank's rows -> xf32                  -> all-reduce f32 (r = 0: and f64[:8])
+//   1 h_round(r):       r = 0: obj[j] + stop rule, (W^T W + rho I)^-1; then the replicated solve / prox / dual step, the rank-local
+//                       v_aux / dual_v step and the stop decision of the round (H is replicated: its norms are whole)
+//   2 h_close:          inner-round bookkeeping, H H^T and its inverse (replicated)
+//   3 w_round(r):       r > 0: the stop decision of round r - 1 from the ALL-REDUCED norm sums xf64[1..4]; S H^T, solve, prox, duals and
+//                       v_aux / dual_v on the rank's rows; the rank's norm sums of the round -> xf64[1..4]   -> all-reduce f64[1:5]
+//   4 w_close:          the decision of the last round, bookkeeping, the KL objective partial of the new pair -> xf64[0]
+namespace {
+__global__ __launch_bounds__(256) void gx_gather_norms_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out, const DevState* __restrict__ st)
+{
+    __shared__ double sh[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!(st->flag || st->inner_stop)) {               // (behind the inner stop nothing is read from the sums: zeros keep the exchange finite)
+        for (int b = tid; b < nblk; b += 256)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += part[(int64_t)b * 4 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if (lane == 0) sh[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid < 4) out[tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+}
+
+// terminate (ao_admm.py:33-43) of the round before from the sums over ALL ranks' rows
+__global__ void gx_decide_global_kernel(const double* __restrict__ n, DevState* __restrict__ st)
+{
+    if (st->flag || st->inner_stop) return;
+    st->inner_count += 1;
+    if (n[0] < 1e-4 * n[1] && n[2] < 1e-4 * n[3]) st->inner_stop = 1;
+}
+}  // namespace
+
+int nmfx_generic_aoadmm_kl_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                                 int64_t j, int round) {
+    E->gxb_img_ready = false;
+    int rc;
+    if ((rc = gx_admm_buffers(E))) return rc;
+    const int64_t mp = E->mp, np = E->np, kp = E->kp;
+    float* W = E->W[0];
+    float* xG = E->xf32 + kp * np;
+    const int* stop = &E->state->inner_stop;
+    const bool hside = phase <= 2;
+    const int64_t cnt4 = (hside ? kp * np : mp * kp) / 4;
+    const int nblk = (int)((cnt4 + 255) / 256);
+    float* X = hside ? E->H : W;
+    float* U = hside ? E->dualH : E->dualW;
+    switch (phase) {
+    case 0:
+        if (round == 0) {
+            if (j == 0 && (rc = gx_kl_objective_partial(E))) return rc;            // obj[0] (ao_admm.py:256)
+            ProfScope ps(E, "gram_tn");
+            if ((rc = gx_split_product<false, false>(E, W, kp, W, kp, xG, kp, kp, mp, 64))) return rc;
+        }
+        { ProfScope ps(E, "hphase");
+          return gx_split_product<false, false>(E, W, kp, E->S, np, E->xf32, kp, np, mp, 8, round > 0 ? stop : nullptr); }
+    case 3:
+        if (round > 0) {
+            hipLaunchKernelGGL(gx_decide_global_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)(E->xf64 + 1), E->state);
+            NMFX_HIP(hipGetLastError());
+        }
+        { ProfScope ps(E, "wphase");
+          if ((rc = gx_split_product<true, true>(E, E->S, np, E->H, np, E->A_part, mp, kp, np, 1, stop))) return rc; }
+        [[fallthrough]];
+    case 1: {
+        if (phase == 1 && round == 0) {
+            hipLaunchKernelGGL(gx_record_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)E->xf64, (long long)j, (long long)min_iter, tol1, tol2,
+                               E->state, E->obj_hist);
+            NMFX_HIP(hipGetLastError());
+            if ((rc = gx_prepare(E, xG, -1.0))) return rc;
+        }
+        ProfScope ps(E, hside ? "inner_h" : "inner_w");
+        hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, hside ? (const float*)E->xf32 : (const float*)E->A_part,
+                           (const float*)X, (const float*)U, E->gx_r, cnt4, (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        if (hside) rc = gx_launch<true, false>(E, GX_STORE, E->Minv, kp, E->gx_r, np, E->gx_d, np, 0, kp, np, kp, 1, nullptr, 0, nullptr, stop);
+        else rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr, stop);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, X, U, prox, (float)lam, cnt4, E->gx_nrm,
+                           (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        if (hside) rc = gx_launch<true, false>(E, GX_VAUX, W, kp, E->gx_d, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, stop, E->S);
+        else rc = gx_launch<true, false>(E, GX_VAUX, E->gx_d, kp, E->H, np, E->DV, np, 0, mp, np, kp, 1, E->V, np, nullptr, stop, E->S);
+        if (rc) return rc;
+        if (hside) hipLaunchKernelGGL(gx_decide_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->state);
+        else hipLaunchKernelGGL(gx_gather_norms_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->xf64 + 1, (const DevState*)E->state);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK; }
+    case 2:
+        hipLaunchKernelGGL(gx_close_kernel, dim3(1), dim3(1), 0, E->stream, E->state, E->inner_hist + j * 2);
+        NMFX_HIP(hipGetLastError());
+        { ProfScope ps(E, "gram_nt");
+          if ((rc = gx_split_product<true, true>(E, E->H, np, E->H, np, E->HHt, kp, kp, np, 64))) return rc; }
+        return gx_prepare(E, E->HHt, -1.0);
+    case 4:
+        if (admm_iter > 0) {
+            hipLaunchKernelGGL(gx_decide_global_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)(E->xf64 + 1), E->state);
+            NMFX_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(gx_close_kernel, dim3(1), dim3(1), 0, E->stream, E->state, E->inner_hist + j * 2 + 1);
+        NMFX_HIP(hipGetLastError());
+        return gx_kl_objective_partial(E);
+    default:
+        E->err = "generic AO-ADMM-KL phase: 0 .. 4"; return NMFX_E_ARG;
+    }
+}
+
 // ADMM (one level, fixed rho): aux_update twice, prox twice, dual updates, KL: v_aux / dual_v from w_aux h_aux (admm.py:292-324).
 // The caller (nmfx_admm_run) has allocated the ADMM state and, for the first iteration, set w_aux = w, h_aux = h.
 // One ADMM iteration beyond 128 components in its two halves (the row-sharded form exchanges between them, r4):

@@ -301,6 +301,8 @@ int nmfx_round_any(nmfx_engine* E, bool cols, const float* B, float* X, float* U
                    const double* nrm_global = nullptr);   // k padded to <= 512: one launch per round
 int nmfx_gather_round_norms(nmfx_engine* E, int nblk, int round);
 // row-sharded AO-ADMM (least-squares loss) beyond 128 components, phase 0 .. 4 = h_products, h_solve, w_products, w_round, w_close
+int nmfx_generic_aoadmm_kl_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
+                                 int64_t j, int round);
 int nmfx_generic_aoadmm_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
                               int64_t j, int round);
 
