@@ -2113,8 +2113,8 @@ static int ao_sharded_ready(nmfx_engine* E, int64_t j, bool any_k = false) {
     E->wimg_ok = false; E->ao_images = false;          // (the phase entry points rebuild the W images themselves)
     int rc;
     // beyond 128 components (r4): the least-squares phases are composed from the generic kernels (kernels_generic.hip,
-    // nmfx_generic_aoadmm_phase_*); the KL phases and the fused W sub-problem stay at k <= 128
-    if (!(any_k && E->kp <= 512) && (rc = nmfx_small_k_only(E, "row-sharded AO-ADMM (KL loss, fused W rounds, or more than 512 components)"))) return rc;
+    // nmfx_generic_aoadmm_phase_*; r5: any number of components the handle takes); the fused W sub-problem stays at k <= 128
+    if (!any_k && (rc = nmfx_small_k_only(E, "row-sharded AO-ADMM with the speculative (fused) W rounds"))) return rc;
     if ((rc = nmfx_enter_family(E, 2))) return rc;
     if ((rc = nmfx_aoadmm_alloc(E))) return rc;
     if ((rc = nmfx_ensure_inner_capacity(E, j + 2))) return rc;

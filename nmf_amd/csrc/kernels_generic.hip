@@ -1945,7 +1945,40 @@ int nmfx_generic_aoadmm_run(nmfx_engine* E, int prox_w, double lam_w, int prox_h
     return NMFX_OK;
 }
 
-// The same iteration in the pieces a ROW-SHARDED run needs (r4; nmfx_aoadmm_phase_* dispatch here beyond 128 components, k <= 512):
+// (r5) the W side of a row-sharded sub-problem: a round's norm sums of the rank's rows for the caller's all-reduce, and the stop decision
+// of the round before from the all-reduced sums
+namespace {
+__global__ __launch_bounds__(256) void gx_gather_norms_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out, const DevState* __restrict__ st)
+{
+    __shared__ double sh[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!(st->flag || st->inner_stop)) {               // (behind the inner stop nothing is read from the sums: zeros keep the exchange finite)
+        for (int b = tid; b < nblk; b += 256)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += part[(int64_t)b * 4 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if (lane == 0) sh[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid < 4) out[tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+}
+
+// terminate (ao_admm.py:33-43) of the round before from the sums over ALL ranks' rows
+__global__ void gx_decide_global_kernel(const double* __restrict__ n, DevState* __restrict__ st)
+{
+    if (st->flag || st->inner_stop) return;
+    st->inner_count += 1;
+    if (n[0] < 1e-4 * n[1] && n[2] < 1e-4 * n[3]) st->inner_stop = 1;
+}
+}  // namespace
+
+// The same iteration in the pieces a ROW-SHARDED run needs (r4; nmfx_aoadmm_phase_* dispatch here beyond 128 components, k <= 512 with one launch per W round,
+// beyond that the rhs / solve / prox launches of gx_ao_subproblem):
 //   0 h_products: [W^T V | W^T W] of this rank's rows into the f32 exchange buffer (xf64[0] holds the objective partial the
 //                 closing phase of the iteration before -- or, at j = 0, this phase -- left)      -> all-reduce f32 + f64[:8]
 //   1 h_solve:    obj[j] and the stop rule, then the H sub-problem (replicated work on the all-reduced sums)
@@ -1999,9 +2032,29 @@ int nmfx_generic_aoadmm_phase(nmfx_engine* E, int phase, int prox, double lam, i
           if (rc) return rc; }
         return gx_prepare(E, E->HHt, -1.0);
     case 3:
+        if (kp > 512) {                                // (r5) the launches of gx_ao_subproblem's long form, with the decision taken from the all-reduced sums
+            const int64_t cnt4 = mp * kp / 4;
+            const int nblk = (int)((cnt4 + 255) / 256);
+            const int* stop = &E->state->inner_stop;
+            if (round > 0) hipLaunchKernelGGL(gx_decide_global_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)(E->xf64 + 1), E->state);
+            else hipLaunchKernelGGL(gx_rhs_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->A_part, (const float*)W, (const float*)E->dualW,
+                                    E->gx_r, cnt4, (const DevState*)E->state);
+            NMFX_HIP(hipGetLastError());
+            if ((rc = gx_launch<true, false>(E, GX_STORE, E->gx_r, kp, E->Minv, kp, E->gx_d, kp, 0, mp, kp, kp, 1, nullptr, 0, nullptr, stop))) return rc;
+            hipLaunchKernelGGL(gx_prox_kernel, dim3((unsigned)nblk), dim3(256), 0, E->stream, (const float*)E->gx_d, W, E->dualW, prox, (float)lam, cnt4, E->gx_nrm,
+                               (const DevState*)E->state, (const float*)E->A_part, E->gx_r);      // (leaves the next round's right-hand side)
+            hipLaunchKernelGGL(gx_gather_norms_kernel, dim3(1), dim3(256), 0, E->stream, (const double*)E->gx_nrm, nblk, E->xf64 + 1, (const DevState*)E->state);
+            NMFX_HIP(hipGetLastError());
+            return NMFX_OK;
+        }
         if ((rc = nmfx_round_any(E, false, E->A_part, W, E->dualW, prox, (float)lam, round, round > 0 ? E->xf64 + 1 : nullptr))) return rc;
         return nmfx_gather_round_norms(E, (int)(mp / 64), round);
     case 4:
+        if (kp > 512) {
+            if (admm_iter > 0) hipLaunchKernelGGL(gx_decide_global_kernel, dim3(1), dim3(1), 0, E->stream, (const double*)(E->xf64 + 1), E->state);
+            hipLaunchKernelGGL(gx_close_kernel, dim3(1), dim3(1), 0, E->stream, E->state, E->inner_hist + j * 2 + 1);
+            NMFX_HIP(hipGetLastError());
+        } else
         if ((rc = nmfx_inner_finish(E, (int)(mp / 64), admm_iter, E->inner_hist + j * 2 + 1, E->xf64 + 1))) return rc;
         if (bf) { ProfScope ps(E, "images");
                   if ((rc = gxb_images_w(E, W))) return rc; }
@@ -2163,36 +2216,6 @@ int nmfx_generic_aoadmm_kl_run(nmfx_engine* E, int prox_w, double lam_w, int pro
 //   3 w_round(r):       r > 0: the stop decision of round r - 1 from the ALL-REDUCED norm sums xf64[1..4]; S H^T, solve, prox, duals and
 //                       v_aux / dual_v on the rank's rows; the rank's norm sums of the round -> xf64[1..4]   -> all-reduce f64[1:5]
 //   4 w_close:          the decision of the last round, bookkeeping, the KL objective partial of the new pair -> xf64[0]
-namespace {
-__global__ __launch_bounds__(256) void gx_gather_norms_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out, const DevState* __restrict__ st)
-{
-    __shared__ double sh[4][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    if (!(st->flag || st->inner_stop)) {               // (behind the inner stop nothing is read from the sums: zeros keep the exchange finite)
-        for (int b = tid; b < nblk; b += 256)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += part[(int64_t)b * 4 + c];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
-        if (lane == 0) sh[wave][c] = v[c];
-    }
-    __syncthreads();
-    if (tid < 4) out[tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
-}
-
-// terminate (ao_admm.py:33-43) of the round before from the sums over ALL ranks' rows
-__global__ void gx_decide_global_kernel(const double* __restrict__ n, DevState* __restrict__ st)
-{
-    if (st->flag || st->inner_stop) return;
-    st->inner_count += 1;
-    if (n[0] < 1e-4 * n[1] && n[2] < 1e-4 * n[3]) st->inner_stop = 1;
-}
-}  // namespace
-
 int nmfx_generic_aoadmm_kl_phase(nmfx_engine* E, int phase, int prox, double lam, int admm_iter, int64_t min_iter, double tol1, double tol2,
                                  int64_t j, int round) {
     E->gxb_img_ready = false;

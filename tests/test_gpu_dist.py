@@ -101,7 +101,7 @@ def _worker(rank, world, rdzv, backend, outdir, k=12, wide=False):
 MUR_KS = [12, 40, 100, 160]     # exact-f32 path; split-bf16 kp = 64 (fused epilogues); kp = 128; generic path (k > 128)
 WIDE_KS = [40, 100]
 RSAG_KS = [12, 40, 100]         # (12: exact-f32 epilogues have no sliced phase B -> all-reduce; 40, 100: k padded to 64 / 128)
-SOLVERS = ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "ao_admm_kl_k160", "admm",
+SOLVERS = ["ao_admm", "ao_admm_bf16", "ao_admm_early", "ao_admm_unfused", "ao_admm_kl", "ao_admm_k160", "ao_admm_k520", "ao_admm_kl_k160", "admm",
            "admm_bf16", "admm_kl", "admm_k160", "anls", "anls_k160"]
 BACKENDS = [(1, "nccl"), (2, "gloo"), (1, "native")]
 
@@ -382,6 +382,12 @@ def _solver_case(solver):
         kw = dict(rho=1.0, distance_type="kl" if solver == "admm_kl" else "eu", reg_w=(0.05, "l1n"),
                   reg_h=(0.05, "l1n") if solver == "admm_kl" else (0.2, "l2n"), min_iter=6, max_iter=6)
         v = R.planted_matrix(m, n, k, seed=33, dtype=np.float32)
+        w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
+        return m, n, k, v, w0, h0, kw
+    if solver == "ao_admm_k520":                           # r5: beyond 512 components the W rounds take the rhs / solve / prox launches (k pads to 640)
+        m, n, k = 700, 640, 520
+        kw = dict(reg_w=(0.1, "l1n"), reg_h=(0.05, "l1n"), min_iter=3, max_iter=3, admm_iter=8)
+        v = R.planted_matrix(m, n, 24, seed=40, dtype=np.float32)
         w0, h0 = R.svd_init(v.astype(np.float64), k, "zero")
         return m, n, k, v, w0, h0, kw
     if solver == "ao_admm_kl_k160":                        # r5: the KL loss beyond 128 components over row shards (generic kernels, nmfx_generic_aoadmm_kl_phase)
