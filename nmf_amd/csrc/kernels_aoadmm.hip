@@ -2281,6 +2281,7 @@ extern "C" int nmfx_aoadmm_phase_w_fused(nmfx_handle_t E, int prox_w, double lam
     if (admm_iter < 1 || admm_iter > NMFX_MAX_FUSED_ROUNDS) { E->err = "phase_w_fused: admm_iter out of range"; return NMFX_E_ARG; }
     NMFX_HIP(hipSetDevice(E->device));
     int rc;
+    if ((rc = nmfx_small_k_only(E, "row-sharded AO-ADMM with the speculative (fused) W rounds"))) return rc;      // (beyond that: nmfx_aoadmm_phase_w_round, one exchange per round)
     if ((rc = ao_fused_alloc(E, admm_iter))) return rc;
     ProfScope ps(E, "inner_w");
     if ((rc = fused_rows_any(E, E->W[0], prox_w, (float)lambda_w, admm_iter, 0, nullptr))) return rc;

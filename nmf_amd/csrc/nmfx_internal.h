@@ -282,7 +282,7 @@ int nmfx_preload_generic();
 // the tuned kernels keep k x k matrices and k-wide panels on chip: everything but MUR ends at k = 128
 inline int nmfx_small_k_only(nmfx_engine* E, const char* what) {
     if (E->kp <= 128) return NMFX_OK;
-    E->err = std::string(what) + ": more than 128 components are supported by MUR, AO-ADMM and ADMM (single GPU) only in this build";
+    E->err = std::string(what) + ": not available with more than 128 components in this build";
     return NMFX_E_ARG;
 }
 int nmfx_ensure_inner_capacity(nmfx_engine* E, int64_t need);

@@ -59,3 +59,17 @@ def test_first_tested_index_confirms_whatever_the_guard_history():
     assert ref.guard_since == 129
     flat = hist[-1]
     assert ref.confirms(hist + [flat + 1e-3], 129)
+
+
+def test_exchange_mode_parsing(monkeypatch):
+    """NMFX_DIST_EXCHANGE (nmf_amd.dist.exchange_mode): the default, the two spellings of each form, and a loud failure otherwise."""
+    import pytest
+    from nmf_amd import dist as nd
+    monkeypatch.delenv("NMFX_DIST_EXCHANGE", raising=False)
+    assert nd.exchange_mode() == "allreduce"
+    for val, want in (("allreduce", "allreduce"), ("0", "allreduce"), ("rsag", "rsag"), ("RS+AG", "rsag"), ("1", "rsag")):
+        monkeypatch.setenv("NMFX_DIST_EXCHANGE", val)
+        assert nd.exchange_mode() == want
+    monkeypatch.setenv("NMFX_DIST_EXCHANGE", "ring")
+    with pytest.raises(ValueError):
+        nd.exchange_mode()

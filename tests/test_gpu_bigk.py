@@ -263,9 +263,9 @@ def test_anls_k256_kkt_at_lambda_zero_with_a_dead_component():
 
 
 def test_row_sharded_phases_run_beyond_128_components():
-    """r4: the row-sharded phase entry points of AO-ADMM (least-squares loss), ADMM and ANLS are composed from the generic kernels beyond
-    128 components (tests/test_gpu_dist.py runs them against the oracle with 1 and 2 ranks); what stays at k <= 128 says so: the
-    KL-loss phases of AO-ADMM and its fused W sub-problem."""
+    """r4: the row-sharded phase entry points of AO-ADMM, ADMM and ANLS are composed from the generic kernels beyond 128 components
+    (tests/test_gpu_dist.py runs them against the oracle with 1 and 2 ranks; r5: AO-ADMM's KL-loss phases too); what stays at
+    k <= 128 says so: AO-ADMM's speculative (fused) W sub-problem."""
     from nmf_amd._lib import NmfxError
     from nmf_amd.engine import Engine
     v = R.planted_matrix(300, 260, 8, seed=1, dtype=np.float32)
@@ -278,8 +278,12 @@ def test_row_sharded_phases_run_beyond_128_components():
     with Engine(300, 260, 160) as eng:
         eng.upload_v(v)
         eng.set_factors(rs.rand(300, 160), rs.rand(160, 260))
+        eng._ck(eng.lib.nmfx_aoadmm_kl_phase_h_products(eng.h, 0, 0))          # (r5: runs)
+        eng.synchronize()
         with pytest.raises(NmfxError, match="more than 128 components"):
-            eng._ck(eng.lib.nmfx_aoadmm_kl_phase_h_products(eng.h, 0, 0))
+            eng.aoadmm_phase_w_fused(0, 0.0, 10)
+        with pytest.raises(NmfxError, match="more than 128 components"):
+            eng.aoadmm_phase_w_repair(0, 0.0, 10, 0)
 
 
 def test_mur_eu_16384x8192_k256_vs_oracle():
