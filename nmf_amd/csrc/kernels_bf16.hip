@@ -1453,6 +1453,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
     if constexpr (VAUX) { if (g0 < g1) vaux_load(g0, vx_cur); }       // (behind the V requests above; the first group's waits drain it)
+    // (r5) KL: the younger wave of each SIMD (4-7, the Y loaders) loses the issue arbitration and ends its sections ~300 cycles behind
+    // its partner, which then waits for it at the barrier (profiles/r05_stamps_kl_cfg4.txt); a static priority for those waves: config 4
+    // W phase 530.5 -> 526.5 us, H phase 451 -> 446 (same box, bit-identical results).  (The Euclidean kernels showed nothing: r2.)
+    if (KL) { if (yrole) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     if (KL && KP == 128) {
         for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
         osum += 0.69314718055994531 * olog;
