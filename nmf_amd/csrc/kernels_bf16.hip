@@ -1457,6 +1457,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // its partner, which then waits for it at the barrier (profiles/r05_stamps_kl_cfg4.txt); a static priority for those waves: config 4
     // W phase 530.5 -> 526.5 us, H phase 451 -> 446 (same box, bit-identical results).  (The Euclidean kernels showed nothing: r2.)
     if (KL) { if (yrole) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    // (the same on the Euclidean forms, measured again in r5: config 5 W phase 2788 -> 2799 us, config 2 117.8 -> 120.7: not there)
     if (KL && KP == 128) {
         for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
         osum += 0.69314718055994531 * olog;
