@@ -68,12 +68,13 @@ def test_unknown_method_and_distance_raise_like_reference():
 
 def test_ao_admm_l1inf_raises_like_reference():
     """nmf/ao_admm.py:143-195: the ao_admm copy of the operator breaks a Cholesky factorisation (scipy LinAlgError) for every
-    placement within a few outer iterations.  With the least-squares loss the device runs the operator until that happens
-    (tests/test_gpu_aoadmm.py, r4); with the KL loss the exception is still raised before any device work."""
+    placement within a few outer iterations.  Up to 128 components the device runs the operator until that happens (both losses:
+    tests/test_gpu_aoadmm.py, r4 / r5); beyond 128 components the exception is still raised before any device work."""
     from nmf_amd.ao_admm import ao_admm
     v = np.random.RandomState(0).rand(16, 12)
     for kind in ("l1inf", "l1inf_transpose"):
-        with pytest.raises(np.linalg.LinAlgError):
-            ao_admm(v, 3, distance_type="kl", reg_w=(0.1, "nn"), reg_h=(0.1, kind), nndsvd_init=(False, "zero"))
-        with pytest.raises(np.linalg.LinAlgError):
-            ao_admm(v, 3, distance_type="kl", reg_w=(0.1, kind), reg_h=(0.1, "nn"), nndsvd_init=(False, "zero"))
+        for loss in ("eu", "kl"):
+            with pytest.raises(np.linalg.LinAlgError):
+                ao_admm(v, 130, distance_type=loss, reg_w=(0.1, "nn"), reg_h=(0.1, kind), nndsvd_init=(False, "zero"))
+            with pytest.raises(np.linalg.LinAlgError):
+                ao_admm(v, 130, distance_type=loss, reg_w=(0.1, kind), reg_h=(0.1, "nn"), nndsvd_init=(False, "zero"))
