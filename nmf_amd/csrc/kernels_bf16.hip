@@ -111,6 +111,26 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a - ah), "v"(b - bh));    // (r5: the two subtractions as ONE v_pk_add_f32 -- 6 % fewer VALU
 }                                                                                  //  instructions in the KL loops -- measured no faster, k = 128 1 % slower: not kept)
+#ifdef NMFX_EXP_FP8D           // experiment (r5): the cross terms of the RESIDUAL product (k = 128 Euclidean form) on the block-scaled fp8 matrix pipe, operands
+                               // converted in registers from the bf16 fragments (fixed scales: hi x 1, lo x 2^9).  Measured: config 5 W phase 2740 -> 2719 us,
+                               // config 3 180.2 -> 178.8 (-0.8 %): the 64 conversions per group cost the issue port what the 12 saved MFMAs give back;
+                               // recorded objective +1e-6 .. +1.4e-5 off the f64 one.  The fp8 pipe pays only with operands that arrive converted (LAB_NOTES R5)
+typedef int fp8_i32x8 __attribute__((ext_vector_type(8)));
+typedef short fp8_s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fp8_bf16x2 __attribute__((ext_vector_type(2)));
+// eight bf16 (one 32x32x16 k-step's fragment) -> eight e4m3 bytes = registers 2 j, 2 j + 1 of a 32x32x64 operand; stored value = x / scale
+__device__ __forceinline__ void frag_to_fp8(const Frag8& f, float scale, int& r0, int& r1) {
+    union { unsigned u; fp8_bf16x2 v; } a, b, c, d;
+    a.u = f.u.x; b.u = f.u.y; c.u = f.u.z; d.u = f.u.w;
+    union { fp8_s16x2 v; int i; } o0, o1;
+    o0.i = 0; o1.i = 0;
+    o0.v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o0.v, a.v, scale, false);
+    o0.v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o0.v, b.v, scale, true);
+    o1.v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o1.v, c.v, scale, false);
+    o1.v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o1.v, d.v, scale, true);
+    r0 = o0.i; r1 = o1.i;
+}
+#endif
 __device__ __forceinline__ void hi8(const float4& p, const float4& q, Frag8& hi) {       // the bf16 image alone (round to nearest even)
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.x) : "v"(p.x), "v"(p.y));
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.u.y) : "v"(p.z), "v"(p.w));
@@ -847,6 +867,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < NK; ++s) { pinu(zh[s].u); pinu(zl[s].u); }
     }
+#ifdef NMFX_EXP_FP8D
+    constexpr bool FP8D = WITH_D && !KL && KP == 128 && NPROB == 1 && VMODE == 0 && !(WITH_OBJ && !KL && KP == 64 && WITH_A);
+    fp8_i32x8 z8h[FP8D ? NK / 4 : 1], z8l[FP8D ? NK / 4 : 1], y8h, y8l;
+    if constexpr (FP8D) {
+#pragma unroll
+        for (int q8 = 0; q8 < NK / 4; ++q8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int a0, a1;
+                frag_to_fp8(zh[4 * q8 + j], 1.f, a0, a1); z8h[q8][2 * j] = a0; z8h[q8][2 * j + 1] = a1;
+                frag_to_fp8(zl[4 * q8 + j], 0.001953125f, a0, a1); z8l[q8][2 * j] = a0; z8l[q8][2 * j + 1] = a1;
+            }
+    }
+#endif
     int ycur = 0, vcur = 0;
 #ifdef NMFX_EXP_STAMPS
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_wait = 0, acc_head = 0, acc_early = 0, acc_mfma = 0;
@@ -1038,6 +1072,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
                     const int s = WITH_D ? 2 * (st - NA) + ss : 0;
+#ifdef NMFX_EXP_FP8D
+                    if constexpr (FP8D) {              // hi hi in bf16; the fragments of four k-steps make one K = 64 operand of each image
+                        d = MFMA32X(fh[set][ss], zh[s], d);
+                        int a0, a1;
+                        frag_to_fp8(fh[set][ss], 1.f, a0, a1); y8h[2 * (s & 3)] = a0; y8h[2 * (s & 3) + 1] = a1;
+                        frag_to_fp8(fl[set][ss], 0.001953125f, a0, a1); y8l[2 * (s & 3)] = a0; y8l[2 * (s & 3) + 1] = a1;
+                        if ((s & 3) == 3) {            // (lo images are stored x 2^9: scale byte 127 - 9)
+                            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(y8l, z8h[s >> 2], d, 0, 0, 0, 118, 0, 127);
+                            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(y8h, z8l[s >> 2], d, 0, 0, 0, 127, 0, 118);
+                        }
+                        continue;
+                    }
+#endif
                     d = MFMA32X(fh[set][ss], zh[s], d);
 #ifndef NMFX_EXP_R2            // experiment (r5): the residual product with TWO terms (Y_lo Z_hi dropped): W phase -11 % (k = 128), -8 % (k = 64);
                                // recorded objective +1.2e-5 .. +4.3e-4 off nmfx_objective_f64 (three terms: 1.6e-8), jitter 1.5e-6 (7e-9): not shipped, LAB_NOTES R5
