@@ -919,20 +919,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     float4 vx_s[2][2], vx_d[2][2];
     const unsigned vx_lane = (unsigned)(((rg * 32 + n31) * 64 + 4 * (8 * hh + 2 * b)) * 4);      // bytes; + 64 s + 16 e, + the tile
     auto vaux_tile = [&](int grp) { return ((int64_t)bx * (ldx / 64) + grp) * 8192; };           // floats (NW = 8: one tile per block and group)
+    // r5: dual_v is only ever touched here and by the transposes between the sub-problems, so inside its 128 x 64 tiles it lives in THIS
+    // kernel's register order -- piece j = 2 s + e of wave w, lane l at float4 index (4 w + j) 64 + l (kl_dv_pos below): every load /
+    // store instruction of a wave is one contiguous KiB instead of 64 pieces of 16 bytes at a 256-byte stride.  (S keeps the layout of
+    // the tile-major X: the product kernels stream it by LDS-DMA.)
+    const unsigned vx_priv = (unsigned)(((wave * 4) * 64 + lane) * 16);                         // bytes; + 1024 j
     auto vaux_load = [&](int grp, f32x4 (&dst)[2][2]) {
         const unsigned long long src = (unsigned long long)(vaux_dv + vaux_tile(grp));
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\t"
-                     "global_load_dwordx4 %2, %4, %5 offset:64\n\tglobal_load_dwordx4 %3, %4, %5 offset:80"
-                     : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[1][0]), "=&v"(dst[1][1]) : "v"(vx_lane), "s"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                     : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[1][0]), "=&v"(dst[1][1]) : "v"(vx_priv), "s"(src) : "memory");
     };
     auto vaux_store = [&](int grp) {
-        const int64_t off = vaux_tile(grp) + vx_lane / 4;
+        const int64_t off = vaux_tile(grp) + vx_lane / 4, offp = vaux_tile(grp) + vx_priv / 4;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 *reinterpret_cast<float4*>(vaux_s + off + 16 * s2 + 4 * e) = vx_s[s2][e];
-                *reinterpret_cast<float4*>(vaux_dv + off + 16 * s2 + 4 * e) = vx_d[s2][e];
+                *reinterpret_cast<float4*>(vaux_dv + offp + 256 * (2 * s2 + e)) = vx_d[s2][e];
             }
     };
     auto vaux_update = [&](const VRegs& v) {           // d[4 a + c] <-> va[a >> 1][a & 1], component c
@@ -1619,6 +1624,13 @@ __global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __res
 
 // out = in^T, both TILE-MAJOR (in: R x C as tiles [128][64], out: C x R as tiles [128][64]): the m x n state of the KL-loss ADMM
 // variants changes orientation between the two sub-problems (r4)
+// PRIV (r5): both sides in the register order of xyt32_bf16_kernel<..., VAUX> (dual_v): element (r, c) of a [128][64] tile at kl_dv_pos(r, c)
+__device__ __forceinline__ int kl_dv_pos(int r, int c) {
+    const int q = c >> 2;                              // 16-byte chunk of the row: q = 8 hh + 4 s + 2 b + e
+    const int w = (r >> 5) + 4 * (q >> 3), j = ((q >> 2) & 1) * 2 + (q & 1), l = (r & 31) + 32 * ((q >> 1) & 1);
+    return (((w * 4 + j) * 64 + l) << 2) + (c & 3);
+}
+template <bool PRIV>
 __global__ __launch_bounds__(256) void tile_transpose_kernel(const float* __restrict__ in, int64_t R, int64_t C, float* __restrict__ out,
                                                               const int* __restrict__ flag)
 {
@@ -1626,6 +1638,14 @@ __global__ __launch_bounds__(256) void tile_transpose_kernel(const float* __rest
     __shared__ float tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    if (PRIV) {
+        const float* src = in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192;
+        for (int r = ty; r < 64; r += 4) tile[r][tx] = src[kl_dv_pos((int)(r0 & 64) + r, tx)];
+        __syncthreads();
+        float* dst = out + ((c0 >> 7) * (R >> 6) + blockIdx.y) * 8192;
+        for (int c = ty; c < 64; c += 4) dst[kl_dv_pos((int)(c0 & 64) + c, tx)] = tile[tx][c];
+        return;
+    }
     const float* src = in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192 + (r0 & 64) * 64;
     for (int r = ty; r < 64; r += 4) tile[r][tx] = src[r * 64 + tx];
     __syncthreads();
@@ -2500,9 +2520,9 @@ int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv) {
     const int from = E->kl_side;
     const int64_t R = from == 0 ? E->np : E->mp, C = from == 0 ? E->mp : E->np;
     const dim3 grid((unsigned)(C / 64), (unsigned)(R / 64));
-    hipLaunchKernelGGL(tile_transpose_kernel, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
+    hipLaunchKernelGGL(tile_transpose_kernel<false>, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
     if (with_dv)
-        hipLaunchKernelGGL(tile_transpose_kernel, grid, dim3(256), 0, E->stream, (const float*)E->kl_DV[from], R, C, E->kl_DV[side], &E->state->flag);
+        hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_DV[from], R, C, E->kl_DV[side], &E->state->flag);
     NMFX_HIP(hipGetLastError());
     E->kl_side = side;
     return NMFX_OK;
