@@ -671,7 +671,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     float* __restrict__ Apart, double* __restrict__ objpart, float* __restrict__ gram_part, int64_t R,
     int ngroups, const int* __restrict__ flag, int ng,
     const int4* __restrict__ sk_seg = nullptr, const int* __restrict__ sk_first = nullptr, int sk_workers = 0, XytSide side = XytSide(),
-    float* __restrict__ vaux_dv = nullptr, float* __restrict__ vaux_s = nullptr, const int* __restrict__ flag2 = nullptr)
+    float* __restrict__ vaux_dv = nullptr, float* __restrict__ vaux_s = nullptr, const int* __restrict__ flag2 = nullptr,
+    int xpriv = 0)               // r5: X (the S of the KL-loss ADMM variants) lies in the auxiliaries kernel's register order inside its tiles (kl_dv_pos)
 {
 #define MFMA32X(a, b, c) ((ABL & 16) ? (c) : MFMA32_BF16(a, b, c))
     if (*flag) return;
@@ -769,6 +770,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }   // rows 4t+g (< 16): row & 15 = row
+    if (xpriv) {
+        // X in the auxiliaries kernel's register order (kl_dv_pos): the KiB of piece j of wave w = row group + 4 hh is what wave (row group, hh)
+        // of THIS kernel wants in its va[j >> 1][j & 1], lane for lane.  So the pieces travel whole (a contiguous KiB per request instead of
+        // 4 rows x 256 B) and stay in that order in the LDS slot: [hh][j][lane] float4s, read back with one conflict-free ds_read_b128 each
+        vbaseA = tile0 + (unsigned long long)((bx % (4 / NRG)) * NRG + lw) * 4096; vbaseB = vbaseA + 16384;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) voffs[t] = (unsigned)(t * 1024 + lane * 16);
+    }
     const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
     const unsigned vdstA = smem0 + VOFF + lw * (VRING * VSLOT), vdstB = vdstA + 4096;
     int yq = 0, vq = 0;
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) vaoff[s][e] = n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
+        for (int e = 0; e < 2; ++e) vaoff[s][e] = xpriv ? ((4 * hh + 2 * s + e) * 64 + lane) * 16 : n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
         yrow[s] = n31 * 128 + 16 * ((4 * hh + 2 * s + b) ^ yswz32(n31));          // + 4096 * (factor tile) + YT * (lo image)
         ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz32(x));                       // + 2048 * (16-factor tile)
     }
@@ -917,12 +926,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // requests in its own vmcnt bookkeeping and would put its waits where it believes the loads are the only ones in flight.
     f32x4 vx_cur[2][2], vx_next[2][2];
     float4 vx_s[2][2], vx_d[2][2];
-    const unsigned vx_lane = (unsigned)(((rg * 32 + n31) * 64 + 4 * (8 * hh + 2 * b)) * 4);      // bytes; + 64 s + 16 e, + the tile
     auto vaux_tile = [&](int grp) { return ((int64_t)bx * (ldx / 64) + grp) * 8192; };           // floats (NW = 8: one tile per block and group)
     // r5: dual_v is only ever touched here and by the transposes between the sub-problems, so inside its 128 x 64 tiles it lives in THIS
     // kernel's register order -- piece j = 2 s + e of wave w, lane l at float4 index (4 w + j) 64 + l (kl_dv_pos below): every load /
-    // store instruction of a wave is one contiguous KiB instead of 64 pieces of 16 bytes at a 256-byte stride.  (S keeps the layout of
-    // the tile-major X: the product kernels stream it by LDS-DMA.)
+    // store instruction of a wave is one contiguous KiB instead of 64 pieces of 16 bytes at a 256-byte stride.  S lies the same way: the
+    // product kernels that stream it by LDS-DMA give every lane its own source address anyway (`xpriv`).
     const unsigned vx_priv = (unsigned)(((wave * 4) * 64 + lane) * 16);                         // bytes; + 1024 j
     auto vaux_load = [&](int grp, f32x4 (&dst)[2][2]) {
         const unsigned long long src = (unsigned long long)(vaux_dv + vaux_tile(grp));
@@ -931,12 +939,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                      : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[1][0]), "=&v"(dst[1][1]) : "v"(vx_priv), "s"(src) : "memory");
     };
     auto vaux_store = [&](int grp) {
-        const int64_t off = vaux_tile(grp) + vx_lane / 4, offp = vaux_tile(grp) + vx_priv / 4;
+        const int64_t offp = vaux_tile(grp) + vx_priv / 4;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                *reinterpret_cast<float4*>(vaux_s + off + 16 * s2 + 4 * e) = vx_s[s2][e];
+                *reinterpret_cast<float4*>(vaux_s + offp + 256 * (2 * s2 + e)) = vx_s[s2][e];
                 *reinterpret_cast<float4*>(vaux_dv + offp + 256 * (2 * s2 + e)) = vx_d[s2][e];
             }
     };
@@ -1639,11 +1647,26 @@ __global__ __launch_bounds__(256) void tile_transpose_kernel(const float* __rest
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     if (PRIV) {
-        const float* src = in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192;
-        for (int r = ty; r < 64; r += 4) tile[r][tx] = src[kl_dv_pos((int)(r0 & 64) + r, tx)];
+        // whole pieces on both sides: wave ty moves the four KiB pieces of the private-order wave w = (its row group of the half tile) + 4 (ty >> 1)
+        const float4* src = reinterpret_cast<const float4*>(in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192);
+        const int l31 = tx & 31, lb = tx >> 5, hq = ty >> 1, r = 32 * (ty & 1) + l31;
+        {
+            const int w = (int)((r0 & 64) >> 5) + (ty & 1) + 4 * hq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = src[(w * 4 + j) * 64 + tx];
+                const int c = 4 * (8 * hq + 4 * (j >> 1) + 2 * lb + (j & 1));
+                tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+            }
+        }
         __syncthreads();
-        float* dst = out + ((c0 >> 7) * (R >> 6) + blockIdx.y) * 8192;
-        for (int c = ty; c < 64; c += 4) dst[kl_dv_pos((int)(c0 & 64) + c, tx)] = tile[tx][c];
+        float4* dst = reinterpret_cast<float4*>(out + ((c0 >> 7) * (R >> 6) + blockIdx.y) * 8192);
+        const int w = (int)((c0 & 64) >> 5) + (ty & 1) + 4 * hq;                   // (r: row of the transposed half tile = column of `tile`)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * (8 * hq + 4 * (j >> 1) + 2 * lb + (j & 1));
+            dst[(w * 4 + j) * 64 + tx] = make_float4(tile[c][r], tile[c + 1][r], tile[c + 2][r], tile[c + 3][r]);
+        }
         return;
     }
     const float* src = in + ((r0 >> 7) * (C >> 6) + blockIdx.x) * 8192 + (r0 & 64) * 64;
@@ -2254,7 +2277,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
                                                              : xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
             int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
             hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2);
+                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv ? 1 : 0);
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
         }
@@ -2295,7 +2318,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
 #endif
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2);
+                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv ? 1 : 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2520,7 +2543,7 @@ int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv) {
     const int from = E->kl_side;
     const int64_t R = from == 0 ? E->np : E->mp, C = from == 0 ? E->mp : E->np;
     const dim3 grid((unsigned)(C / 64), (unsigned)(R / 64));
-    hipLaunchKernelGGL(tile_transpose_kernel<false>, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
+    hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
     if (with_dv)
         hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_DV[from], R, C, E->kl_DV[side], &E->state->flag);
     NMFX_HIP(hipGetLastError());
@@ -2547,7 +2570,7 @@ int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2) {
     auto kern = E->kp == 64 ? k64 : k128;
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, (float*)nullptr, E->obj_part, (float*)nullptr, R,
-                       (int)(ldx / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), E->kl_DV[side], E->kl_S[side], flag2);
+                       (int)(ldx / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), E->kl_DV[side], E->kl_S[side], flag2, 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2565,7 +2588,7 @@ int nmfx_bf16_kl_objective(nmfx_engine* E) {
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, (const float*)E->Vtile, E->np, (const unsigned short*)E->Hhi, (const unsigned short*)E->Hlo, E->np,
                        (const unsigned short*)E->Whi[0], (const unsigned short*)E->Wlo[0], (float*)nullptr, E->obj_part, (float*)nullptr, E->mp,
                        (int)(E->np / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr,
-                       (const int*)nullptr);
+                       (const int*)nullptr, 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2573,11 +2596,16 @@ int nmfx_bf16_kl_objective(nmfx_engine* E) {
 // the two right-hand-side products with S in the place of V (slabs as nmfx_bf16_vtw / nmfx_bf16_vht leave them; no objective)
 int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2) {
     (void)flag2;       // (a product behind the inner stop is wasted work, not a wrong result: its consumers are no-ops)
+    E->xyt_xpriv = true;                               // S lies in the auxiliaries kernel's register order (r5)
+    int rc;
     if (side == 0)
-        return launch_xyt(E, false, E->kl_S[0], true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
-                          E->Bt_part, E->kp == 64 ? E->G_part : nullptr, "hphase", false, E->gram_ng_h, terms);
-    return launch_xyt(E, false, E->kl_S[1], true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
-                      E->A_part, E->kp == 64 ? E->HHt_part : nullptr, "wphase_noobj", false, E->gram_ng_w, terms);
+        rc = launch_xyt(E, false, E->kl_S[0], true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
+                        E->Bt_part, E->kp == 64 ? E->G_part : nullptr, "hphase", false, E->gram_ng_h, terms);
+    else
+        rc = launch_xyt(E, false, E->kl_S[1], true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
+                        E->A_part, E->kp == 64 ? E->HHt_part : nullptr, "wphase_noobj", false, E->gram_ng_w, terms);
+    E->xyt_xpriv = false;
+    return rc;
 }
 
 // xf32 = [ (sum of the B^T slabs)^T  (kp x np) | sum of the G slabs ], xf64[0] = sum of obj_part
@@ -2762,7 +2790,7 @@ int nmfx_bf16_sk_product(nmfx_engine* E, int side, bool obj, const float* gsrc, 
     if ((rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm))) return rc;
     if (obj) E->obj_count = P.nseg;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, P.slabs, E->obj_part,
-                       (float*)nullptr, R, ngroups, &E->state->flag, 1, (const int4*)P.seg, (const int*)P.first, P.workers, job, (float*)nullptr, (float*)nullptr, (const int*)nullptr);
+                       (float*)nullptr, R, ngroups, &E->state->flag, 1, (const int4*)P.seg, (const int*)P.first, P.workers, job, (float*)nullptr, (float*)nullptr, (const int*)nullptr, 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -128,6 +128,7 @@ struct nmfx_engine {
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     const int* xyt_flag2 = nullptr;  // a second skip flag for the next 32-row product launches (the inner stop of a KL-ADMM sub-problem)
+    bool xyt_xpriv = false;          // the next 32-row product launches read an X that lies in the KL auxiliaries' register order (kl_dv_pos)
     int xyt_nw = 8;                // waves per block of the next 32-row product launch (4: 64-row blocks, two per CU; set and reset by the caller)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     const float* ao_b_src = nullptr; const int* ao_b_cnt = nullptr;   // AO-ADMM H side, behind a stream-K product: B^T slabs the fused rounds sum themselves (+ what their first launch records)
