@@ -204,9 +204,10 @@ def parity_block(v, w_g, h_g, obj_g, w_r, h_r, obj_r, block=2048):
 
 
 ALL_KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "sum_hht", "w_update", "pack",
-               "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "kl_round_h", "kl_round_w", "transpose",
+               "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "kl_vaux_fused", "kl_round_h", "kl_round_w", "transpose",
                "nnls", "small")
-V_SIZED = ("wphase", "wphase_noobj", "objective", "hphase", "kl_vaux")      # launches that stream V (or V^T) once
+V_SIZED = ("wphase", "wphase_noobj", "objective", "hphase", "kl_vaux", "kl_vaux_fused")      # launches that stream V (or V^T) once
+KL_STREAMS = {"kl_vaux": 4, "kl_vaux_fused": 3}      # V-sized streams of the KL auxiliaries' launches: V and dual_v read, dual_v (and S) written
 
 
 def device_planted(eng, torch, m, n, k, seed, dev, chunk=8192, rows=None):
@@ -561,10 +562,10 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                 "algorithmic_gflop_per_iter": flops / 1e9, "algorithmic_gbytes_per_iter": nbytes / 1e9,
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
                 "dominant_kernel": ({"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
-                                     # (the KL auxiliaries' update reads V and dual_v and writes dual_v and S: four V-sized streams)
-                                     "algorithmic_bytes_per_launch": m * n * 4.0 * (4 if dom == "kl_vaux" else 1), "bound": "hbm",
-                                     "achieved_gbs": m * n * 4.0 * (4 if dom == "kl_vaux" else 1) / dsec / 1e9,
-                                     "frac": m * n * 4.0 * (4 if dom == "kl_vaux" else 1) / dsec / 1e9 / PEAK_HBM_GBS}
+                                     # (the KL auxiliaries' update reads V and dual_v and writes dual_v -- and S, unless the launch forms the next product itself)
+                                     "algorithmic_bytes_per_launch": m * n * 4.0 * KL_STREAMS.get(dom, 1), "bound": "hbm",
+                                     "achieved_gbs": m * n * 4.0 * KL_STREAMS.get(dom, 1) / dsec / 1e9,
+                                     "frac": m * n * 4.0 * KL_STREAMS.get(dom, 1) / dsec / 1e9 / PEAK_HBM_GBS}
                                     if bound == "hbm" else
                                     # split bf16: every algorithmic product is three bf16 MFMA terms (hi hi + lo hi + hi lo)
                                     {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (split bf16: 3 executed terms per product)",
@@ -646,12 +647,13 @@ def other_configs(torch, dev, only=None):
         # the KL-loss variants (nmf/ao_admm.py:71-101, nmf/admm.py:303-315) on the config-3 shape: two V-sized auxiliaries (v_aux, dual_v)
         # updated in EVERY inner round; split bf16 (r4: the auxiliaries as a mode of the product kernel) and the exact-f32 path beside it.
         # Algorithmic work per inner round: the product of the right-hand side and the product inside the auxiliaries' update;
-        # V read, dual_v read + written, S written + read
+        # V read, dual_v read + written (r5: S = v_aux + dual_v stays in registers between the rounds of a sub-problem -- per sub-problem it is
+        # read once by the first round's product and written once by the last round: 3 T + 2 V-sized streams; the exact-f32 leg moves 5 T)
         dict(name="aoadmm_kl_on_cfg3_shape", workload="AO-ADMM KL loss, reg_w = reg_h = (0, 'nn'), V=16384x8192 f32, k=128, admm_iter=10, uniform "
                                                       "random start of the data's scale (split bf16: auxiliaries as a mode of the product kernel)",
              m=16384, n=8192, k=128, steps=3, warmup=1, init="rand_kl", admm_iter=T,
              queue=lambda e, f, c: e.aoadmm_run(1, 0, 0.0, 0, 0.0, T, NEVER, 1e-3, 1e-3, f, c),
-             flops=lambda t: 4.0 * 16384 * 8192 * 128 * (t[0] + t[1]), nbytes=lambda t: 5.0 * 16384 * 8192 * 4 * (t[0] + t[1])),
+             flops=lambda t: 4.0 * 16384 * 8192 * 128 * (t[0] + t[1]), nbytes=lambda t: (3.0 * (t[0] + t[1]) + 4.0) * 16384 * 8192 * 4),
         dict(name="aoadmm_kl_exact_f32", workload="AO-ADMM KL loss on the config-3 shape with the exact-f32 kernels (NMFX_PRECISION=f32)",
              m=16384, n=8192, k=128, steps=2, warmup=1, init="rand_kl", admm_iter=T, precision="f32",
              queue=lambda e, f, c: e.aoadmm_run(1, 0, 0.0, 0, 0.0, T, NEVER, 1e-3, 1e-3, f, c),

@@ -144,30 +144,7 @@ __global__ __launch_bounds__(KP * 4 + 64) void ao_prepare_mfma_kernel(
     ao_prepare_body<KP, true>(prep_lds, src, 1, k, Minv, st, fixed_rho, false, out64, soft_bad, src64, ld64);
 }
 
-// ---- inner stop test -------------------------------------------------------
-// `terminate` (ao_admm.py:33-43) on the four sums of squares: ||X - aux|| / ||X|| < 1e-2 and ||X - X_prev|| / ||U|| < 1e-2,
-// written without the square roots and divisions (~1500 cycles of f64 per test on the serial path of every round):
-// sqrt(a) / sqrt(b) < 1e-2  <=>  a < 1e-4 b for a >= 0, b > 0; b = 0 gives inf or nan on the left (false) and a < 0 on the
-// right (false); a nan makes both false.  Only sums within a rounding error of the threshold could be told apart.
-__device__ __forceinline__ bool inner_test(double a, double b, double c, double d) {
-    return (a < 1e-4 * b) && (c < 1e-4 * d);
-}
-// Sum the four norm partials of the previous round; identical in every block.
-__device__ __forceinline__ bool inner_round_fired(const double* __restrict__ part, int nblk, double* sh)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // wave w sums component w
-    double s = 0.0;
-    if (wave < 4)
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * 4 + wave];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0 && wave < 4) sh[wave] = s;
-    __syncthreads();
-    const bool hit = inner_test(sh[0], sh[1], sh[2], sh[3]);
-    __syncthreads();
-    return hit;
-}
-
+// (inner_test / inner_round_fired: kernels_small.h -- the fused auxiliaries launch of the KL loss applies the same test, r5)
 __device__ __forceinline__ float prox_apply(float aux, float dual, float shift) {
     const float d = (aux - dual) - shift;              // nn: shift = 0; l1n: lambda / rho
     return (d < 0.f) ? 0.f : d;                        // np.where(d < 0, 0, d): NaN stays NaN
@@ -2015,11 +1992,16 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     // ---- H sub-problem (state in the orientation of V^T) ----
     if ((rc = nmfx_bf16_kl_orient(E, 0, true))) return rc;
     if (!E->wimg_ok && (rc = nmfx_bf16_images_w(E, W, 0))) return rc;  // W^T images: Y of the products and of the auxiliaries (left by the objective pass)
+    // r5, k padded to 128: the auxiliaries of round r also form the product of round r + 1 (S stays in registers; NMFX_KL_FUSE=0: separate launches)
+    static const bool fuse_on = !(getenv("NMFX_KL_FUSE") && atoi(getenv("NMFX_KL_FUSE")) == 0);
+    const bool fuse = fuse_on && E->kp == 128;
     for (int r = 0; r < admm_iter; ++r) {
-        E->xyt_flag2 = r > 0 ? stop : nullptr;
-        rc = nmfx_bf16_kl_product(E, 0, 4);                            // B^T slabs = S^T W (FOUR terms: with three the KL objective history left its 5e-5 bar -- 1.2e-4 at k = 64, the objective near its optimum is 1e-5 of sum V)
-        E->xyt_flag2 = nullptr;
-        if (rc) return rc;
+        if (r == 0 || !fuse) {
+            E->xyt_flag2 = r > 0 ? stop : nullptr;
+            rc = nmfx_bf16_kl_product(E, 0, 4);                        // B^T slabs = S^T W (FOUR terms: with three the KL objective history left its 5e-5 bar -- 1.2e-4 at k = 64, the objective near its optimum is 1e-5 of sum V)
+            E->xyt_flag2 = nullptr;
+            if (rc) return rc;
+        }
         if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);
         else {
             if (r == 0 && (rc = nmfx_launch_gram_tn(E, W, E->mp, E->G_part, E->gsplit))) return rc;
@@ -2029,7 +2011,9 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
         if (r == 0 && (rc = nmfx_launch_prepare(E, E->xf32 + (int64_t)E->kp * E->np, 1, j, min_iter, tol1, tol2, -1.0))) return rc;
         if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, r))) return rc;
         if ((rc = nmfx_bf16_images_h(E, true, E->auxH))) return rc;    // (h_aux)^T images: Z of the auxiliaries
-        if ((rc = nmfx_bf16_vaux(E, 0, stop))) return rc;
+        if (fuse) rc = nmfx_bf16_vaux_fused(E, 0, stop, E->nrm_part + (int64_t)(r & 1) * (E->np / 64) * 4, (int)(E->np / 64), r == admm_iter - 1);
+        else rc = nmfx_bf16_vaux(E, 0, stop);
+        if (rc) return rc;
     }
     if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
     // ---- W sub-problem (transposed data: the orientation of V) ----
@@ -2039,14 +2023,18 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
     if ((rc = nmfx_launch_prepare(E, E->HHt, 0, j, min_iter, tol1, tol2, -1.0))) return rc;
     for (int r = 0; r < admm_iter; ++r) {
-        E->xyt_flag2 = r > 0 ? stop : nullptr;
-        rc = nmfx_bf16_kl_product(E, 1, 4);                            // A slabs = S H^T
-        E->xyt_flag2 = nullptr;
-        if (rc) return rc;
+        if (r == 0 || !fuse) {
+            E->xyt_flag2 = r > 0 ? stop : nullptr;
+            rc = nmfx_bf16_kl_product(E, 1, 4);                        // A slabs = S H^T
+            E->xyt_flag2 = nullptr;
+            if (rc) return rc;
+        }
         if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
         if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, r))) return rc;
         if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;       // w_aux images: Z
-        if ((rc = nmfx_bf16_vaux(E, 1, stop))) return rc;
+        if (fuse) rc = nmfx_bf16_vaux_fused(E, 1, stop, E->nrm_part + (int64_t)(r & 1) * (E->mp / 64) * 4, (int)(E->mp / 64), r == admm_iter - 1);
+        else rc = nmfx_bf16_vaux(E, 1, stop);
+        if (rc) return rc;
     }
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
     E->himg_both = false;

@@ -102,6 +102,15 @@ __device__ __forceinline__ void dma_run2_nt(unsigned long long base, unsigned ds
 template <int N> __device__ __forceinline__ void dma_wait_le() {      // at most N DMAs still in flight
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
+__device__ __forceinline__ void dma_wait_le_rt(int n) {                 // the same with a wave-uniform count (a multiple of 4, at most 52)
+    switch (n >> 2) {
+        case 0: dma_wait_le<0>(); break;   case 1: dma_wait_le<4>(); break;   case 2: dma_wait_le<8>(); break;   case 3: dma_wait_le<12>(); break;
+        case 4: dma_wait_le<16>(); break;  case 5: dma_wait_le<20>(); break;  case 6: dma_wait_le<24>(); break;  case 7: dma_wait_le<28>(); break;
+        case 8: dma_wait_le<32>(); break;  case 9: dma_wait_le<36>(); break;  case 10: dma_wait_le<40>(); break; case 11: dma_wait_le<44>(); break;
+        case 12: dma_wait_le<48>(); break;
+        default: dma_wait_le<52>(); break;
+    }
+}
 __device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void pinu(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
@@ -680,8 +689,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // VMODE 1 = VAUX (above); VMODE 2 = the KL objective of (Z, Y) alone -- sum x log(x / zy) [inf, nan -> 0] - x + zy, nmf/utils.py:21-26 --
     // where the objective-only form evaluates the residual: the closing objective of the KL-loss ADMM variants (r4; the exact-f32 pass
     // took 400 us at 16384 x 8192, k = 128)
-    constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2;
-    static_assert(VMODE == 0 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
+    // VMODE 3 = VAUXF (r5): the auxiliaries AND the next round's right-hand-side product in one pass -- the KL form at KP = 128 (product Z Y, the
+    // element-wise step where the accumulator stands, its result split to bf16 as the A operand of the second product) with v_aux / dual_v in the
+    // place of the quotient: S = v_aux + dual_v never goes to HBM between two rounds of a sub-problem (it is stored when the launch finds that its
+    // round is the sub-problem's last: `ng` != 0, or the round's `terminate` norms -- `objpart` points at them, `sk_workers` = their block count --
+    // pass the test that the next round's kernel will apply).  Per round X read + dual_v read and written: 3 V-sized streams instead of 5.
+    constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2, VAUXF = VMODE == 3;
+    static_assert(VMODE == 0 || VMODE == 3 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
+    static_assert(VMODE != 3 || (!WITH_OBJ && WITH_A && KL && KP == 128 && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VAUXF: the KL form at KP = 128");
     static_assert(!SK || (KP == 128 && !KL && NPROB == 1 && NW == 8 && WITH_A && ABL == 0), "stream-K: the Euclidean k = 128 products");
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
@@ -699,6 +714,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave & (NRG - 1), hh = wave / NRG;  // compute role: row group, column half
+    bool store_s = false;                              // VAUXF: this round is the sub-problem's last (wave-uniform)
+    if constexpr (VAUXF) {
+        store_s = ng != 0;
+        if (!store_s) store_s = inner_round_fired(reinterpret_cast<const double*>(objpart), sk_workers, reinterpret_cast<double*>(smem));
+    }
     const int n31 = lane & 31, b = lane >> 5;          // 32x32x16 coordinates
     const int x = lane & 15, g = lane >> 4;            // 16x16x32 coordinates (Gram by-product)
 #ifdef NMFX_EXP_BLOCKTIME
@@ -1379,10 +1399,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // tiles) on the SAME Y(grp) buffer; the two-barrier loop of the objective-free products (V slot refilled as soon as the tile is
     // in registers).  Fragment reads run one stage ahead on two register sets, D stages first, then the A stages.
     auto kl128_group = [&](int grp, VRegs& cur) {
-        if (yrole) dma_wait_le<0>();
+        if (yrole) {                                   // (VAUXF: the last group's stores and this group's dual_v loads are younger than Y(grp))
+            if constexpr (VAUXF) dma_wait_le_rt(4 + (grp > g0 ? (store_s ? 8 : 4) : 0)); else dma_wait_le<0>();
+        }
         else {
             const int ahead = min(VAHEAD - 1, g1 - 1 - grp);
-            if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
+            if constexpr (VAUXF) {
+                // vmcnt retires in order and counts the dual_v loads (4 per group, issued in the middle of the group before) and stores (4, or 8
+                // with S, in front of them) as well: younger than V(grp) are, besides V(grp + 1 ..), the loads of this and the last two groups and
+                // the stores of the last three, as far as this block has run that many
+                const int d = grp - g0;
+                dma_wait_le_rt(8 * ahead + 4 * min(d + 1, 3) + (store_s ? 8 : 4) * min(d, 3));
+            }
+            else if (ahead >= 2) dma_wait_le<16>(); else if (ahead == 1) dma_wait_le<8>(); else dma_wait_le<0>();
         }
         __syncthreads();
         if (yrole) { if (grp + 1 < g1) issue_y(); }
@@ -1435,8 +1464,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                     d = MFMA32X(fh[set][ss], zh[WITH_D ? s : 0], d);
                     d = MFMA32X(fl[set][ss], zh[WITH_D ? s : 0], d);
                     d = MFMA32X(fh[set][ss], zl[WITH_D ? s : 0], d);
-                    if (TERMS >= 4) d = MFMA32X(fl[set][ss], zl[WITH_D ? s : 0], d);
+                    if (TERMS >= 4 && !VAUXF) d = MFMA32X(fl[set][ss], zl[WITH_D ? s : 0], d);   // (VAUXF: P = Z Y with three terms, as the separate auxiliaries launch forms it)
                 }
+                if (VAUXF && u == NDK - 1) {           // v_aux, dual_v, S where the accumulator stands; S split as the second product's A operand
+                    NMFX_FENCE();
+                    // dual_v(grp): younger in the queue are only this group's V (V loaders) / Y (Y loaders) requests, 8 each
+                    if (yrole ? grp + 1 < g1 : grp + VRING < g1) dma_wait_le<8>(); else dma_wait_le<0>();
+                    vaux_update(cur);
+                    {
+                        const int64_t offp = vaux_tile(grp) + vx_priv / 4;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(vaux_dv + offp + 256 * (2 * s2 + e)) = vx_d[s2][e];
+                        if (store_s) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(vaux_s + offp + 256 * (2 * s2 + e)) = vx_s[s2][e];
+                        }
+                    }
+                    // dual_v of the NEXT group into the registers the update has just released (there is no room for a second set): in flight
+                    // through the second product, the barrier and the next product Z Y
+                    if (grp + 1 < g1) vaux_load(grp + 1, vx_cur);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) split8(vx_s[s2][0], vx_s[s2][1], cur.vh[s2], cur.vl[s2]);
+                    NMFX_FENCE();
+                } else
                 if (u == NDK - 1) {                    // quotient x / (zy + 1e-9) (v_rcp_f32) and the objective terms, as in kl_iter
                     NMFX_FENCE();
 #pragma unroll
@@ -1512,7 +1566,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < 2; ++s) split8(P.va[s][0], P.va[s][1], P.vh[s], P.vl[s]);
     }
-    if constexpr (VAUX) { if (g0 < g1) vaux_load(g0, vx_cur); }       // (behind the V requests above; the first group's waits drain it)
+    if constexpr (VAUX || VAUXF) { if (g0 < g1) vaux_load(g0, vx_cur); }       // (behind the V requests above; VAUX: the first group's waits drain it)
     // (r5) KL: the younger wave of each SIMD (4-7, the Y loaders) loses the issue arbitration and ends its sections ~300 cycles behind
     // its partner, which then waits for it at the barrier (profiles/r05_stamps_kl_cfg4.txt); a static priority for those waves: config 4
     // W phase 530.5 -> 526.5 us, H phase 451 -> 446 (same box, bit-identical results).  (The Euclidean kernels showed nothing: r2.)
@@ -2571,6 +2625,31 @@ int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2) {
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, (float*)nullptr, E->obj_part, (float*)nullptr, R,
                        (int)(ldx / 64), &E->state->flag, 1, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), E->kl_DV[side], E->kl_S[side], flag2, 0);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// r5: the auxiliaries of round r AND the right-hand-side product of round r + 1 in one launch (xyt32_bf16_kernel<..., VAUXF>; KP = 128 only):
+// slabs where nmfx_bf16_kl_product(E, side, 4) leaves them, bit for bit (same grid, same group order, S split in registers as the product
+// splits it after its LDS read).  nrm / nblk: the `terminate` partials round r's factor kernel has just written; last: r is the final round.
+int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const double* nrm, int nblk, bool last) {
+    if (E->kp != 128) { E->err = "vaux_fused: k padded to 128 only"; return NMFX_E_STATE; }
+    ProfScope ps(E, "kl_vaux_fused");
+    const float* X = side == 0 ? E->Vt : E->Vtile;
+    const int64_t ldx = side == 0 ? E->mp : E->np, R = side == 0 ? E->np : E->mp;
+    const int splits = side == 0 ? E->bt_split : E->bf_wsplit;
+    const unsigned short* Yhi = side == 0 ? E->WThi : E->Hhi;
+    const unsigned short* Ylo = side == 0 ? E->WTlo : E->Hlo;
+    const unsigned short* Zhi = side == 0 ? E->HThi : E->Whi[0];
+    const unsigned short* Zlo = side == 0 ? E->HTlo : E->Wlo[0];
+    float* Apart = side == 0 ? E->Bt_part : E->A_part;
+    if (!E->kl_S[side] || !Zhi || !Apart) { E->err = "vaux_fused: state, images or slabs missing"; return NMFX_E_STATE; }
+    const dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+    const size_t shm = 160 * 1024;
+    auto kern = xyt32_bf16_kernel<false, 4, 0, true, 128, 1, false, true, 8, false, 3>;
+    int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, Apart, const_cast<double*>(nrm), (float*)nullptr, R,
+                       (int)(ldx / 64), &E->state->flag, last ? 1 : 0, (const int4*)nullptr, (const int*)nullptr, nblk, XytSide(), E->kl_DV[side], E->kl_S[side], flag2, 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -45,3 +45,28 @@ __device__ __forceinline__ int nmfx_record_objective_pair(DevState* st, double* 
     }
     return rule;
 }
+
+// ---- inner stop test -------------------------------------------------------
+// `terminate` (ao_admm.py:33-43) on the four sums of squares: ||X - aux|| / ||X|| < 1e-2 and ||X - X_prev|| / ||U|| < 1e-2,
+// written without the square roots and divisions (~1500 cycles of f64 per test on the serial path of every round):
+// sqrt(a) / sqrt(b) < 1e-2  <=>  a < 1e-4 b for a >= 0, b > 0; b = 0 gives inf or nan on the left (false) and a < 0 on the
+// right (false); a nan makes both false.  Only sums within a rounding error of the threshold could be told apart.
+__device__ __forceinline__ bool inner_test(double a, double b, double c, double d) {
+    return (a < 1e-4 * b) && (c < 1e-4 * d);
+}
+// Sum the four norm partials of the previous round; identical in every block.
+__device__ __forceinline__ bool inner_round_fired(const double* __restrict__ part, int nblk, double* sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // wave w sums component w
+    double s = 0.0;
+    if (wave < 4)
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * 4 + wave];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0 && wave < 4) sh[wave] = s;
+    __syncthreads();
+    const bool hit = inner_test(sh[0], sh[1], sh[2], sh[3]);
+    __syncthreads();
+    return hit;
+}
+

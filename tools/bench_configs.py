@@ -23,7 +23,7 @@ from nmf_amd.synth import planted_matrix  # noqa: E402
 
 NEVER = 10 ** 12
 KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "sum_hht", "w_update", "pack",
-           "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "nnls", "small")
+           "h_update", "images", "row_sums", "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "kl_vaux_fused", "nnls", "small")
 
 
 def run(name, m, n, k, queue, finish=None, steps=20, warmup=3, init="random", flops=None, note=""):
