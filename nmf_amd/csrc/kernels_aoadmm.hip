@@ -1992,9 +1992,9 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     // ---- H sub-problem (state in the orientation of V^T) ----
     if ((rc = nmfx_bf16_kl_orient(E, 0, true))) return rc;
     if (!E->wimg_ok && (rc = nmfx_bf16_images_w(E, W, 0))) return rc;  // W^T images: Y of the products and of the auxiliaries (left by the objective pass)
-    // r5, k padded to 128: the auxiliaries of round r also form the product of round r + 1 (S stays in registers; NMFX_KL_FUSE=0: separate launches)
-    static const bool fuse_on = !(getenv("NMFX_KL_FUSE") && atoi(getenv("NMFX_KL_FUSE")) == 0);
-    const bool fuse = fuse_on && E->kp == 128;
+    // r5: the auxiliaries of round r also form the product of round r + 1 (S stays in registers; NMFX_KL_FUSE=0: separate launches).  At k padded to
+    // 64 the products' Gram by-product (W^T W, H H^T) is that of round 0's launch: the slabs stay where they are, the fixed factor does not change
+    static const bool fuse = !(getenv("NMFX_KL_FUSE") && atoi(getenv("NMFX_KL_FUSE")) == 0);
     for (int r = 0; r < admm_iter; ++r) {
         if (r == 0 || !fuse) {
             E->xyt_flag2 = r > 0 ? stop : nullptr;

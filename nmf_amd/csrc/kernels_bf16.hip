@@ -696,14 +696,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // pass the test that the next round's kernel will apply).  Per round X read + dual_v read and written: 3 V-sized streams instead of 5.
     constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2, VAUXF = VMODE == 3;
     static_assert(VMODE == 0 || VMODE == 3 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
-    static_assert(VMODE != 3 || (!WITH_OBJ && WITH_A && KL && KP == 128 && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VAUXF: the KL form at KP = 128");
+    static_assert(VMODE != 3 || (!WITH_OBJ && WITH_A && KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VAUXF: the one-register-set KL form (kl128_group, at either KP)");
     static_assert(!SK || (KP == 128 && !KL && NPROB == 1 && NW == 8 && WITH_A && ABL == 0), "stream-K: the Euclidean k = 128 products");
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
     static_assert(NW == 8 || (NW == 4 && KP == 64 && !KL && NPROB == 1 && WITH_A), "four-wave blocks: the Euclidean k = 64 products");
     constexpr int NRG = NW / 2;                        // row groups of 32 rows per block (NW = 4: 64-row blocks, two of them per CU)
-    constexpr int YR = (KL && KP == 64) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
+    constexpr int YR = (KL && KP == 64 && VMODE != 3) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL && NW == 8) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
     constexpr bool PIPE = WITH_OBJ && !KL && KP == 64 && WITH_A;
     constexpr bool EARLY = !PIPE;
-    constexpr int VAHEAD = (KL && KP == 64) ? 2 : VRING;   // groups requested before the loop
+    constexpr int VAHEAD = (KL && KP == 64 && VMODE != 3) ? 2 : VRING;   // groups requested before the loop
     Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
     if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
@@ -1468,8 +1468,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
                 }
                 if (VAUXF && u == NDK - 1) {           // v_aux, dual_v, S where the accumulator stands; S split as the second product's A operand
                     NMFX_FENCE();
-                    // dual_v(grp): younger in the queue are only this group's V (V loaders) / Y (Y loaders) requests, 8 each
-                    if (yrole ? grp + 1 < g1 : grp + VRING < g1) dma_wait_le<8>(); else dma_wait_le<0>();
+                    // dual_v(grp): younger in the queue are only this group's V (V loaders: 8) / Y (Y loaders: YPW) requests
+                    if (yrole) { if (grp + 1 < g1) dma_wait_le<YPW>(); else dma_wait_le<0>(); }
+                    else { if (grp + VRING < g1) dma_wait_le<8>(); else dma_wait_le<0>(); }
                     vaux_update(cur);
                     {
                         const int64_t offp = vaux_tile(grp) + vx_priv / 4;
@@ -1572,7 +1573,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // W phase 530.5 -> 526.5 us, H phase 451 -> 446 (same box, bit-identical results).  (The Euclidean kernels showed nothing: r2.)
     if (KL) { if (yrole) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     // (the same on the Euclidean forms, measured again in r5: config 5 W phase 2788 -> 2799 us, config 2 117.8 -> 120.7: not there)
-    if (KL && KP == 128) {
+    if (KL && (KP == 128 || VAUXF)) {
         for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
         osum += 0.69314718055994531 * olog;
     } else if (KL) {
@@ -2629,11 +2630,10 @@ int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2) {
     return NMFX_OK;
 }
 
-// r5: the auxiliaries of round r AND the right-hand-side product of round r + 1 in one launch (xyt32_bf16_kernel<..., VAUXF>; KP = 128 only):
+// r5: the auxiliaries of round r AND the right-hand-side product of round r + 1 in one launch (xyt32_bf16_kernel<..., VAUXF>):
 // slabs where nmfx_bf16_kl_product(E, side, 4) leaves them, bit for bit (same grid, same group order, S split in registers as the product
 // splits it after its LDS read).  nrm / nblk: the `terminate` partials round r's factor kernel has just written; last: r is the final round.
 int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const double* nrm, int nblk, bool last) {
-    if (E->kp != 128) { E->err = "vaux_fused: k padded to 128 only"; return NMFX_E_STATE; }
     ProfScope ps(E, "kl_vaux_fused");
     const float* X = side == 0 ? E->Vt : E->Vtile;
     const int64_t ldx = side == 0 ? E->mp : E->np, R = side == 0 ? E->np : E->mp;
@@ -2646,7 +2646,9 @@ int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const doubl
     if (!E->kl_S[side] || !Zhi || !Apart) { E->err = "vaux_fused: state, images or slabs missing"; return NMFX_E_STATE; }
     const dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
     const size_t shm = 160 * 1024;
-    auto kern = xyt32_bf16_kernel<false, 4, 0, true, 128, 1, false, true, 8, false, 3>;
+    auto k64 = xyt32_bf16_kernel<false, 4, 0, true, 64, 1, false, true, 8, false, 3>;
+    auto k128 = xyt32_bf16_kernel<false, 4, 0, true, 128, 1, false, true, 8, false, 3>;
+    auto kern = E->kp == 64 ? k64 : k128;
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldx, Zhi, Zlo, Apart, const_cast<double*>(nrm), (float*)nullptr, R,
                        (int)(ldx / 64), &E->state->flag, last ? 1 : 0, (const int4*)nullptr, (const int*)nullptr, nblk, XytSide(), E->kl_DV[side], E->kl_S[side], flag2, 0);

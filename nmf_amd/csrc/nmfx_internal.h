@@ -242,7 +242,7 @@ bool nmfx_sk_enabled(const nmfx_engine* E);
 int nmfx_bf16_kl_state(nmfx_engine* E, bool reset);
 int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv);
 int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2 = nullptr);
-int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const double* nrm, int nblk, bool last);   // + the next round's product (r5, k padded to 128)
+int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const double* nrm, int nblk, bool last);   // + the next round's product (r5)
 int nmfx_bf16_kl_objective(nmfx_engine* E);      // obj_part <- KL(V, W H) from the images of W[0] (buffer 0) and H; E->obj_count entries
 int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2 = nullptr);
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);

@@ -52,8 +52,9 @@ CASES = [
     # r4: the KL-loss variants run their V-sized products, auxiliaries and objective on the split-bf16 kernels; the exact-f32 launches
     ({"NMFX_KL_BF16": "0"}, "ao_admm", (384, 320, 40), dict(distance_type="kl", reg_w=[0, "nn"], reg_h=[0.02, "l1n"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_KL_BF16": "0"}, "admm", (384, 320, 100), dict(rho=1.0, distance_type="kl", reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
-    # r5: at k padded to 128 the auxiliaries launch of a round also forms the next round's right-hand-side product; the separate launches
+    # r5: the auxiliaries launch of a round also forms the next round's right-hand-side product; the separate launches
     ({"NMFX_KL_FUSE": "0"}, "ao_admm", (384, 320, 100), dict(distance_type="kl", reg_w=[0, "nn"], reg_h=[0.02, "l1n"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_KL_FUSE": "0"}, "ao_admm", (384, 320, 40), dict(distance_type="kl", reg_w=[0.02, "l1n"], reg_h=[0, "nn"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_CINV": "0"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),      # elimination kernels only
@@ -309,7 +310,9 @@ out = []
 for (m, n, k, seed, kw) in [
         (384, 320, 100, 1, dict(reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=8, max_iter=8, admm_iter=10)),
         (256, 640, 128, 2, dict(reg_w=(0.05, "l1n"), reg_h=(0, "nn"), min_iter=5, max_iter=5, admm_iter=3)),
-        (130, 200, 70, 3, dict(reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=3, max_iter=3, admm_iter=1))]:
+        (130, 200, 70, 3, dict(reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=3, max_iter=3, admm_iter=1)),
+        (320, 256, 40, 4, dict(reg_w=(0.05, "l1n"), reg_h=(0, "nn"), min_iter=6, max_iter=6, admm_iter=8)),      # k padded to 64
+        (192, 448, 64, 5, dict(reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=4, max_iter=4, admm_iter=2))]:
     v = R.planted_matrix(m, n, 24, seed=seed, dtype=np.float32)
     res = ao_admm(v.copy(), k, distance_type="kl", nndsvd_init=(True, "zero"), **kw)
     out.append({"w": hashlib.sha1(np.ascontiguousarray(res.w).tobytes()).hexdigest(), "h": hashlib.sha1(np.ascontiguousarray(res.h).tobytes()).hexdigest(),
@@ -319,7 +322,7 @@ print(json.dumps(out))
 
 
 def test_aoadmm_kl_fused_auxiliaries_equal_the_separate_launches_bit_for_bit():
-    """r5, k padded to 128: `xyt32_bf16_kernel<..., VAUXF>` forms v_aux / dual_v of round r and, from S in registers, the right-hand-side
+    """r5, k padded to 64 or 128: `xyt32_bf16_kernel<..., VAUXF>` forms v_aux / dual_v of round r and, from S in registers, the right-hand-side
     product of round r + 1 (nmf/ao_admm.py:85-95); S is stored only in a sub-problem's last round -- the admm_iter-th, or the one whose
     `terminate` (ao_admm.py:97) fires, which the launch finds out itself.  Same grid, same order of additions: factors, objective history
     and inner counts equal those of the separate launches (NMFX_KL_FUSE=0) bit for bit -- with inner stops (the first case: counts below

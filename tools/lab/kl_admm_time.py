@@ -16,7 +16,7 @@ v = planted_matrix(m, n, min(k, 64), seed=0, dtype=np.float32)
 rs = np.random.RandomState(0)
 w0, h0 = rs.rand(m, k) + 0.01, rs.rand(k, n) / k + 0.01
 KERNELS = ("wphase", "wphase_noobj", "objective", "hphase", "gram_nt", "gram_tn", "sum_hht", "w_update", "pack", "h_update", "images",
-           "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "small", "kl_round_h", "kl_round_w", "transpose")
+           "prepare", "inner_h", "inner_w", "sums", "kl_vaux", "kl_vaux_fused", "small", "kl_round_h", "kl_round_w", "transpose")
 for name, queue in (("ao_admm kl", lambda e, f, c: e.aoadmm_run(1, 0, 0.0, 0, 0.0, T, NEVER, 1e-3, 1e-3, f, c)),
                     ("admm kl", lambda e, f, c: e.admm_run(1, 1.0, 0, 0.0, 0, 0.0, NEVER, 1e-3, 1e-3, f, c))):
     with Engine(m, n, k) as e:
