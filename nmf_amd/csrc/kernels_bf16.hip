@@ -701,9 +701,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
     static_assert(NPROB == 1 || (NPROB == 2 && KP == 128 && WITH_OBJ && !KL), "pair mode: the k = 128 W phase with its objective");
     static_assert(WITH_A || (WITH_OBJ && !KL && NPROB == 1 && ABL == 0), "without the A-product the launch must at least compute the Euclidean objective");
-    static_assert(NW == 8 || (NW == 4 && KP == 64 && !KL && NPROB == 1 && WITH_A), "four-wave blocks: the Euclidean k = 64 products");
+    static_assert(NW == 8 || (NW == 4 && KP == 64 && NPROB == 1 && WITH_A && VMODE == 0), "four-wave blocks: the k = 64 products");
+    // KL in its one-register-set form (kl128_group): KP = 128, the fused auxiliaries (VAUXF), and -- experiment NMFX_EXP_KLNW4 -- KP = 64 in four-wave blocks
+    constexpr bool KLONE = KL && (KP == 128 || VMODE == 3 || NW == 4);
     constexpr int NRG = NW / 2;                        // row groups of 32 rows per block (NW = 4: 64-row blocks, two of them per CU)
-    constexpr int YR = (KL && KP == 64 && VMODE != 3) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
+    constexpr int YR = (KL && !KLONE) ? 3 : 2;       // Y ring (KL, KP = 64: the second product runs one group behind the first)
     constexpr int YT = KP * 128, YBUF = 2 * YT, VOFF = YR * YBUF, VRING = (KP == 64 && !KL && NW == 8) ? 4 : 3, VSLOT = 8192;
     constexpr int NT = KP / 32, NTP = NT / 2;          // factor tiles of 32, pairs of them (one A stage each per k-step)
     constexpr int NK = KP / 16;                        // k-steps of the product Z Y
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     //    (read during group g - 1), so V(g + 4) goes out there: 3 groups in flight as before.
     constexpr bool PIPE = WITH_OBJ && !KL && KP == 64 && WITH_A;
     constexpr bool EARLY = !PIPE;
-    constexpr int VAHEAD = (KL && KP == 64 && VMODE != 3) ? 2 : VRING;   // groups requested before the loop
+    constexpr int VAHEAD = (KL && !KLONE) ? 2 : VRING;   // groups requested before the loop
     Frag8 zh[WITH_D ? NK : 1], zl[WITH_D ? NK : 1];    // Z^T fragments: row r0 + n31, factors 16 s + 8 b .. + 7
     if (WITH_D) {                                      // ahead of the DMAs: vmcnt retires in order, so waiting for these does not drain the stream
 #pragma unroll
@@ -1573,7 +1575,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // W phase 530.5 -> 526.5 us, H phase 451 -> 446 (same box, bit-identical results).  (The Euclidean kernels showed nothing: r2.)
     if (KL) { if (yrole) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     // (the same on the Euclidean forms, measured again in r5: config 5 W phase 2788 -> 2799 us, config 2 117.8 -> 120.7: not there)
-    if (KL && (KP == 128 || VAUXF)) {
+    if (KLONE) {
         for (int grp = g0; grp < g1; ++grp) kl128_group(grp, P);
         osum += 0.69314718055994531 * olog;
     } else if (KL) {
@@ -2316,6 +2318,14 @@ static int launch_xyt_t(nmfx_engine* E, const float* X, bool tiled, int64_t ldx,
     return NMFX_OK;
 }
 
+static bool nmfx_kl_nw4() {
+#ifdef NMFX_EXP_KLNW4
+    static const bool on = getenv("NMFX_KL_NW4") && atoi(getenv("NMFX_KL_NW4")) == 1;
+    return on;
+#else
+    return false;
+#endif
+}
 template <bool OBJ, int TERMS, bool KL = false, int KP = 64, bool WITH_A = true>
 static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R, int ngroups, int splits,
                           const unsigned short* Yhi, const unsigned short* Ylo, int64_t ldy, const unsigned short* Zhi,
@@ -2337,6 +2347,23 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
             return NMFX_OK;
         }
     }
+#ifdef NMFX_EXP_KLNW4          // experiment (r5): MUR-KL at k padded to 64 in FOUR-wave blocks of 64 rows, two per CU, in the one-register-set
+                               // form (80 KiB of LDS each: Y double buffer + V ring of 3) -- the two waves of a SIMD then belong to different workgroups, no
+                               // barrier ties them, one's VALU sections can meet the other's MFMAs.  Correct (the KL tests pass with NMFX_KL_NW4=1) and
+                               // SLOWER than the eight-wave cross-group pipeline: config 4 W phase 538 -> 588 us, H phase 414-430 -> 474-479
+                               // (profiles/r05_kl_four_wave_blocks_experiment.txt).  Not built by default.
+    if constexpr (KL && KP == 64 && TERMS == 3 && WITH_A) {
+        if (nmfx_kl_nw4()) {
+            grid = dim3((unsigned)(R / 64), (unsigned)splits); block = dim3(256); shm = 80 * 1024;
+            auto k4 = xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
+            int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
+            hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
+                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, 0);
+            NMFX_HIP(hipGetLastError());
+            return NMFX_OK;
+        }
+    }
+#endif
     if constexpr (!KL && KP == 64 && TERMS == 3) {
         // V and V^T together small enough to live in the Infinity Cache (see the kernel's TEMPORAL note; NMFX_TEMPORAL=0/1 overrides)
         static const int forced = getenv("NMFX_TEMPORAL") ? atoi(getenv("NMFX_TEMPORAL")) : -1;
@@ -2388,7 +2415,8 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
     const bool nw4 = E->xyt_nw == 4 && E->kp == 64 && !kl && tiled && gram_part && Apart && terms == 3 &&
                      !(getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1);
     if (!nw4) E->xyt_nw = 8;
-    if (obj) E->obj_count = (R / (nw4 ? 64 : 128)) * splits;
+    const bool klnw4 = kl && tiled && E->kp == 64 && terms == 3 && nmfx_kl_nw4() && !(getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1);
+    if (obj) E->obj_count = (R / ((nw4 || klnw4) ? 64 : 128)) * splits;
 #define NMFX_XYT2(KP_, OBJ_, KL_, T_) \
     launch_xyt_t<KP_, OBJ_, KL_, T_>(E, X, tiled, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, gram_part, ng)
 #define NMFX_XYT(KP_, OBJ_, KL_) (terms == 3 ? NMFX_XYT2(KP_, OBJ_, KL_, 3) : NMFX_XYT2(KP_, OBJ_, KL_, 4))

@@ -390,7 +390,7 @@ int nmfx_mur_kl_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j) {
       hipLaunchKernelGGL(col_sums_final_kernel, dim3((unsigned)((E->kp + 3) / 4)), dim3(256), 0, E->stream,
                          E->kl_part + (int64_t)(E->np / 64) * E->kp, (int)(E->mp / 64), E->kp, E->G_part, &E->state->flag);
       NMFX_HIP(hipGetLastError()); }
-    return nmfx_bf16_pack_t(E, E->G_part, 1, (int64_t)(E->mp / 128) * E->bf_wsplit);
+    return nmfx_bf16_pack_t(E, E->G_part, 1, E->obj_count);            // (the W phase's launch has set it: (mp / 128) * bf_wsplit, or mp / 64 row blocks with NMFX_KL_NW4)
 }
 
 int nmfx_mur_kl_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j) {
