@@ -80,7 +80,7 @@ CASES = [
     ({"NMFX_GX_STAGGER": "0"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
     ({"NMFX_GX_STAGGER": "16"}, "mur", (384, 256, 160), dict(distance_type="eu", min_iter=10, max_iter=10)),
     ({"NMFX_GXR": "0"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
-    ({"NMFX_GX_ANLS_BF16": "0"}, "anls", (384, 320, 160), dict(min_iter=3, max_iter=3, lambda_w=0.05, lambda_h=0.02, nndsvd_init=NNDSVD)),   # ANLS beyond 128 on the exact-f32 products
+    ({"NMFX_GX_ANLS_BF16": "0"}, "anls", (256, 192, 144), dict(min_iter=2, max_iter=2, lambda_w=0.05, lambda_h=0.02, nndsvd_init=NNDSVD)),   # ANLS beyond 128 on the exact-f32 products
     ({"NMFX_GX_ROUNDS_F32": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0, "nn"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),   # exact-f32 inner products of the any-rank rounds
     ({"NMFX_GXB_NOFIT": "1"}, "mur", (384, 256, 160), dict(distance_type="kl", min_iter=10, max_iter=10)),
     ({"NMFX_GXB_NOFIT": "1"}, "ao_admm", (384, 320, 160), dict(reg_w=[0.05, "l1n"], reg_h=[0.05, "l1n"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
