@@ -374,7 +374,7 @@ int nmfx_set_factors(nmfx_handle_t E, const double* w, const double* hmat) {
     float* zero[] = {E->dualW, E->dualH, E->auxW, E->auxH, E->S, E->DV, E->kl_S[0], E->kl_DV[0], E->kl_S[1], E->kl_DV[1]};
     const int64_t mn = E->mp * E->np;
     const int64_t zc[] = {E->mp * E->kp, E->kp * E->np, E->mp * E->kp, E->kp * E->np, mn, mn, mn, mn, mn, mn};
-    E->kl_side = 0;                                    // (split-bf16 form of the same state: zero in both orientations)
+    E->kl_side = 0; E->kl_s_side = 0;                  // (split-bf16 form of the same state: zero in both orientations)
     for (int i = 0; i < 10; ++i)
         if (zero[i]) NMFX_HIP(hipMemsetAsync(zero[i], 0, (size_t)zc[i] * 4, E->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, E->stream, E->state);

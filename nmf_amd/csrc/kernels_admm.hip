@@ -194,7 +194,10 @@ static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double
     if ((rc = nmfx_bf16_kl_state(E, false))) return rc;
     // ---- h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T S + rho (h + dual_h)) ----
     if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // (w_aux)^T images: Y
-    if ((rc = nmfx_bf16_kl_product(E, 0, 4))) return rc;
+    // r5: w_aux^T S straight from the buffer the auxiliaries write (orientation of V) through the product kernel's transposing requests;
+    // NMFX_KL_GATHER=0: from a transposed copy made at the end of every iteration
+    static const bool gather = !(getenv("NMFX_KL_GATHER") && atoi(getenv("NMFX_KL_GATHER")) == 0);
+    if ((rc = nmfx_bf16_kl_product(E, 0, 4, nullptr, E->kl_s_side == 1))) return rc;
     if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);
     else {
         if ((rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
@@ -226,8 +229,8 @@ static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double
     // ---- v_aux, dual_v from w_aux h_aux; the new S in both orientations ----
     if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // the new w_aux: Z
     if ((rc = nmfx_bf16_vaux(E, 1))) return rc;
-    E->kl_side = 1;
-    if ((rc = nmfx_bf16_kl_orient(E, 0, false))) return rc;            // (kl_S[1] stays valid: the W-side product of the next iteration reads it)
+    E->kl_s_side = 1;
+    if (!gather && (rc = nmfx_bf16_kl_orient(E, 0, false, true))) return rc;   // (kl_S[1] stays valid: the W-side product of the next iteration reads it)
     E->wimg_ok = false; E->himg_both = false;
     return admm_kl_objective_bf16(E);                                  // KL objective of (w, h) (admm.py:324)
 }

@@ -1990,7 +1990,10 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_kl_state(E, false))) return rc;
     // ---- H sub-problem (state in the orientation of V^T) ----
-    if ((rc = nmfx_bf16_kl_orient(E, 0, true))) return rc;
+    // r5: the first product of a sub-problem reads S where the other sub-problem's auxiliaries left it (transposing requests, NMFX_KL_GATHER=0:
+    // a transposed copy as before); only dual_v changes orientation between the sub-problems
+    static const bool gather = !(getenv("NMFX_KL_GATHER") && atoi(getenv("NMFX_KL_GATHER")) == 0);
+    if ((rc = nmfx_bf16_kl_orient(E, 0, true, !gather))) return rc;
     if (!E->wimg_ok && (rc = nmfx_bf16_images_w(E, W, 0))) return rc;  // W^T images: Y of the products and of the auxiliaries (left by the objective pass)
     // r5: the auxiliaries of round r also form the product of round r + 1 (S stays in registers; NMFX_KL_FUSE=0: separate launches).  At k padded to
     // 64 the products' Gram by-product (W^T W, H H^T) is that of round 0's launch: the slabs stay where they are, the fixed factor does not change
@@ -1998,7 +2001,7 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     for (int r = 0; r < admm_iter; ++r) {
         if (r == 0 || !fuse) {
             E->xyt_flag2 = r > 0 ? stop : nullptr;
-            rc = nmfx_bf16_kl_product(E, 0, 4);                        // B^T slabs = S^T W (FOUR terms: with three the KL objective history left its 5e-5 bar -- 1.2e-4 at k = 64, the objective near its optimum is 1e-5 of sum V)
+            rc = nmfx_bf16_kl_product(E, 0, 4, nullptr, r == 0 && E->kl_s_side != 0);   // B^T slabs = S^T W (FOUR terms: with three the KL objective history left its 5e-5 bar -- 1.2e-4 at k = 64, the objective near its optimum is 1e-5 of sum V)
             E->xyt_flag2 = nullptr;
             if (rc) return rc;
         }
@@ -2015,9 +2018,10 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
         else rc = nmfx_bf16_vaux(E, 0, stop);
         if (rc) return rc;
     }
+    if (admm_iter > 0) E->kl_s_side = 0;                               // (the last round's auxiliaries have stored S in this orientation)
     if ((rc = nmfx_inner_finish(E, (int)(E->np / 64), admm_iter, E->inner_hist + j * 2))) return rc;
     // ---- W sub-problem (transposed data: the orientation of V) ----
-    if ((rc = nmfx_bf16_kl_orient(E, 1, true))) return rc;
+    if ((rc = nmfx_bf16_kl_orient(E, 1, true, !gather))) return rc;
     if ((rc = nmfx_bf16_images_h(E, false))) return rc;                // H images: Y
     if ((rc = nmfx_launch_gram_nt(E, E->H, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
@@ -2025,7 +2029,7 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
     for (int r = 0; r < admm_iter; ++r) {
         if (r == 0 || !fuse) {
             E->xyt_flag2 = r > 0 ? stop : nullptr;
-            rc = nmfx_bf16_kl_product(E, 1, 4);                        // A slabs = S H^T
+            rc = nmfx_bf16_kl_product(E, 1, 4, nullptr, r == 0 && E->kl_s_side != 1);   // A slabs = S H^T
             E->xyt_flag2 = nullptr;
             if (rc) return rc;
         }
@@ -2036,6 +2040,7 @@ static int aoadmm_kl_iteration_bf16(nmfx_engine* E, int prox_w, double lam_w, in
         else rc = nmfx_bf16_vaux(E, 1, stop);
         if (rc) return rc;
     }
+    if (admm_iter > 0) E->kl_s_side = 1;
     if ((rc = nmfx_inner_finish(E, (int)(E->mp / 64), admm_iter, E->inner_hist + j * 2 + 1))) return rc;
     E->himg_both = false;
     return ao_kl_objective(E);                                         // KL objective of the new pair (utils.py:21-26)

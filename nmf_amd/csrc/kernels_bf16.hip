@@ -777,7 +777,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     const int gfirst = SK ? sk_start : rev ? g1 - 1 : g0;
     int y_left = g1 - gfirst, v_left = g1 - gfirst;     // (SK) requests until the wrap back to group g0
     const long long span_y = (long long)(g1 - g0) * 128ll, span_v = (long long)(g1 - g0) * 32768ll;
-    const long long ystep = rev ? -128ll : 128ll, vstep = rev ? -32768ll : 32768ll;
+    const long long ystep = rev ? -128ll : 128ll;
+    long long vstep = rev ? -32768ll : 32768ll, vstep2 = vstep;      // (xpriv = 2: the steps alternate; they are swapped after every group's requests)
     unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)gfirst * 128ull;
     unsigned yoffs[YPW];
 #pragma unroll
@@ -800,6 +801,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) voffs[t] = (unsigned)(t * 1024 + lane * 16);
     }
+    if (xpriv == 2) {
+        // X in the tiles of the OTHER orientation (rows there = columns here), in their register order: S as the auxiliaries kernel of the other
+        // sub-problem left it -- the first product of a sub-problem needs no transposed copy (r5).  Row group lw of this block is column half
+        // hhB = lw & 1 of the other side's column group 2 bx + (lw >> 1); this kernel's group g is the half g & 1 of the other side's row block
+        // g >> 1, i.e. its row groups 2 (g & 1), 2 (g & 1) + 1.  The LDS slot is [64 columns c][32 rows] f32: request p (0..7), lane i fetches the
+        // 16 bytes of (c = 8 p + (i >> 3), rows 4 (i & 7) ..) from piece w = 2 (g & 1) + (p >> 2) + 4 hhB, j = 2 s + e, lane (c & 31) + 32 bb, where
+        // 4 (i & 7) = 16 s + 8 bb + 4 e -- eight runs of 128 bytes per request; read_va takes its four columns with four ds_read_b32
+        const unsigned long long tilesB = (unsigned long long)(R / 64);
+        vbaseA = (unsigned long long)X + ((unsigned long long)(gfirst >> 1) * tilesB + 2 * bx + (lw >> 1)) * 32768ull + 16384ull * (lw & 1) + 8192ull * (gfirst & 1);
+        vbaseB = vbaseA + 4096;
+        const int i7 = lane & 7, s_ = i7 >> 2, bb = (i7 >> 1) & 1, e_ = i7 & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) voffs[t] = (unsigned)((2 * s_ + e_) * 1024 + ((lane >> 3) + 32 * bb) * 16 + t * 128);
+        const long long even = 8192ll, odd = (long long)tilesB * 32768ll - 8192ll;
+        vstep = (gfirst & 1) ? odd : even; vstep2 = (gfirst & 1) ? even : odd;
+    }
     const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
     const unsigned vdstA = smem0 + VOFF + lw * (VRING * VSLOT), vdstB = vdstA + 4096;
     int yq = 0, vq = 0;
@@ -821,13 +838,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #else
             (TEMPORAL ? dma_run2 : dma_run2_nt)(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
 #endif
-            if (st == 3) { vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1); }
+            if (st == 3) { vbaseA += vstep; vbaseB += vstep; { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
+                           vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1); }
         }
     };
     auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
-        vbaseA += vstep; vbaseB += vstep; vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1);
+        vbaseA += vstep; vbaseB += vstep; { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
+        vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1);
         if (SK && --v_left == 0) { vbaseA -= span_v; vbaseB -= span_v; }
     };
 
@@ -836,7 +855,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) vaoff[s][e] = xpriv ? ((4 * hh + 2 * s + e) * 64 + lane) * 16 : n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
+        for (int e = 0; e < 2; ++e) vaoff[s][e] = xpriv == 2 ? 4 * (8 * hh + 4 * s + 2 * b + e) * 128 + n31 * 4
+                                                : xpriv ? ((4 * hh + 2 * s + e) * 64 + lane) * 16 : n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
         yrow[s] = n31 * 128 + 16 * ((4 * hh + 2 * s + b) ^ yswz32(n31));          // + 4096 * (factor tile) + YT * (lo image)
         ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz32(x));                       // + 2048 * (16-factor tile)
     }
@@ -941,7 +961,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
+            for (int e = 0; e < 2; ++e) {
+                if (xpriv == 2) {                      // (slot [column][row]: the lane's four columns are 128 bytes apart; conflict free, 32 consecutive words per half wave)
+                    const float* q_ = reinterpret_cast<const float*>(vt + vaoff[s][e]);
+                    va[s][e] = make_float4(q_[0], q_[32], q_[64], q_[96]);
+                } else va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
+            }
     };
     // VAUX: the lane's 16 elements of a group -- row n31 of its row group, 16-byte chunks 8 hh + 4 s + 2 b + e -- of dual_v (in) and
     // of the new S / dual_v (out), at the positions of the tile-major X.  The loads are inline asm: hipcc does not count the LDS-DMA
@@ -2342,7 +2367,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
                                                              : xyt32_bf16_kernel<OBJ, TERMS, 0, KL, KP, 1, false, WITH_A, 4>;
             int rc4 = nmfx_allow_lds(E, reinterpret_cast<const void*>(k4), (int)shm); if (rc4) return rc4;
             hipLaunchKernelGGL(k4, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv ? 1 : 0);
+                               gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv);
             NMFX_HIP(hipGetLastError());
             return NMFX_OK;
         }
@@ -2400,7 +2425,7 @@ static int launch_xyt32_t(nmfx_engine* E, const float* X, int64_t ldx, int64_t R
 #endif
     int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, block, shm, E->stream, X, ldx, Yhi, Ylo, ldy, Zhi, Zlo, Apart, E->obj_part,
-                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv ? 1 : 0);
+                       gram_part, R, ngroups, &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr, E->xyt_flag2, E->xyt_xpriv);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -2433,7 +2458,8 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
     }
     if (E->kp == 64) {
         // k padded to 64: the 32-row kernel (NMFX_XYT16=1 keeps the 16-row form, for A/B runs)
-        static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        static const bool rows16_env = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        const bool rows16 = rows16_env && !E->xyt_xpriv;      // (an X in the auxiliaries' register order is only read by the 32-row kernel)
         if (kl && tiled && !rows16) {
 #define NMFX_X32K(OBJ_, T_) launch_xyt32_t<OBJ_, T_, true>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, nullptr, ng)
             if (terms == 3) return obj ? NMFX_X32K(true, 3) : NMFX_X32K(false, 3);
@@ -2460,7 +2486,8 @@ static int launch_xyt(nmfx_engine* E, bool obj, const float* X, bool tiled, int6
         return obj ? NMFX_XYT(128, true, true) : NMFX_XYT(128, false, true);
     }
     {   // Euclidean products with k padded to 128: the 32-row kernel as well (NMFX_XYT16=1: the 16-row form)
-        static const bool rows16 = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        static const bool rows16_env = getenv("NMFX_XYT16") && atoi(getenv("NMFX_XYT16")) == 1;
+        const bool rows16 = rows16_env && !E->xyt_xpriv;
         if (tiled && !rows16) {
 #define NMFX_X32B(OBJ_, T_) launch_xyt32_t<OBJ_, T_, false, 128>(E, X, ldx, R, ngroups, splits, Yhi, Ylo, ldy, Zhi, Zlo, Apart, nullptr, ng)
             if (terms == 3) return obj ? NMFX_X32B(true, 3) : NMFX_X32B(false, 3);
@@ -2614,23 +2641,28 @@ int nmfx_bf16_kl_state(nmfx_engine* E, bool reset) {
             NMFX_HIP(hipMemsetAsync(E->kl_S[i], 0, (size_t)cnt * sizeof(float), E->stream));
             NMFX_HIP(hipMemsetAsync(E->kl_DV[i], 0, (size_t)cnt * sizeof(float), E->stream));
         }
-        E->kl_side = 0;
+        E->kl_side = 0; E->kl_s_side = 0;
     }
     return NMFX_OK;
 }
 
-// bring the state into the orientation of `side` (a no-op when it is there)
-int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv) {
-    if (E->kl_side == side) return NMFX_OK;
+// bring the state into the orientation of `side` (a no-op for what is there): S (with_s) from the side that holds it (kl_s_side), dual_v
+// (with_dv) from kl_side.  r5: a sub-problem's first product can read S from the other orientation's tiles (nmfx_bf16_kl_product, gather),
+// so the AO-ADMM loop only moves dual_v and the ADMM loop nothing
+int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv, bool with_s) {
+    const bool do_s = with_s && E->kl_s_side != side, do_dv = with_dv && E->kl_side != side;
+    if (!do_s && !do_dv) return NMFX_OK;
     ProfScope ps(E, "transpose");
-    const int from = E->kl_side;
+    const int from = 1 - side;
     const int64_t R = from == 0 ? E->np : E->mp, C = from == 0 ? E->mp : E->np;
     const dim3 grid((unsigned)(C / 64), (unsigned)(R / 64));
-    hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
-    if (with_dv)
+    if (do_s)
+        hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_S[from], R, C, E->kl_S[side], &E->state->flag);
+    if (do_dv)
         hipLaunchKernelGGL(tile_transpose_kernel<true>, grid, dim3(256), 0, E->stream, (const float*)E->kl_DV[from], R, C, E->kl_DV[side], &E->state->flag);
     NMFX_HIP(hipGetLastError());
-    E->kl_side = side;
+    if (do_s) E->kl_s_side = side;
+    if (do_dv) E->kl_side = side;
     return NMFX_OK;
 }
 
@@ -2702,18 +2734,21 @@ int nmfx_bf16_kl_objective(nmfx_engine* E) {
     return NMFX_OK;
 }
 
-// the two right-hand-side products with S in the place of V (slabs as nmfx_bf16_vtw / nmfx_bf16_vht leave them; no objective)
-int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2) {
+// the two right-hand-side products with S in the place of V (slabs as nmfx_bf16_vtw / nmfx_bf16_vht leave them; no objective).
+// gather (r5): S is read from the OTHER orientation's buffer through the transposing request pattern of xyt32_bf16_kernel (xpriv = 2) --
+// the same operand values in the same order as from a transposed copy, hence the same slabs bit for bit, without the V-sized transpose
+int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2, bool gather) {
     (void)flag2;       // (a product behind the inner stop is wasted work, not a wrong result: its consumers are no-ops)
-    E->xyt_xpriv = true;                               // S lies in the auxiliaries kernel's register order (r5)
+    E->xyt_xpriv = gather ? 2 : 1;                     // S lies in the auxiliaries kernel's register order (r5)
+    const float* S = E->kl_S[gather ? 1 - side : side];
     int rc;
     if (side == 0)
-        rc = launch_xyt(E, false, E->kl_S[0], true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
+        rc = launch_xyt(E, false, S, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
                         E->Bt_part, E->kp == 64 ? E->G_part : nullptr, "hphase", false, E->gram_ng_h, terms);
     else
-        rc = launch_xyt(E, false, E->kl_S[1], true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
+        rc = launch_xyt(E, false, S, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
                         E->A_part, E->kp == 64 ? E->HHt_part : nullptr, "wphase_noobj", false, E->gram_ng_w, terms);
-    E->xyt_xpriv = false;
+    E->xyt_xpriv = 0;
     return rc;
 }
 

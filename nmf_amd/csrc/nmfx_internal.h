@@ -118,7 +118,8 @@ struct nmfx_engine {
     float* Asum = nullptr;         // [mp][kp] summed V H^T (ADMM)
     float* S = nullptr; float* DV = nullptr;    // [mp][np] KL-ADMM: v_aux + dual_v, dual_v
     float* kl_S[2] = {nullptr, nullptr}; float* kl_DV[2] = {nullptr, nullptr};   // ... split-bf16 form (r4): tile-major, [0] rows n (like Vt), [1] rows m (like Vtile)
-    int kl_side = 0;               // the orientation that holds the current state
+    int kl_side = 0;               // the orientation that holds the current dual_v
+    int kl_s_side = 0;             // ... and the one whose buffer holds the current S = v_aux + dual_v
     // split-bf16 mode (kernels_bf16.hip): V^T and bf16 hi/lo images of the factors
     int precision = 0;             // 0 = f32 MFMA, 1 = split bf16 (k padded to 64 only)
     bool bf_ready = false;
@@ -128,7 +129,7 @@ struct nmfx_engine {
     int gram_ng_w = 1, gram_ng_h = 1;   // row blocks sharing the Gram by-product of the W / H phase (kp = 64)
     int64_t obj_count = 0;         // entries of obj_part the last objective-producing launch wrote
     const int* xyt_flag2 = nullptr;  // a second skip flag for the next 32-row product launches (the inner stop of a KL-ADMM sub-problem)
-    bool xyt_xpriv = false;          // the next 32-row product launches read an X that lies in the KL auxiliaries' register order (kl_dv_pos)
+    int xyt_xpriv = 0;                // the next 32-row product launches read an X that lies in the KL auxiliaries' register order (kl_dv_pos)
     int xyt_nw = 8;                // waves per block of the next 32-row product launch (4: 64-row blocks, two per CU; set and reset by the caller)
     int ao_a_slabs = 0;            // AO-ADMM W side: slabs of A_part the fused inner kernel adds itself (0: auxW holds the sum)
     const float* ao_b_src = nullptr; const int* ao_b_cnt = nullptr;   // AO-ADMM H side, behind a stream-K product: B^T slabs the fused rounds sum themselves (+ what their first launch records)
@@ -240,11 +241,11 @@ int nmfx_bf16_pack_sk(nmfx_engine* E, int64_t j, int64_t min_iter, double tol1, 
 bool nmfx_sk_enabled(const nmfx_engine* E);
 // KL-loss ADMM variants on the split-bf16 kernels (kernels_bf16.hip, r4)
 int nmfx_bf16_kl_state(nmfx_engine* E, bool reset);
-int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv);
+int nmfx_bf16_kl_orient(nmfx_engine* E, int side, bool with_dv, bool with_s = true);
 int nmfx_bf16_vaux(nmfx_engine* E, int side, const int* flag2 = nullptr);
 int nmfx_bf16_vaux_fused(nmfx_engine* E, int side, const int* flag2, const double* nrm, int nblk, bool last);   // + the next round's product (r5)
 int nmfx_bf16_kl_objective(nmfx_engine* E);      // obj_part <- KL(V, W H) from the images of W[0] (buffer 0) and H; E->obj_count entries
-int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2 = nullptr);
+int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2 = nullptr, bool gather = false);
 int nmfx_mur_eu_phase_a_bf16(nmfx_engine* E, double lambda_w, int64_t j);
 int nmfx_mur_eu_phase_b_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j);
 int nmfx_mur_eu_phase_b_slice_bf16(nmfx_engine* E, double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t j, int cb0, int nblk);

@@ -55,6 +55,7 @@ CASES = [
     # r5: the auxiliaries launch of a round also forms the next round's right-hand-side product; the separate launches
     ({"NMFX_KL_FUSE": "0"}, "ao_admm", (384, 320, 100), dict(distance_type="kl", reg_w=[0, "nn"], reg_h=[0.02, "l1n"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_KL_FUSE": "0"}, "ao_admm", (384, 320, 40), dict(distance_type="kl", reg_w=[0.02, "l1n"], reg_h=[0, "nn"], min_iter=4, max_iter=4, admm_iter=6, nndsvd_init=NNDSVD)),
+    ({"NMFX_KL_GATHER": "0"}, "admm", (384, 320, 100), dict(rho=1.0, distance_type="kl", reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=5, max_iter=5, nndsvd_init=NNDSVD)),
     ({"NMFX_AO_ROWS_RB": "128"}, "ao_admm", (384, 320, 100), dict(reg_w=[0, "nn"], reg_h=[0, "nn"], min_iter=6, max_iter=6, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_LDS": "1"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),
     ({"NMFX_NNLS_CINV": "0"}, "anls", (320, 256, 40), dict(min_iter=4, max_iter=4, nndsvd_init=NNDSVD)),      # elimination kernels only
@@ -306,34 +307,42 @@ os.environ["NMF_AMD_QUIET"] = "1"
 import numpy as np
 from oracle import nmf_ref as R
 from nmf_amd.ao_admm import ao_admm
+from nmf_amd.admm import admm
 out = []
 for (m, n, k, seed, kw) in [
         (384, 320, 100, 1, dict(reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=8, max_iter=8, admm_iter=10)),
         (256, 640, 128, 2, dict(reg_w=(0.05, "l1n"), reg_h=(0, "nn"), min_iter=5, max_iter=5, admm_iter=3)),
         (130, 200, 70, 3, dict(reg_w=(0, "nn"), reg_h=(0, "nn"), min_iter=3, max_iter=3, admm_iter=1)),
         (320, 256, 40, 4, dict(reg_w=(0.05, "l1n"), reg_h=(0, "nn"), min_iter=6, max_iter=6, admm_iter=8)),      # k padded to 64
-        (192, 448, 64, 5, dict(reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=4, max_iter=4, admm_iter=2))]:
+        (192, 448, 64, 5, dict(reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=4, max_iter=4, admm_iter=2)),
+        (200, 520, 90, 6, dict(rho=1.0, reg_w=(0, "nn"), reg_h=(0.02, "l1n"), min_iter=6, max_iter=6)),           # no admm_iter: admm.py's loop
+        (448, 192, 30, 7, dict(rho=2.0, reg_w=(0.05, "l1n"), reg_h=(0, "nn"), min_iter=5, max_iter=5))]:
     v = R.planted_matrix(m, n, 24, seed=seed, dtype=np.float32)
-    res = ao_admm(v.copy(), k, distance_type="kl", nndsvd_init=(True, "zero"), **kw)
+    fn = ao_admm if "admm_iter" in kw else admm
+    res = fn(v.copy(), k, distance_type="kl", nndsvd_init=(True, "zero"), **kw)
     out.append({"w": hashlib.sha1(np.ascontiguousarray(res.w).tobytes()).hexdigest(), "h": hashlib.sha1(np.ascontiguousarray(res.h).tobytes()).hexdigest(),
-                "obj": [float(x) for x in res.obj_history], "inner": [list(map(int, t)) for t in ao_admm.last_inner_counts]})
+                "obj": [float(x) for x in res.obj_history], "inner": [list(map(int, t)) for t in ao_admm.last_inner_counts] if fn is ao_admm else []})
 print(json.dumps(out))
 '''
 
 
-def test_aoadmm_kl_fused_auxiliaries_equal_the_separate_launches_bit_for_bit():
-    """r5, k padded to 64 or 128: `xyt32_bf16_kernel<..., VAUXF>` forms v_aux / dual_v of round r and, from S in registers, the right-hand-side
-    product of round r + 1 (nmf/ao_admm.py:85-95); S is stored only in a sub-problem's last round -- the admm_iter-th, or the one whose
-    `terminate` (ao_admm.py:97) fires, which the launch finds out itself.  Same grid, same order of additions: factors, objective history
-    and inner counts equal those of the separate launches (NMFX_KL_FUSE=0) bit for bit -- with inner stops (the first case: counts below
-    admm_iter), with admm_iter reached every time, and with a single round per sub-problem."""
+def test_kl_admm_fused_auxiliaries_and_gathered_products_equal_the_separate_launches_bit_for_bit():
+    """r5.  (a) AO-ADMM with the KL loss, k padded to 64 or 128: `xyt32_bf16_kernel<..., VAUXF>` forms v_aux / dual_v of round r and, from S in
+    registers, the right-hand-side product of round r + 1 (nmf/ao_admm.py:85-95); S is stored only in a sub-problem's last round -- the
+    admm_iter-th, or the one whose `terminate` (ao_admm.py:97) fires, which the launch finds out itself.  (b) Both KL-loss ADMM variants: the
+    first product of a sub-problem (ADMM: w_aux^T S of every iteration, nmf/admm.py:303) reads S from the other orientation's buffer through
+    transposing requests instead of from a transposed copy.  Same grids, same operand values, same order of additions: factors, objective
+    history and inner counts equal those of the separate launches (NMFX_KL_FUSE=0) and of the transposed copies (NMFX_KL_GATHER=0) bit for
+    bit -- with inner stops (the first case: counts below admm_iter), with admm_iter reached every time, with a single round per sub-problem."""
     runs = {}
-    for fuse in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", CHILD_KLFUSE % {"root": ROOT}], env=dict(os.environ, NMF_AMD_NO_TORCH="1", NMFX_KL_FUSE=fuse),
+    for tag, env in (("default", {}), ("separate", {"NMFX_KL_FUSE": "0"}), ("copies", {"NMFX_KL_GATHER": "0"}),
+                     ("r4", {"NMFX_KL_FUSE": "0", "NMFX_KL_GATHER": "0"})):
+        out = subprocess.run([sys.executable, "-c", CHILD_KLFUSE % {"root": ROOT}], env=dict(os.environ, NMF_AMD_NO_TORCH="1", **env),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        runs[fuse] = json.loads(out.stdout.strip().splitlines()[-1])
-    assert runs["1"] == runs["0"]
-    inner = [c for t in runs["1"][0]["inner"] for c in t]
+        runs[tag] = json.loads(out.stdout.strip().splitlines()[-1])
+    for tag in ("separate", "copies", "r4"):
+        assert runs[tag] == runs["default"], tag
+    inner = [c for t in runs["default"][0]["inner"] for c in t]
     assert min(inner) < 10 <= max(inner), inner           # (the case meant to stop inside its rounds does, and not always)
-    assert all(np.isfinite(r["obj"]).all() for r in runs["1"])
+    assert all(np.isfinite(r["obj"]).all() for r in runs["default"])
