@@ -190,15 +190,21 @@ static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double
     float* W = E->W[0];
     const int64_t kk = (int64_t)E->kp * E->kp;
     const int64_t nobj32 = E->obj_count;                               // partials of the KL objective pass that closed the iteration before
+    // r5 (NMFX_KL_GATHER, default on): no transposed copy of S -- a product reads it from the buffer of the other orientation through the
+    // product kernel's transposing requests.  The auxiliaries then run in the orientation of V^T (side 0: X = V^T, Y = w_aux^T images,
+    // Z = h_aux^T images), where their launch can also form w_aux^T S, the first product of the NEXT iteration, from S in registers
+    // (NMFX_KL_FUSE, default on; w_aux does not change in between).  NMFX_KL_GATHER=0: the r4 sequence (auxiliaries in the orientation
+    // of V, S transposed at the end of every iteration).
+    static const bool gather = !(getenv("NMFX_KL_GATHER") && atoi(getenv("NMFX_KL_GATHER")) == 0);
+    static const bool fuse = gather && !(getenv("NMFX_KL_FUSE") && atoi(getenv("NMFX_KL_FUSE")) == 0);
     if ((rc = nmfx_bf16_prepare(E))) return rc;
     if ((rc = nmfx_bf16_kl_state(E, false))) return rc;
     // ---- h_aux = (w_aux^T w_aux + rho I)^-1 (w_aux^T S + rho (h + dual_h)) ----
     if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // (w_aux)^T images: Y
-    // r5: w_aux^T S straight from the buffer the auxiliaries write (orientation of V) through the product kernel's transposing requests;
-    // NMFX_KL_GATHER=0: from a transposed copy made at the end of every iteration
-    static const bool gather = !(getenv("NMFX_KL_GATHER") && atoi(getenv("NMFX_KL_GATHER")) == 0);
-    if ((rc = nmfx_bf16_kl_product(E, 0, 4, nullptr, E->kl_s_side == 1))) return rc;
-    if (E->kp == 64) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);
+    const bool have_bt = fuse && E->kl_bt_ready;                       // (left by the auxiliaries launch of the iteration before)
+    E->kl_bt_ready = false;
+    if (!have_bt && (rc = nmfx_bf16_kl_product(E, 0, 4, nullptr, E->kl_s_side != 0))) return rc;
+    if (E->kp == 64 && !gather) rc = nmfx_bf16_pack_t(E, E->G_part, nmfx_bf16_g_slabs(E), nobj32);    // (the product's Gram by-product)
     else {
         if ((rc = nmfx_launch_gram_tn(E, E->auxW, E->mp, E->G_part, E->gsplit))) return rc;
         rc = nmfx_bf16_pack_t(E, E->G_part, E->gsplit, nobj32);
@@ -213,8 +219,8 @@ static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double
         if ((rc = nmfx_launch_prox_l1inf(E, true, prox_h == NMFX_PROX_L1INF_T, rho, lam_h, 1.0, true))) return rc;
     } else if ((rc = nmfx_inner_cols(E, E->Minv, E->auxH, 0, prox_h, (float)lam_h, 0))) return rc;
     // ---- w_aux from the NEW h_aux ----
-    if ((rc = nmfx_bf16_images_h(E, false, E->auxH))) return rc;       // h_aux images: Y of the product and of the auxiliaries
-    if ((rc = nmfx_bf16_kl_product(E, 1, 4))) return rc;
+    if ((rc = nmfx_bf16_images_h(E, gather, E->auxH))) return rc;      // h_aux images: Y of the product (and, transposed, Z of the auxiliaries in the orientation of V^T)
+    if ((rc = nmfx_bf16_kl_product(E, 1, 4, nullptr, E->kl_s_side != 1))) return rc;
     if ((rc = nmfx_launch_gram_nt(E, E->auxH, E->np, E->np, E->HHt_part, E->gsplit))) return rc;
     if ((rc = nmfx_launch_sum_partials(E, E->HHt_part, E->gsplit, kk, E->HHt))) return rc;
     if ((rc = nmfx_launch_sum_partials(E, E->A_part, E->bf_wsplit, E->mp * E->kp, E->Asum))) return rc;
@@ -226,11 +232,17 @@ static int admm_kl_iteration_bf16(nmfx_engine* E, double rho, int prox_w, double
         if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 1, prox_w, (float)lam_w, 0))) return rc;
         if ((rc = nmfx_launch_prox_l1inf(E, false, prox_w == NMFX_PROX_L1INF_T, rho, lam_w, 1.0, true))) return rc;
     } else if ((rc = nmfx_inner_rows(E, E->Asum, W, E->Minv, E->auxW, 0, prox_w, (float)lam_w, 0))) return rc;
-    // ---- v_aux, dual_v from w_aux h_aux; the new S in both orientations ----
-    if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // the new w_aux: Z
-    if ((rc = nmfx_bf16_vaux(E, 1))) return rc;
-    E->kl_s_side = 1;
-    if (!gather && (rc = nmfx_bf16_kl_orient(E, 0, false, true))) return rc;   // (kl_S[1] stays valid: the W-side product of the next iteration reads it)
+    // ---- v_aux, dual_v from w_aux h_aux; the new S ----
+    if ((rc = nmfx_bf16_images_w(E, E->auxW, 0))) return rc;           // the new w_aux: Z (orientation of V) / Y (orientation of V^T)
+    if (!gather) {
+        if ((rc = nmfx_bf16_vaux(E, 1))) return rc;
+        E->kl_s_side = 1;
+        if ((rc = nmfx_bf16_kl_orient(E, 0, false, true))) return rc;  // (kl_S[1] stays valid: the W-side product of the next iteration reads it)
+    } else {
+        if (fuse) { if ((rc = nmfx_bf16_vaux_fused(E, 0, nullptr, nullptr, 0, true))) return rc; E->kl_bt_ready = true; }
+        else if ((rc = nmfx_bf16_vaux(E, 0))) return rc;
+        E->kl_s_side = 0;
+    }
     E->wimg_ok = false; E->himg_both = false;
     return admm_kl_objective_bf16(E);                                  // KL objective of (w, h) (admm.py:324)
 }
@@ -322,6 +334,7 @@ extern "C" int nmfx_admm_run(nmfx_handle_t E, int distance, double rho, int prox
                              double lambda_h, int64_t min_iter, double tol1, double tol2, int64_t first,
                              int64_t count) {
     int rc = admm_begin(E, distance, rho, prox_w, prox_h, first, count, true); if (rc) return rc;
+    E->kl_bt_ready = false;    // (slabs a fused auxiliaries launch left for this iteration are not trusted across calls)
     if (E->kp > 128)           // composed from the generic product kernel (kernels_generic.hip)
         return nmfx_generic_admm_run(E, distance, rho, prox_w, lambda_w, prox_h, lambda_h, min_iter, tol1, tol2, first, count);
     for (int64_t j = first; j < first + count; ++j) {

@@ -120,6 +120,7 @@ struct nmfx_engine {
     float* kl_S[2] = {nullptr, nullptr}; float* kl_DV[2] = {nullptr, nullptr};   // ... split-bf16 form (r4): tile-major, [0] rows n (like Vt), [1] rows m (like Vtile)
     int kl_side = 0;               // the orientation that holds the current dual_v
     int kl_s_side = 0;             // ... and the one whose buffer holds the current S = v_aux + dual_v
+    bool kl_bt_ready = false;      // ADMM-KL: Bt_part holds w_aux^T S of the coming iteration (left by the fused auxiliaries launch)
     // split-bf16 mode (kernels_bf16.hip): V^T and bf16 hi/lo images of the factors
     int precision = 0;             // 0 = f32 MFMA, 1 = split bf16 (k padded to 64 only)
     bool bf_ready = false;
