@@ -694,8 +694,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     // place of the quotient: S = v_aux + dual_v never goes to HBM between two rounds of a sub-problem (it is stored when the launch finds that its
     // round is the sub-problem's last: `ng` != 0, or the round's `terminate` norms -- `objpart` points at them, `sk_workers` = their block count --
     // pass the test that the next round's kernel will apply).  Per round X read + dual_v read and written: 3 V-sized streams instead of 5.
-    constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2, VAUXF = VMODE == 3;
-    static_assert(VMODE == 0 || VMODE == 3 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
+    // VMODE 4 = XGATHER (r5): the plain product form with X read from the tiles of the OTHER orientation (see the DMA plan).  A template mode, not
+    // an argument: as a run-time branch in read_va and in the group step it cost EVERY instantiation 5-13 % (config 2 W phase 117 -> 128 us, H phase
+    // 88 -> 100, config 5 H phase 1745 -> 1900: profiles/r05_gather_as_runtime_branch_regression.txt)
+    constexpr bool VAUX = VMODE == 1, KLOBJ = VMODE == 2, VAUXF = VMODE == 3, XGATHER = VMODE == 4;
+    static_assert(VMODE != 4 || (!WITH_OBJ && WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "XGATHER: the objective-free Euclidean product form");
+    static_assert(VMODE == 0 || VMODE == 3 || VMODE == 4 || (WITH_OBJ && !WITH_A && !KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VMODE: the objective-only form of the kernel");
     static_assert(VMODE != 3 || (!WITH_OBJ && WITH_A && KL && NPROB == 1 && NW == 8 && !SK && ABL == 0), "VAUXF: the one-register-set KL form (kl128_group, at either KP)");
     static_assert(!SK || (KP == 128 && !KL && NPROB == 1 && NW == 8 && WITH_A && ABL == 0), "stream-K: the Euclidean k = 128 products");
     static_assert(KP == 64 || (KP == 128 && ABL == 0), "KP = 64 or 128");
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     int y_left = g1 - gfirst, v_left = g1 - gfirst;     // (SK) requests until the wrap back to group g0
     const long long span_y = (long long)(g1 - g0) * 128ll, span_v = (long long)(g1 - g0) * 32768ll;
     const long long ystep = rev ? -128ll : 128ll;
-    long long vstep = rev ? -32768ll : 32768ll, vstep2 = vstep;      // (xpriv = 2: the steps alternate; they are swapped after every group's requests)
+    long long vstep = rev ? -32768ll : 32768ll, vstep2 = vstep;      // (XGATHER: the steps alternate; they are swapped after every group's requests)
     unsigned long long ybase = (unsigned long long)ysrc + (unsigned long long)gfirst * 128ull;
     unsigned yoffs[YPW];
 #pragma unroll
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
     unsigned voffs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const int row = 4 * t + g; voffs[t] = (unsigned)((row * 64 + 4 * (x ^ row)) * 4); }   // rows 4t+g (< 16): row & 15 = row
-    if (xpriv) {
+    if (xpriv && !XGATHER) {
         // X in the auxiliaries kernel's register order (kl_dv_pos): the KiB of piece j of wave w = row group + 4 hh is what wave (row group, hh)
         // of THIS kernel wants in its va[j >> 1][j & 1], lane for lane.  So the pieces travel whole (a contiguous KiB per request instead of
         // 4 rows x 256 B) and stay in that order in the LDS slot: [hh][j][lane] float4s, read back with one conflict-free ds_read_b128 each
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) voffs[t] = (unsigned)(t * 1024 + lane * 16);
     }
-    if (xpriv == 2) {
+    if constexpr (XGATHER) {
         // X in the tiles of the OTHER orientation (rows there = columns here), in their register order: S as the auxiliaries kernel of the other
         // sub-problem left it -- the first product of a sub-problem needs no transposed copy (r5).  Row group lw of this block is column half
         // hhB = lw & 1 of the other side's column group 2 bx + (lw >> 1); this kernel's group g is the half g & 1 of the other side's row block
@@ -838,14 +842,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #else
             (TEMPORAL ? dma_run2 : dma_run2_nt)(st < 2 ? vbaseA : vbaseB, (st < 2 ? vdstA : vdstB) + vq * VSLOT + (st & 1) * 2048, voffs[2 * (st & 1)], voffs[2 * (st & 1) + 1]);
 #endif
-            if (st == 3) { vbaseA += vstep; vbaseB += vstep; { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
+            if (st == 3) { vbaseA += vstep; vbaseB += vstep; if constexpr (XGATHER) { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
                            vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1); }
         }
     };
     auto issue_v = [&]() {      // rows 16..31 of the tile: same lane offsets (row & 15 repeats), base + 16 rows
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseA, vdstA + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
         (TEMPORAL ? dma_run4 : dma_run4_nt)(vbaseB, vdstB + vq * VSLOT, voffs[0], voffs[1], voffs[2], voffs[3]);
-        vbaseA += vstep; vbaseB += vstep; { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
+        vbaseA += vstep; vbaseB += vstep; if constexpr (XGATHER) { const long long t_ = vstep; vstep = vstep2; vstep2 = t_; }
         vq = (NW == 4) ? vq + 1 - 3 * (vq >> 1) : ((vq == VRING - 1) ? 0 : vq + 1);
         if (SK && --v_left == 0) { vbaseA -= span_v; vbaseB -= span_v; }
     };
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) vaoff[s][e] = xpriv == 2 ? 4 * (8 * hh + 4 * s + 2 * b + e) * 128 + n31 * 4
+        for (int e = 0; e < 2; ++e) vaoff[s][e] = XGATHER ? 4 * (8 * hh + 4 * s + 2 * b + e) * 128 + n31 * 4
                                                 : xpriv ? ((4 * hh + 2 * s + e) * 64 + lane) * 16 : n31 * 256 + 16 * ((8 * hh + 4 * s + 2 * b + e) ^ (n31 & 15));
         yrow[s] = n31 * 128 + 16 * ((4 * hh + 2 * s + b) ^ yswz32(n31));          // + 4096 * (factor tile) + YT * (lo image)
         ylane[s] = x * 128 + 16 * ((4 * s + g) ^ yswz32(x));                       // + 2048 * (16-factor tile)
@@ -962,7 +966,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xyt32_bf16_kernel(
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                if (xpriv == 2) {                      // (slot [column][row]: the lane's four columns are 128 bytes apart; conflict free, 32 consecutive words per half wave)
+                if constexpr (XGATHER) {               // (slot [column][row]: the lane's four columns are 128 bytes apart; conflict free, 32 consecutive words per half wave)
                     const float* q_ = reinterpret_cast<const float*>(vt + vaoff[s][e]);
                     va[s][e] = make_float4(q_[0], q_[32], q_[64], q_[96]);
                 } else va[s][e] = *reinterpret_cast<const float4*>(vt + vaoff[s][e]);
@@ -2735,19 +2739,37 @@ int nmfx_bf16_kl_objective(nmfx_engine* E) {
 }
 
 // the two right-hand-side products with S in the place of V (slabs as nmfx_bf16_vtw / nmfx_bf16_vht leave them; no objective).
-// gather (r5): S is read from the OTHER orientation's buffer through the transposing request pattern of xyt32_bf16_kernel (xpriv = 2) --
+// gather (r5): S is read from the OTHER orientation's buffer through the transposing request pattern of xyt32_bf16_kernel (VMODE 4, XGATHER) --
 // the same operand values in the same order as from a transposed copy, hence the same slabs bit for bit, without the V-sized transpose
 int nmfx_bf16_kl_product(nmfx_engine* E, int side, int terms, const int* flag2, bool gather) {
     (void)flag2;       // (a product behind the inner stop is wasted work, not a wrong result: its consumers are no-ops)
-    E->xyt_xpriv = gather ? 2 : 1;                     // S lies in the auxiliaries kernel's register order (r5)
     const float* S = E->kl_S[gather ? 1 - side : side];
-    int rc;
-    if (side == 0)
-        rc = launch_xyt(E, false, S, true, E->mp, E->np, (int)(E->mp / 64), E->bt_split, E->WThi, E->WTlo, E->mp, nullptr, nullptr,
-                        E->Bt_part, E->kp == 64 ? E->G_part : nullptr, "hphase", false, E->gram_ng_h, terms);
-    else
-        rc = launch_xyt(E, false, S, true, E->np, E->mp, (int)(E->np / 64), E->bf_wsplit, E->Hhi, E->Hlo, E->np, nullptr, nullptr,
-                        E->A_part, E->kp == 64 ? E->HHt_part : nullptr, "wphase_noobj", false, E->gram_ng_w, terms);
+    const int64_t ldx = side == 0 ? E->mp : E->np, R = side == 0 ? E->np : E->mp;
+    const int splits = side == 0 ? E->bt_split : E->bf_wsplit;
+    const unsigned short* Yhi = side == 0 ? E->WThi : E->Hhi;
+    const unsigned short* Ylo = side == 0 ? E->WTlo : E->Hlo;
+    float* Apart = side == 0 ? E->Bt_part : E->A_part;
+    float* gram = E->kp == 64 ? (side == 0 ? E->G_part : E->HHt_part) : nullptr;
+    const int ng = side == 0 ? E->gram_ng_h : E->gram_ng_w;
+    const char* name = side == 0 ? "hphase" : "wphase_noobj";
+    if (gather && terms == 4) {                        // the launch launch_xyt would make for these arguments, in the XGATHER form of the kernel
+        ProfScope ps(E, name);
+        E->xyt_nw = 8;
+        const dim3 grid((unsigned)(R / 128), (unsigned)splits), block(512);
+        const size_t shm = 160 * 1024;
+        auto k64 = xyt32_bf16_kernel<false, 4, 0, false, 64, 1, false, true, 8, false, 4>;
+        auto k128 = xyt32_bf16_kernel<false, 4, 0, false, 128, 1, false, true, 8, false, 4>;
+        auto kern = E->kp == 64 ? k64 : k128;
+        int rc = nmfx_allow_lds(E, reinterpret_cast<const void*>(kern), (int)shm); if (rc) return rc;
+        hipLaunchKernelGGL(kern, grid, block, shm, E->stream, S, ldx, Yhi, Ylo, ldx, (const unsigned short*)nullptr, (const unsigned short*)nullptr, Apart, E->obj_part,
+                           gram, R, (int)(ldx / 64), &E->state->flag, ng, (const int4*)nullptr, (const int*)nullptr, 0, XytSide(), (float*)nullptr, (float*)nullptr,
+                           E->xyt_flag2, 1);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
+    if (gather) { E->err = "kl_product: the gathered form is built for four terms"; return NMFX_E_ARG; }
+    E->xyt_xpriv = 1;                                  // S lies in the auxiliaries kernel's register order (r5)
+    const int rc = launch_xyt(E, false, S, true, ldx, R, (int)(ldx / 64), splits, Yhi, Ylo, ldx, nullptr, nullptr, Apart, gram, name, false, ng, terms);
     E->xyt_xpriv = 0;
     return rc;
 }
