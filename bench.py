@@ -441,10 +441,13 @@ def scaling_model(torch, dev, base_ms):
                 eng.set_factors(w0, h0)
                 eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 0, 3)
                 eng.synchronize()
+                # (as many steps as keep the timed region at the N = 2 shard's length: with 6 steps of a 0.65 ms N = 8 step the one call's fixed
+                #  cost and the ramp of the first launches read 700 us where tools/lab/shard_step_probe.py reads 623, r5)
+                nsteps = steps * world // 2
                 t0 = time.perf_counter()
-                eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 3, steps)
+                eng.mur_run_sharded(0, 0.0, 0.0, NEVER, 1e-5, 1e-5, 3, nsteps)
                 eng.synchronize()
-                step = (time.perf_counter() - t0) / steps
+                step = (time.perf_counter() - t0) / nsteps
                 _, _, n_obj = eng.state()
                 obj = eng.objectives(0, n_obj)
                 assert np.all(np.isfinite(obj)) and obj[-1] < obj[0], f"scaling_model {cfg} N={world}: bad objective history"
@@ -469,7 +472,7 @@ def scaling_model(torch, dev, base_ms):
 
 
 def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init, flops, nbytes, admm_iter=0, repeat_dist=None,
-                 precision=None, bound="hbm", check_f64=False):
+                 precision=None, bound="hbm", check_f64=False, kl_streams=None):
     """One of BASELINE.json's non-headline single-GPU configs: iterations/s over `steps` steps after `warmup`,
     per-kernel device times (HIP events on the engine's stream, separate pass), the algorithmic work per
     iteration and the dominant kernel against the HBM roofline."""
@@ -548,6 +551,9 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
             flops, nbytes = flops(inner), nbytes(inner)
             paths = eng.inner_paths()
         dom = max((kn for kn in prof if kn in V_SIZED), key=lambda kn: prof[kn]["us_per_launch"])
+
+        def kl_streams_of(kn):          # (ADMM's fused auxiliaries launch always stores S: kl_streams = 4)
+            return (kl_streams if kl_streams and kn == "kl_vaux_fused" else KL_STREAMS.get(kn, 1))
         if repeat_dist is not None and dom in ("wphase", "hphase"):      # MUR: the same launch back to back (see main())
             prof[dom]["us_per_launch_with_event_per_launch"] = prof[dom]["us_per_launch"]
             prof[dom]["us_per_launch"] = round(eng.profile_repeat(dom, 20, repeat_dist) * 1e3, 2)
@@ -563,9 +569,9 @@ def other_config(torch, dev, name, workload, m, n, k, queue, steps, warmup, init
                 "tflops": flops / dt / 1e12, "hbm_gbs": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS,
                 "dominant_kernel": ({"name": dom, "us_per_launch": prof[dom]["us_per_launch"],
                                      # (the KL auxiliaries' update reads V and dual_v and writes dual_v -- and S, unless the launch forms the next product itself)
-                                     "algorithmic_bytes_per_launch": m * n * 4.0 * KL_STREAMS.get(dom, 1), "bound": "hbm",
-                                     "achieved_gbs": m * n * 4.0 * KL_STREAMS.get(dom, 1) / dsec / 1e9,
-                                     "frac": m * n * 4.0 * KL_STREAMS.get(dom, 1) / dsec / 1e9 / PEAK_HBM_GBS}
+                                     "algorithmic_bytes_per_launch": m * n * 4.0 * kl_streams_of(dom), "bound": "hbm",
+                                     "achieved_gbs": m * n * 4.0 * kl_streams_of(dom) / dsec / 1e9,
+                                     "frac": m * n * 4.0 * kl_streams_of(dom) / dsec / 1e9 / PEAK_HBM_GBS}
                                     if bound == "hbm" else
                                     # split bf16: every algorithmic product is three bf16 MFMA terms (hi hi + lo hi + hi lo)
                                     {"name": dom, "us_per_launch": prof[dom]["us_per_launch"], "bound": "mfma (split bf16: 3 executed terms per product)",
@@ -661,7 +667,9 @@ def other_configs(torch, dev, only=None):
         dict(name="admm_kl_on_cfg3_shape", workload="ADMM KL loss, rho = 1, reg_w = reg_h = (0, 'nn'), V=16384x8192 f32, k=128 (split bf16)",
              m=16384, n=8192, k=128, steps=8, warmup=2, init="rand_kl",
              queue=lambda e, f, c: e.admm_run(1, 1.0, 0, 0.0, 0, 0.0, NEVER, 1e-3, 1e-3, f, c),
-             flops=8.0 * 16384 * 8192 * 128, nbytes=7.0 * 16384 * 8192 * 4),
+             # (V-sized streams per iteration: the auxiliaries read V and dual_v and write dual_v and S -- their launch also forms the next
+             #  iteration's first product from S in registers (r5) --, the second product reads S, the objective pass reads V: 6; r4's sequence: 7 + a transpose)
+             flops=8.0 * 16384 * 8192 * 128, nbytes=6.0 * 16384 * 8192 * 4, kl_streams=4),
         # ADMM (nmf/admm.py:292-334) beyond 128 components: V-sized products with FOUR split-bf16 terms (they are fed back through the
         # unshifted-rho Gram systems), the objective of (w, h) by one more product; algorithmic work: three V-sized products
         dict(name="admm_k256_on_cfg2_shape", workload="ADMM Euclidean, rho = 1, reg_w = (0, 'nn'), reg_h = (0.1, 'l1n'), V=16384x8192 f32, k=256, "
