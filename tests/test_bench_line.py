@@ -51,3 +51,21 @@ def test_headline_without_optional_legs():
         d[k] = None
     line = bench.headline(d)
     assert line["cpu_baseline"] is None and line["parity"] is None and "cfg3" not in line
+
+
+def test_this_rounds_record_and_line_agree():
+    """profiles/r05_bench_n1.json is the line bench.py printed, profiles/r05_bench_n1_detail.json the record it was built from: the same
+    function gives the same line, and the fused KL-ADMM legs carry their stream counts (3 per AO-ADMM round, 4 for ADMM's stored S)."""
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")) as f:
+        printed = json.loads(f.read().strip().splitlines()[-1])
+    with open(os.path.join(ROOT, "profiles", "r05_bench_n1_detail.json")) as f:
+        detail = json.load(f)
+    assert len(json.dumps(printed)) < bench.HEADLINE_LIMIT
+    rebuilt = bench.headline(detail)
+    for key in ("value", "ms_per_step", "roofline", "cpu_baseline", "parity", "cfg3", "cfg4", "cfg5_on_1_gpu"):
+        assert rebuilt[key] == printed[key], key
+    legs = {leg["config"]: leg for leg in detail["other_configs"] if "config" in leg}
+    ao = legs["aoadmm_kl_on_cfg3_shape"]["dominant_kernel"]
+    assert ao["name"] == "kl_vaux_fused" and ao["algorithmic_bytes_per_launch"] == 3 * 16384 * 8192 * 4.0
+    assert 0.3 < ao["frac"] < 1.0
